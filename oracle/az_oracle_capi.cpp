@@ -1,0 +1,317 @@
+// az_oracle_capi.cpp -- CPU ORACLE (TEST INFRASTRUCTURE ONLY).
+//
+// extern "C" surface over az_oracle.hpp / az_oracle_games.hpp so that tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive the oracle
+// through ctypes.  Nothing in the shipped engine links this file.
+#include "az_oracle_games.hpp"
+
+#include <thread>
+
+using namespace azo;
+
+namespace {
+
+enum NetKind { NET_STUB = 0, NET_HASH = 1, NET_REPLAY = 2 };
+
+struct TreeBase {
+    virtual ~TreeBase() = default;
+    virtual int get_action_prob(uint64_t mine, uint64_t theirs, float temp, uint64_t seed, uint64_t game_id,
+                                float* pi, uint16_t* counts, float* q) = 0;
+    virtual SearchStats stats() = 0;
+    virtual size_t n_nodes() = 0;
+};
+
+C4Array array_from_bits(uint64_t mine, uint64_t theirs, bool literal) {
+    C4Array g;
+    g.literal_windows = literal;
+    for (int c = 0; c < C4_W; ++c)
+        for (int row = 0; row < C4_H; ++row) {
+            uint64_t bit = 1ull << (c * 7 + row);
+            int r = C4_H - 1 - row;
+            if (mine & bit) { g.s[r][c] = 1; g.heights[c] = (uint8_t)(row + 1); }
+            else if (theirs & bit) { g.s[r][c] = -1; g.heights[c] = (uint8_t)(row + 1); }
+        }
+    return g;
+}
+
+template <class G> G make_state(uint64_t mine, uint64_t theirs, const Quirks& q);
+template <> C4Bits make_state<C4Bits>(uint64_t mine, uint64_t theirs, const Quirks&) { return C4Bits{mine, theirs}; }
+template <> C4Array make_state<C4Array>(uint64_t mine, uint64_t theirs, const Quirks& q) {
+    return array_from_bits(mine, theirs, q.b6_literal_windows);
+}
+
+struct NetBox {
+    StubNet stub;
+    HashNet hash;
+    ReplayNet replay;
+    NNet* get(int kind) {
+        if (kind == NET_STUB) return &stub;
+        if (kind == NET_HASH) return &hash;
+        return &replay;
+    }
+};
+
+template <class G>
+struct TreeImpl : TreeBase {
+    NetBox nets;
+    std::unique_ptr<AsyncMcts<G>> mcts;
+    Quirks quirks;
+    // eval records (for replay parity the other way round and for debugging)
+    std::vector<uint64_t> rec_states;
+    std::vector<float> rec_pi, rec_v;
+
+    int get_action_prob(uint64_t mine, uint64_t theirs, float temp, uint64_t seed, uint64_t game_id, float* pi,
+                        uint16_t* counts, float* q) override {
+        try {
+            G s = make_state<G>(mine, theirs, quirks);
+            uint64_t ply = (uint64_t)__builtin_popcountll(mine | theirs);
+            auto p = mcts->get_action_prob(s, temp, seed, game_id, ply, counts, q);
+            for (size_t i = 0; i < p.size(); ++i) pi[i] = p[i];
+            return 0;
+        } catch (const std::exception&) {
+            return -1;
+        }
+    }
+    SearchStats stats() override { return mcts->stats; }
+    size_t n_nodes() override { return mcts->nodes->size(); }
+};
+
+Quirks quirks_from_bits(uint32_t b) {
+    Quirks q;
+    q.b1_parent_action = b & 1;
+    q.b2_same_sign_backup = b & 2;
+    q.b4_literal_z = b & 4;
+    q.b6_literal_windows = b & 8;
+    return q;
+}
+
+template <class G>
+TreeBase* make_tree(int has_root, uint64_t mine, uint64_t theirs, size_t reserve, size_t sims, size_t max_depth,
+                    size_t model_id, int cpuct, int net_kind, uint64_t salt, uint32_t qbits) {
+    auto* t = new TreeImpl<G>();
+    t->quirks = quirks_from_bits(qbits);
+    t->nets.hash.salt = salt;
+    NNet* net = t->nets.get(net_kind);
+    if (has_root)
+        t->mcts.reset(new AsyncMcts<G>(make_state<G>(mine, theirs, t->quirks), reserve, sims, 1, max_depth,
+                                       model_id, cpuct, net, C4_W));
+    else
+        t->mcts.reset(new AsyncMcts<G>(reserve, sims, 1, max_depth, model_id, cpuct, net, C4_W));
+    t->mcts->quirks = t->quirks;
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- packed counter, src/node.rs:16-93 -----------------------------------
+uint64_t azo_ctr_init() { return 0x7FFFFFFF00000000ull; }
+uint64_t azo_ctr_visit(uint64_t c) {
+    Node<DummyGame> n; n.win_counter.store(c); n.visit(); return n.win_counter.load();
+}
+uint64_t azo_ctr_unvisit(uint64_t c, float v, float scale) {
+    Node<DummyGame> n(scale); n.win_counter.store(c); n.unvisit(v); return n.win_counter.load();
+}
+float azo_ctr_w(uint64_t c, float scale) { Node<DummyGame> n(scale); n.win_counter.store(c); return n.get_w(); }
+uint32_t azo_ctr_n(uint64_t c) { Node<DummyGame> n; n.win_counter.store(c); return n.get_n(); }
+uint32_t azo_ctr_vloss(uint64_t c) { Node<DummyGame> n; n.win_counter.store(c); return n.get_vloss(); }
+float azo_ctr_q(uint64_t c, float scale) { Node<DummyGame> n(scale); n.win_counter.store(c); return n.compute_q(); }
+// PUCT term of best_child, src/node.rs:352-356 (C6)
+float azo_puct(uint64_t child_ctr, float prior, uint32_t parent_n, int32_t cpuct) {
+    Node<DummyGame> ch; ch.win_counter.store(child_ctr);
+    return ch.compute_q() +
+           (((float)cpuct * prior) * std::sqrt((float)(uint16_t)parent_n + EPS)) / (float)(uint16_t)(1 + ch.get_n());
+}
+
+// ---- RNG of the build -------------------------------------------------------
+uint64_t azo_rng_draw(uint64_t seed, uint64_t game_id, uint64_t ply, uint64_t purpose) {
+    return rng_draw(seed, game_id, ply, purpose);
+}
+uint32_t azo_rng_choose(uint64_t r, uint32_t k) { return rng_choose(r, k); }
+int azo_rng_choose_weighted(uint64_t r, const float* w, int n) { return rng_choose_weighted(r, w, n); }
+
+// ---- Connect Four on canonical (mine, theirs) bitboards --------------------
+// canonical successor: play `a` for the side to move, then swap sides
+void azo_c4_play(uint64_t mine, uint64_t theirs, int a, uint64_t* out2) {
+    C4Bits b{mine, theirs};
+    auto nx = b.get_next_state(1, (uint8_t)a);
+    C4Bits c = nx.first.get_canonical_form(nx.second);
+    out2[0] = c.p1; out2[1] = c.m1;
+}
+float azo_c4_ended(uint64_t mine, uint64_t theirs) { return C4Bits{mine, theirs}.get_game_ended(1); }
+float azo_c4_ended_array(uint64_t mine, uint64_t theirs, int literal) {
+    return array_from_bits(mine, theirs, literal != 0).get_game_ended(1);
+}
+int azo_c4_valid_mask(uint64_t mine, uint64_t theirs) {
+    auto v = C4Bits{mine, theirs}.get_valid_moves(1);
+    int m = 0;
+    for (int c = 0; c < C4_W; ++c) if (v[c]) m |= 1 << c;
+    return m;
+}
+void azo_c4_features(uint64_t mine, uint64_t theirs, float* out84) {
+    auto f = C4Bits{mine, theirs}.to_features();
+    std::memcpy(out84, f.data(), 84 * sizeof(float));
+}
+void azo_c4_features_array(uint64_t mine, uint64_t theirs, float* out84) {
+    auto f = array_from_bits(mine, theirs, false).to_features();
+    std::memcpy(out84, f.data(), 84 * sizeof(float));
+}
+uint64_t azo_c4_mirror(uint64_t b) { return C4Bits::mirror(b); }
+void azo_hashnet(uint64_t mine, uint64_t theirs, uint64_t salt, float* pi7, float* v) {
+    hashnet_eval(mine, theirs, salt, pi7, v);
+}
+
+// ---- AsyncMcts -------------------------------------------------------------
+void* azo_tree_new(int game_kind, int has_root, uint64_t mine, uint64_t theirs, uint64_t reserve, uint64_t sims,
+                   uint64_t max_depth, uint64_t model_id, int cpuct, int net_kind, uint64_t salt, uint32_t qbits) {
+    try {
+        if (game_kind == 0)
+            return make_tree<C4Bits>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits);
+        return make_tree<C4Array>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits);
+    } catch (const std::exception&) {
+        return nullptr;
+    }
+}
+void azo_tree_free(void* t) { delete (TreeBase*)t; }
+int azo_tree_get_action_prob(void* t, uint64_t mine, uint64_t theirs, float temp, uint64_t seed, uint64_t game_id,
+                             float* pi, uint16_t* counts, float* q) {
+    return ((TreeBase*)t)->get_action_prob(mine, theirs, temp, seed, game_id, pi, counts, q);
+}
+void azo_tree_stats(void* t, uint64_t* out7) {
+    SearchStats s = ((TreeBase*)t)->stats();
+    out7[0] = s.sims; out7[1] = s.expansions; out7[2] = s.leaf_evals; out7[3] = s.link_hits;
+    out7[4] = s.terminal_hits; out7[5] = s.depth_sum; out7[6] = ((TreeBase*)t)->n_nodes();
+}
+
+// ---- Coach::execute_episode x n_games ---------------------------------------
+// Outputs: boards [cap,2,6,7], pis [cap,7], zs [cap] (both symmetries per ply,
+// game-id order then ply order), game_len [n_games] plies, moves [n_games,42],
+// stats [6] summed over games.  Replay mode (net_kind 2): per-game record
+// ranges rec_off[n_games+1] into rec_states/rec_pi/rec_v; replay_bad[g] != 0
+// if the search asked for a different state or more records than were given.
+// Returns number of samples written, or -1 on error / overflow of cap.
+int64_t azo_selfplay(int64_t n_games, uint64_t first_game_id, uint64_t sims, uint64_t temp_threshold, int cpuct,
+                     uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind, uint64_t salt,
+                     int game_kind, uint32_t qbits, int threads, float* boards, float* pis, float* zs,
+                     int64_t cap, int32_t* game_len, uint8_t* moves, uint64_t* stats6, const int64_t* rec_off,
+                     const uint64_t* rec_states, const float* rec_pi, const float* rec_v, int32_t* replay_bad) {
+    struct PerGame { std::vector<TrainingSample> s; std::vector<uint8_t> moves; SearchStats st; bool bad = false; bool err = false; };
+    std::vector<PerGame> res((size_t)n_games);
+    auto run_one = [&](int64_t g) {
+        try {
+            NetBox nets;
+            nets.hash.salt = salt;
+            if (net_kind == NET_REPLAY) {
+                nets.replay.states = rec_states ? rec_states + 2 * rec_off[g] : nullptr;
+                nets.replay.pis = rec_pi + 7 * rec_off[g];
+                nets.replay.vs = rec_v + rec_off[g];
+                nets.replay.n = (size_t)(rec_off[g + 1] - rec_off[g]);
+            }
+            Quirks q = quirks_from_bits(qbits);
+            if (game_kind == 0) {
+                AsyncMcts<C4Bits> m(reserve, sims, 1, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
+                m.quirks = q;
+                res[g].s = execute_episode<C4Bits>(m, temp_threshold, seed, first_game_id + (uint64_t)g, &res[g].moves);
+                res[g].st = m.stats;
+            } else {
+                AsyncMcts<C4Array> m(reserve, sims, 1, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
+                m.quirks = q;
+                res[g].s = execute_episode<C4Array>(m, temp_threshold, seed, first_game_id + (uint64_t)g, &res[g].moves);
+                res[g].st = m.stats;
+            }
+            if (net_kind == NET_REPLAY) res[g].bad = nets.replay.mismatch || nets.replay.pos != nets.replay.n;
+        } catch (const std::exception&) {
+            res[g].err = true;
+        }
+    };
+    if (threads <= 1) {
+        for (int64_t g = 0; g < n_games; ++g) run_one(g);
+    } else {
+        std::atomic<int64_t> next{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&] { for (int64_t g; (g = next.fetch_add(1)) < n_games;) run_one(g); });
+        for (auto& th : pool) th.join();
+    }
+    int64_t n = 0;
+    SearchStats tot;
+    for (int64_t g = 0; g < n_games; ++g) {
+        if (res[g].err) return -1;
+        if (game_len) game_len[g] = (int32_t)res[g].moves.size();
+        if (moves) for (size_t i = 0; i < res[g].moves.size() && i < 42; ++i) moves[g * 42 + i] = res[g].moves[i];
+        if (replay_bad) replay_bad[g] = res[g].bad ? 1 : 0;
+        tot.sims += res[g].st.sims; tot.expansions += res[g].st.expansions; tot.leaf_evals += res[g].st.leaf_evals;
+        tot.link_hits += res[g].st.link_hits; tot.terminal_hits += res[g].st.terminal_hits; tot.depth_sum += res[g].st.depth_sum;
+        for (auto& ts : res[g].s) {
+            if (boards) {
+                if (n >= cap) return -1;
+                std::memcpy(boards + n * 84, ts.board.data(), 84 * sizeof(float));
+                std::memcpy(pis + n * 7, ts.pi.data(), 7 * sizeof(float));
+                zs[n] = ts.v;
+            }
+            ++n;
+        }
+    }
+    if (stats6) { stats6[0] = tot.sims; stats6[1] = tot.expansions; stats6[2] = tot.leaf_evals; stats6[3] = tot.link_hits; stats6[4] = tot.terminal_hits; stats6[5] = tot.depth_sum; }
+    return n;
+}
+
+// ---- arena::play_games (C16), per-game tree pair (B8) -----------------------
+// model slot 0 = new net (salt_new / model id 1), slot 1 = old net (model id 0).
+// results[g] (optional, [num]) = +1 first seat won, -1 second seat won, 0 draw.
+int azo_arena(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
+              uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
+    try {
+        uint64_t half = num / 2;
+        std::vector<int8_t> res(2 * half, 0);
+        auto run_one = [&](uint64_t gi) {
+            int first = gi < half ? 0 : 1;
+            NetBox nets;
+            nets.hash.salt = salt;
+            AsyncMcts<C4Bits> trees[2] = {
+                AsyncMcts<C4Bits>(reserve, sims, 1, max_depth, (size_t)new_model_id, cpuct, nets.get(net_kind), C4_W),
+                AsyncMcts<C4Bits>(reserve, sims, 1, max_depth, (size_t)old_model_id, cpuct, nets.get(net_kind), C4_W)};
+            auto mk = [&](int slot) {
+                return std::function<uint8_t(const C4Bits&)>([&trees, slot, seed, gi](const C4Bits& s) {
+                    uint64_t ply = (uint64_t)__builtin_popcountll(s.p1 | s.m1);
+                    auto p = trees[slot].get_action_prob(s, 0.0f, seed, gi, ply);   // src/coach.rs:369-372
+                    // argmax with max_by (last max), src/coach.rs:356-363
+                    size_t best = 0;
+                    for (size_t i = 1; i < p.size(); ++i) if (!(p[best] > p[i])) best = i;
+                    return (uint8_t)best;
+                });
+            };
+            std::function<uint8_t(const C4Bits&)> acts[2] = {mk(first), mk(1 - first)};
+            res[gi] = play_game<C4Bits>(acts, std::nullopt);
+        };
+        if (threads <= 1) {
+            for (uint64_t g = 0; g < 2 * half; ++g) run_one(g);
+        } else {
+            std::atomic<uint64_t> next{0};
+            std::vector<std::thread> pool;
+            std::atomic<bool> failed{false};
+            for (int t = 0; t < threads; ++t)
+                pool.emplace_back([&] {
+                    try { for (uint64_t g; (g = next.fetch_add(1)) < 2 * half;) run_one(g); }
+                    catch (...) { failed = true; }
+                });
+            for (auto& th : pool) th.join();
+            if (failed) return -1;
+        }
+        wld3[0] = wld3[1] = wld3[2] = 0;
+        for (uint64_t gi = 0; gi < 2 * half; ++gi) {
+            int first = gi < half ? 0 : 1;
+            int win_cond = first == 0 ? 1 : -1, lose_cond = first == 0 ? -1 : 1;   // src/arena.rs:80-81
+            if (res[gi] == win_cond) wld3[0]++;
+            else if (res[gi] == lose_cond) wld3[1]++;
+            else wld3[2]++;
+            if (results) results[gi] = res[gi];
+        }
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+}  // extern "C"
