@@ -1,0 +1,138 @@
+// az_common.h -- device/host helpers shared by the engine's HIP kernels.
+//
+// Everything here is integer work or IEEE f32 in a fixed operation order: the
+// engine is compiled with -ffp-contract=off and uses the *_rn intrinsics for the
+// PUCT term so results match the reference's arithmetic (src/node.rs:51-92,
+// :343-357) bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AZ_HD __host__ __device__ __forceinline__
+#define AZ_D __device__ __forceinline__
+
+namespace az {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int ACTIONS = 7;
+constexpr int PATH_CAP = 48;          // a Connect Four line has at most 42 plies
+constexpr int LANES = 8;              // lanes cooperating on one game (7 children + 1)
+
+// ---- node record (one uint4 per slot) ---------------------------------------
+// x: link  (NONE, or tree-local index of the canonical node: NodeLink.1, src/node.rs:129)
+// y: prior (f32 bits) of the edge parent->this slot: parent.mu.p[a], src/node.rs:354
+// z: meta  bits 0-2 a (src/node.rs:19) | 3-5 nchild | 6 expanded (mu.s is Some)
+//          | 7-8 ecode (e, src/node.rs:20) | 9 has_prior (mu.p is Some)
+// w: child_base (children are contiguous: src/node.rs:313-317)
+constexpr uint32_t META_A_MASK = 7u;
+constexpr uint32_t META_NCHILD_SHIFT = 3;
+constexpr uint32_t META_EXPANDED = 1u << 6;
+constexpr uint32_t META_ECODE_SHIFT = 7;
+constexpr uint32_t META_HAS_PRIOR = 1u << 9;
+
+// ecode <-> e (C9: e = -get_game_ended(1) of the canonical state)
+constexpr uint32_t E_NONE = 0, E_PLUS1 = 1, E_MINUS1 = 2, E_DRAW = 3;
+AZ_HD float ecode_value(uint32_t c) {
+    return c == E_PLUS1 ? 1.0f : (c == E_MINUS1 ? -1.0f : (c == E_DRAW ? -1e-4f : 0.0f));
+}
+
+// ---- packed win counter 0xWWWWWWWW_NNNN_VVVV, src/node.rs:17,36 ---------------
+constexpr uint64_t CTR_INIT = 0x7FFFFFFF00000000ull;
+constexpr uint64_t CTR_VISIT = 0x0000000000010001ull;   // src/node.rs:77-80
+constexpr float WIN_SCALE = 100.0f;                     // src/node.rs:13
+AZ_HD uint32_t ctr_n(uint64_t c) { return (uint32_t)((c >> 16) & 0xFFFFu); }
+AZ_HD uint32_t ctr_vloss(uint64_t c) { return (uint32_t)(c & 0xFFFFu); }
+// src/node.rs:83-92
+AZ_D uint64_t ctr_unvisit_delta(float win_val) {
+    uint32_t incr = (uint32_t)fabsf(__fmul_rn(WIN_SCALE, win_val));
+    uint64_t d = (win_val < 0.0f) ? ((uint64_t)incr << 32) : ((uint64_t)(0xFFFFFFFFu - incr) << 32);
+    return 1ull | d;
+}
+// src/node.rs:61-64 then :51-58
+AZ_D float ctr_w(uint64_t c) {
+    return __fdiv_rn((float)((int64_t)(c >> 32) - 0x7FFFFFFFll), WIN_SCALE);
+}
+AZ_D float ctr_q(uint64_t c) {
+    uint32_t n = ctr_n(c);
+    if (n == 0) return 0.0f;
+    return __fdiv_rn(__fsub_rn(ctr_w(c), (float)ctr_vloss(c)), (float)n);
+}
+// src/node.rs:352-356 (C6): q + ((cpuct*p) * sqrt(N_parent + 1e-6)) / (1 + n_child)
+AZ_D float puct(uint64_t child_ctr, float prior, float sqrt_parent, float cpuct_f) {
+    float denom = (float)((ctr_n(child_ctr) + 1u) & 0xFFFFu);   // u16 arithmetic
+    return __fadd_rn(ctr_q(child_ctr), __fdiv_rn(__fmul_rn(__fmul_rn(cpuct_f, prior), sqrt_parent), denom));
+}
+AZ_D float puct_sqrt_parent(uint32_t parent_n) { return __fsqrt_rn(__fadd_rn((float)parent_n, 1e-6f)); }
+
+// ---- RNG of the build ------------------------------------------
+AZ_HD uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t RNG_TIEBREAK = 1, RNG_MOVE = 2, RNG_WEIGHTS = 3;
+AZ_HD uint64_t rng_draw(uint64_t seed, uint64_t game_id, uint64_t ply, uint64_t purpose) {
+    return mix64(mix64(mix64(mix64(seed) ^ game_id) ^ ply) ^ purpose);
+}
+AZ_HD uint32_t rng_choose(uint64_t r, uint32_t k) { return (uint32_t)(((r >> 32) * (uint64_t)k) >> 32); }
+
+// ---- Connect Four on canonical bitboards (connect_four_game.rs:81-238) --------
+// bit(col,row) = col*7 + row, row 0 = bottom; `mine` = side to move.
+constexpr uint64_t C4_FULL = 0x3Full | (0x3Full << 7) | (0x3Full << 14) | (0x3Full << 21) | (0x3Full << 28) |
+                             (0x3Full << 35) | (0x3Full << 42);
+AZ_HD uint64_t c4_top(int c) { return 1ull << (c * 7 + 5); }
+AZ_HD bool c4_has_four(uint64_t b) {
+    uint64_t m;
+    m = b & (b >> 1); if (m & (m >> 2)) return true;
+    m = b & (b >> 7); if (m & (m >> 14)) return true;
+    m = b & (b >> 6); if (m & (m >> 12)) return true;
+    m = b & (b >> 8); if (m & (m >> 16)) return true;
+    return false;
+}
+// valid-move bitmask (bit c set <=> heights[c] < 6), connect_four_game.rs:105-110
+AZ_HD uint32_t c4_valid_mask(uint64_t mine, uint64_t theirs) {
+    uint64_t mask = mine | theirs;
+    uint32_t v = 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) v |= (mask & c4_top(c)) ? 0u : (1u << c);
+    return v;
+}
+// get_next_state(1, a) then get_canonical_form(next_player): connect_four_game.rs:90-103, :198-203 (B5)
+AZ_HD void c4_play(uint64_t mine, uint64_t theirs, int a, uint64_t* nmine, uint64_t* ntheirs) {
+    uint64_t mask = mine | theirs;
+    uint64_t nb = (mask + (1ull << (a * 7))) & (0x3Full << (a * 7));
+    *nmine = theirs;
+    *ntheirs = mine | nb;
+}
+// ecode of a canonical state: e = -get_game_ended(1), connect_four_game.rs:112-196 (B6), src/node.rs:293-294
+AZ_HD uint32_t c4_ecode(uint64_t mine, uint64_t theirs) {
+    if (c4_has_four(mine)) return E_MINUS1;        // ended = +1 (unreachable in legal play)
+    if (c4_has_four(theirs)) return E_PLUS1;       // ended = -1: the player who moved in has won
+    if ((mine | theirs) == C4_FULL) return E_DRAW; // ended = DRAW_EPS
+    return E_NONE;
+}
+AZ_HD uint64_t c4_mirror(uint64_t b) {
+    uint64_t r = 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) r |= ((b >> (c * 7)) & 0x7Full) << ((6 - c) * 7);
+    return r;
+}
+// feature (plane, row-from-top, col) of a canonical state, connect_four_game.rs:219-237 (S8)
+AZ_HD float c4_feature(uint64_t mine, uint64_t theirs, int plane, int r, int c) {
+    uint64_t bit = 1ull << (c * 7 + (5 - r));
+    return ((plane == 0 ? mine : theirs) & bit) ? 1.0f : 0.0f;
+}
+AZ_HD uint32_t c4_hash(uint64_t mine, uint64_t theirs) { return (uint32_t)mix64(mine ^ mix64(theirs)); }
+
+// test-fixture net (exact in f32); oracle twin: hashnet_eval in oracle/az_oracle_games.hpp
+AZ_HD void hashnet_eval(uint64_t mine, uint64_t theirs, uint64_t salt, float* pi, float* v) {
+    uint64_t h = mix64(mine ^ mix64(theirs ^ mix64(salt)));
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+        pi[a] = (float)(uint32_t)((mix64(h + (uint64_t)a) >> 40) + 1) * (1.0f / 16777216.0f);
+    *v = (float)(uint32_t)(mix64(h + 7) >> 40) * (1.0f / 8388608.0f) - 1.0f;
+}
+
+}  // namespace az

@@ -1,0 +1,713 @@
+// az_engine.hip -- C-ABI implementation (include/az_engine.h): host orchestration of the
+// tree kernels (az_tree.hip) and the nets (az_net.hip) on one HIP stream.
+//
+// There is NO CPU fallback: every entry point runs the HIP kernels or fails with a status.
+#include "../../include/az_engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "az_net.h"
+#include "az_tree.h"
+
+using namespace az;
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct HipFail { hipError_t code; const char* what; };
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw HipFail{_e, #expr}; } while (0)
+
+struct DeviceMem {
+    std::vector<void*> ptrs;
+    template <class T> T* alloc(size_t n) {
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+    ~DeviceMem() { release(); }
+};
+
+struct NetModel {
+    int kind = -1;
+    uint64_t salt = 0;
+    ConvNet* conv = nullptr;
+};
+
+// timed regions (profile mode): event pairs recorded on the engine stream, resolved at sync points
+enum Region { RG_TREE = 0, RG_NET = 1, RG_COUNT };
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    struct Rec { hipEvent_t a, b; int region; };
+    std::vector<Rec> open;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+    hipEvent_t begin(hipStream_t s) { hipEvent_t a = get(); HIPCHK(hipEventRecord(a, s)); return a; }
+    void end(hipEvent_t a, int region, hipStream_t s) {
+        hipEvent_t b = get();
+        HIPCHK(hipEventRecord(b, s));
+        open.push_back({a, b, region});
+    }
+    // call after the stream has been synchronised
+    void resolve(double* ms_by_region) {
+        for (auto& r : open) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) ms_by_region[r.region] += ms;
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        open.clear();
+    }
+    ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+struct TreeHost {
+    DeviceMem mem;
+    TreeDev d{};
+    EvalBatch eb{};
+    void create(int G, uint64_t R, uint32_t H, int log_cap) {
+        d.G = G; d.R = (uint32_t)R; d.H = H;
+        size_t slots = (size_t)G * R;
+        d.rec = mem.alloc<uint4>(slots);
+        d.ctr = mem.alloc<uint64_t>(slots);
+        d.state = mem.alloc<ulonglong2>(slots);
+        d.hash = mem.alloc<uint32_t>((size_t)G * H);
+        d.len = mem.alloc<uint32_t>(G);
+        d.root = mem.alloc<uint32_t>(G);
+        d.active = mem.alloc<uint8_t>(G);
+        d.path = mem.alloc<uint32_t>((size_t)G * PATH_CAP);
+        d.path_len = mem.alloc<uint32_t>(G);
+        d.leaf = mem.alloc<uint32_t>(G);
+        d.leaf_kind = mem.alloc<uint32_t>(G);
+        d.leaf_val = mem.alloc<float>(G);
+        d.slot_of = mem.alloc<int32_t>(G);
+        d.err = mem.alloc<uint32_t>(ERR_COUNT);
+        d.stat = mem.alloc<uint64_t>((size_t)G * ST_COUNT);
+        d.log_cap = log_cap;
+        d.log_len = mem.alloc<uint32_t>(G);
+        d.log_state = mem.alloc<ulonglong2>((size_t)G * std::max(log_cap, 0));
+        d.log_pi = mem.alloc<float>((size_t)G * std::max(log_cap, 0) * 7);
+        d.log_v = mem.alloc<float>((size_t)G * std::max(log_cap, 0));
+        HIPCHK(hipMemset(d.err, 0, ERR_COUNT * sizeof(uint32_t)));
+        HIPCHK(hipMemset(d.stat, 0, (size_t)G * ST_COUNT * sizeof(uint64_t)));
+        HIPCHK(hipMemset(d.log_len, 0, G * sizeof(uint32_t)));
+        HIPCHK(hipMemset(d.active, 1, G));
+        HIPCHK(hipMemset(d.leaf_kind, 0, G * sizeof(uint32_t)));
+        eb.cap = G;
+        eb.n = mem.alloc<uint32_t>(1);
+        eb.tree = mem.alloc<uint32_t>(G);
+        eb.state = mem.alloc<ulonglong2>(G);
+        eb.pi = mem.alloc<float>((size_t)G * 8);
+        eb.v = mem.alloc<float>(G);
+        HIPCHK(hipMemset(eb.n, 0, sizeof(uint32_t)));
+    }
+};
+
+uint32_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return (uint32_t)p;
+}
+// Largest tree an episode of <= `calls` get_action_prob calls can build: the initial root + 7,
+// per call one fresh root (S10) and num_sims expansions, 7 placeholders each.
+uint64_t reachable_slots(int num_sims, int calls) {
+    return 8ull + (uint64_t)calls * ((uint64_t)num_sims * 7ull + 8ull);
+}
+uint32_t hash_entries(int num_sims, int calls) {
+    return next_pow2(2ull * ((uint64_t)calls * ((uint64_t)num_sims + 1) + 2));
+}
+
+}  // namespace
+
+struct az_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    az_config cfg{};
+    std::string err;
+    std::map<int, NetModel> nets;
+    az_stats stats{};
+    Profiler prof;
+    NetProfile netprof;
+    // eval log of the last az_selfplay
+    std::vector<int32_t> sp_log_count;
+    std::vector<uint64_t> sp_log_states;
+    std::vector<float> sp_log_pi, sp_log_v;
+    int sp_log_cap = 0;
+};
+
+struct az_tree {
+    az_engine* e = nullptr;
+    TreeHost th;
+    DeviceMem mem;
+    int num_sims = 0, max_depth = 0, model_id = 0, cpuct = 0;
+    ulonglong2* d_root_states = nullptr;
+    float* d_pi = nullptr;
+    uint16_t* d_counts = nullptr;
+    float* d_q = nullptr;
+};
+
+namespace {
+
+az_status fail(az_engine* e, az_status st, const std::string& msg) {
+    if (e) e->err = msg;
+    return st;
+}
+az_status fail_hip(az_engine* e, const HipFail& f) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "HIP error %d (%s) at %s", (int)f.code, hipGetErrorString(f.code), f.what);
+    return fail(e, AZ_ERR_HIP, buf);
+}
+
+void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int rows_hint) {
+    if (net.kind == AZ_NET_CONV) {
+        convnet_forward(net.conv, eb, rows_hint, e->stream, e->prof.on ? &e->netprof : nullptr);
+    } else {
+        launch_net_fixture(eb, net.kind, net.salt, e->stream);
+    }
+}
+
+// get_action_prob body shared by every entry point: S10/S1 prologue, then num_sims x
+// {select+expand, compact, predict, mask+store+backup}  (src/async_mcts.rs:81-82, :191-217).
+void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int num_sims, SearchParams sp,
+                const NetModel& net) {
+    hipStream_t s = e->stream;
+    launch_root_prepare(th.d, d_root_states, s);
+    launch_compact(th.d, th.eb, s);
+    net_forward(e, net, th.eb, th.d.G);
+    launch_backup(th.d, th.eb, 1, s);
+    for (int i = 0; i < num_sims; ++i) {
+        hipEvent_t t0 = nullptr;
+        if (e->prof.on) t0 = e->prof.begin(s);
+        launch_select(th.d, sp, s);
+        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
+        launch_compact(th.d, th.eb, s);
+        if (e->prof.on) t0 = e->prof.begin(s);
+        net_forward(e, net, th.eb, th.d.G);
+        if (e->prof.on) { e->prof.end(t0, RG_NET, s); t0 = e->prof.begin(s); }
+        launch_backup(th.d, th.eb, 0, s);
+        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
+    }
+}
+
+void resolve_profile(az_engine* e) {
+    if (!e->prof.on) return;
+    double ms[RG_COUNT] = {0, 0};
+    e->prof.resolve(ms);
+    e->stats.tree_ms += ms[RG_TREE];
+    e->stats.net_total_ms += ms[RG_NET];
+}
+
+// fold the per-tree counters into the engine stats and clear them
+void harvest_stats(az_engine* e, TreeHost& th) {
+    std::vector<uint64_t> h((size_t)th.d.G * ST_COUNT);
+    HIPCHK(hipMemcpy(h.data(), th.d.stat, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(th.d.stat, 0, h.size() * sizeof(uint64_t)));
+    uint64_t sims = 0, depth = 0;
+    for (int g = 0; g < th.d.G; ++g) {
+        const uint64_t* st = &h[(size_t)g * ST_COUNT];
+        sims += st[ST_SIMS];
+        e->stats.expansions += st[ST_EXPANSIONS];
+        e->stats.leaf_evals += st[ST_LEAF_EVALS];
+        e->stats.link_hits += st[ST_LINK_HITS];
+        e->stats.terminal_hits += st[ST_TERMINAL_HITS];
+        depth += st[ST_DEPTH_SUM];
+    }
+    e->stats.simulations += sims;
+    e->stats.depth_sum += depth;
+    // algorithmic tree bytes per simulation, SURVEY.md 8(d): 128 per selection level + 356 per expansion
+    e->stats.tree_bytes += 128.0 * (double)depth + 356.0 * (double)sims;
+}
+
+az_status check_tree_errors(az_engine* e, TreeHost& th) {
+    uint32_t h[ERR_COUNT];
+    HIPCHK(hipMemcpy(h, th.d.err, sizeof h, hipMemcpyDeviceToHost));
+    if (h[ERR_CAPACITY] || h[ERR_HASH_FULL] || h[ERR_PATH] || h[ERR_TERMINAL_ROOT])
+        HIPCHK(hipMemset(th.d.err, 0, sizeof h));
+    if (h[ERR_CAPACITY]) return fail(e, AZ_ERR_CAPACITY, "node arena exhausted (reserve too small; src/node.rs:237)");
+    if (h[ERR_HASH_FULL]) return fail(e, AZ_ERR_CAPACITY, "transposition table full");
+    if (h[ERR_PATH]) return fail(e, AZ_ERR_CAPACITY, "node_path overflow");
+    if (h[ERR_TERMINAL_ROOT]) return fail(e, AZ_ERR_TERMINAL_ROOT, "get_action_prob on a finished game (src/async_mcts.rs:85)");
+    return AZ_OK;
+}
+
+az_status find_net(az_engine* e, int model_id, NetModel** out) {
+    auto it = e->nets.find(model_id);
+    if (it == e->nets.end() || it->second.kind < 0) return fail(e, AZ_ERR_NO_MODEL, "model id not initialised");
+    *out = &it->second;
+    return AZ_OK;
+}
+
+struct ScopedTimer {
+    az_engine* e;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~ScopedTimer() {
+        e->stats.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+az_status az_create(const az_config* cfg, az_engine** out) {
+    if (!out) return AZ_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<az_engine> e(new az_engine());
+    if (cfg) e->cfg = *cfg;
+    if (e->cfg.max_batch <= 0) e->cfg.max_batch = 8192;
+    if (e->cfg.net_channels <= 0) e->cfg.net_channels = 512;
+    e->device = e->cfg.device;
+    e->prof.on = e->cfg.profile != 0;
+    try {
+        int n = 0;
+        HIPCHK(hipGetDeviceCount(&n));
+        if (n <= 0 || e->device >= n) return AZ_ERR_HIP;
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipStreamCreate(&e->stream));
+    } catch (const HipFail&) {
+        return AZ_ERR_HIP;
+    }
+    *out = e.release();
+    return AZ_OK;
+}
+
+void az_destroy(az_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->nets) if (kv.second.conv) convnet_destroy(kv.second.conv);
+    { double ms[RG_COUNT] = {0, 0}; e->prof.resolve(ms); }
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* az_last_error(const az_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+az_status az_get_stats(az_engine* e, az_stats* out) {
+    if (!e || !out) return AZ_ERR_BAD_ARGUMENT;
+    *out = e->stats;
+    out->net_launches = e->netprof.launches;
+    out->net_conv2_ms = e->netprof.conv2_ms;
+    out->net_conv2_flops = e->netprof.conv2_flops;
+    out->net_total_flops = e->netprof.total_flops;
+    return AZ_OK;
+}
+az_status az_reset_stats(az_engine* e) {
+    if (!e) return AZ_ERR_BAD_ARGUMENT;
+    e->stats = az_stats{};
+    e->netprof = NetProfile{};
+    return AZ_OK;
+}
+
+// ---- NNet ------------------------------------------------------------------------------------
+az_status az_net_set_kind(az_engine* e, int32_t model_id, az_net_kind kind, uint64_t salt) {
+    if (!e || (kind != AZ_NET_STUB && kind != AZ_NET_HASH)) return fail(e, AZ_ERR_BAD_ARGUMENT, "kind must be STUB or HASH");
+    NetModel& m = e->nets[model_id];
+    m.kind = kind;
+    // two hash nets with the same salt but different model ids differ (oracle: HashNet::predict)
+    m.salt = salt + (uint64_t)model_id * 0x51ED27ull;
+    return AZ_OK;
+}
+
+static az_status ensure_conv(az_engine* e, int32_t model_id, NetModel** out) {
+    NetModel& m = e->nets[model_id];
+    if (!m.conv) {
+        const char* why = nullptr;
+        m.conv = convnet_create(e->cfg.net_channels, e->cfg.max_batch, &why);
+        if (!m.conv) return fail(e, AZ_ERR_HIP, why ? why : "convnet_create failed");
+    }
+    *out = &m;
+    return AZ_OK;
+}
+
+az_status az_net_init_random(az_engine* e, int32_t model_id, uint64_t seed) {
+    if (!e) return AZ_ERR_BAD_ARGUMENT;
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        NetModel* m;
+        az_status st = ensure_conv(e, model_id, &m);
+        if (st) return st;
+        convnet_init_random(m->conv, seed);
+        m->kind = AZ_NET_CONV;
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+int64_t az_net_param_count(const az_engine* e) { return e ? convnet_param_count(e->cfg.net_channels) : 0; }
+
+az_status az_net_set_params(az_engine* e, int32_t model_id, const float* params, int64_t n) {
+    if (!e || !params) return AZ_ERR_BAD_ARGUMENT;
+    if (n != convnet_param_count(e->cfg.net_channels)) return fail(e, AZ_ERR_BAD_ARGUMENT, "parameter count mismatch");
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        NetModel* m;
+        az_status st = ensure_conv(e, model_id, &m);
+        if (st) return st;
+        if (!convnet_set_params(m->conv, params, n)) return fail(e, AZ_ERR_HIP, "convnet_set_params failed");
+        m->kind = AZ_NET_CONV;
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_net_get_params(az_engine* e, int32_t model_id, float* params, int64_t n) {
+    if (!e || !params) return AZ_ERR_BAD_ARGUMENT;
+    NetModel* m;
+    az_status st = find_net(e, model_id, &m);
+    if (st) return st;
+    if (m->kind != AZ_NET_CONV) return fail(e, AZ_ERR_BAD_ARGUMENT, "model has no parameters");
+    if (!convnet_get_params(m->conv, params, n)) return fail(e, AZ_ERR_BAD_ARGUMENT, "parameter count mismatch");
+    return AZ_OK;
+}
+
+az_status az_net_save(az_engine* e, int32_t model_id, const char* path) {
+    if (!e || !path) return AZ_ERR_BAD_ARGUMENT;
+    int64_t n = az_net_param_count(e);
+    std::vector<float> p((size_t)n);
+    az_status st = az_net_get_params(e, model_id, p.data(), n);
+    if (st) return st;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(e, AZ_ERR_IO, std::string("cannot write ") + path);
+    const char magic[8] = {'A', 'Z', 'N', 'E', 'T', '0', '0', '1'};
+    int64_t hdr[2] = {(int64_t)e->cfg.net_channels, n};
+    bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(hdr, sizeof(int64_t), 2, f) == 2 &&
+              std::fwrite(p.data(), sizeof(float), (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    return ok ? AZ_OK : fail(e, AZ_ERR_IO, "short write");
+}
+
+az_status az_net_load(az_engine* e, int32_t model_id, const char* path) {
+    if (!e || !path) return AZ_ERR_BAD_ARGUMENT;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(e, AZ_ERR_IO, std::string("cannot read ") + path);
+    char magic[8];
+    int64_t hdr[2];
+    int64_t n = az_net_param_count(e);
+    std::vector<float> p((size_t)n);
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "AZNET001", 8) == 0 &&
+              std::fread(hdr, sizeof(int64_t), 2, f) == 2 && hdr[0] == e->cfg.net_channels && hdr[1] == n &&
+              std::fread(p.data(), sizeof(float), (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    if (!ok) return fail(e, AZ_ERR_IO, "bad or mismatching weights file");
+    return az_net_set_params(e, model_id, p.data(), n);
+}
+
+az_status az_net_predict_states(az_engine* e, int32_t model_id, const uint64_t* states, int32_t B, float* pi, float* v) {
+    if (!e || !states || !pi || !v || B < 0) return AZ_ERR_BAD_ARGUMENT;
+    NetModel* m;
+    az_status st = find_net(e, model_id, &m);
+    if (st) return st;
+    ScopedTimer timer{e};
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        DeviceMem mem;
+        const int chunk = e->cfg.max_batch;
+        EvalBatch eb{};
+        eb.cap = chunk;
+        eb.n = mem.alloc<uint32_t>(1);
+        eb.tree = mem.alloc<uint32_t>(chunk);
+        eb.state = mem.alloc<ulonglong2>(chunk);
+        eb.pi = mem.alloc<float>((size_t)chunk * 8);
+        eb.v = mem.alloc<float>(chunk);
+        std::vector<float> hp((size_t)chunk * 8);
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            uint32_t nb = (uint32_t)std::min(chunk, B - b0);
+            HIPCHK(hipMemcpyAsync(eb.n, &nb, sizeof nb, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(eb.state, states + 2 * (size_t)b0, (size_t)nb * 16, hipMemcpyDefault, e->stream));
+            net_forward(e, *m, eb, (int)nb);
+            HIPCHK(hipMemcpyAsync(hp.data(), eb.pi, (size_t)nb * 8 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            std::vector<float> packed((size_t)nb * 7);
+            for (uint32_t i = 0; i < nb; ++i)
+                for (int a = 0; a < 7; ++a) packed[(size_t)i * 7 + a] = hp[(size_t)i * 8 + a];
+            HIPCHK(hipMemcpy(pi + (size_t)b0 * 7, packed.data(), packed.size() * sizeof(float), hipMemcpyDefault));
+            HIPCHK(hipMemcpy(v + b0, eb.v, (size_t)nb * sizeof(float), hipMemcpyDefault));
+        }
+        resolve_profile(e);
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_net_predict(az_engine* e, int32_t model_id, const float* boards, int32_t B, float* pi, float* v) {
+    if (!e || !boards || B < 0) return AZ_ERR_BAD_ARGUMENT;
+    try {
+        // [B,2,6,7] f32 planes -> canonical bitboards (the planes are 0/1 by contract, connect_four_game.rs:227-233)
+        std::vector<float> hb((size_t)B * AZ_FEATURES);
+        HIPCHK(hipMemcpy(hb.data(), boards, hb.size() * sizeof(float), hipMemcpyDefault));
+        std::vector<uint64_t> states((size_t)B * 2, 0);
+        for (int b = 0; b < B; ++b)
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 7; ++c) {
+                    uint64_t bit = 1ull << (c * 7 + (5 - r));
+                    if (hb[(size_t)b * 84 + r * 7 + c] != 0.0f) states[2 * b] |= bit;
+                    if (hb[(size_t)b * 84 + 42 + r * 7 + c] != 0.0f) states[2 * b + 1] |= bit;
+                }
+        return az_net_predict_states(e, model_id, states.data(), B, pi, v);
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_net_train(az_engine* e, int32_t, int32_t, const float*, const float*, const float*, int64_t) {
+    return fail(e, AZ_ERR_UNSUPPORTED, "NNet::train is the next tier (SURVEY.md 8f-2)");
+}
+
+// ---- AsyncMcts -------------------------------------------------------------------------------
+az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_t num_sims, int32_t max_depth,
+                         int32_t model_id, int32_t cpuct, az_tree** out) {
+    if (!e || !out || n_games <= 0 || num_sims <= 0 || reserve < 8 || max_depth < 0)
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_tree_create: bad argument");
+    if (n_games > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_tree_create: at most 65536 trees per batch");
+    *out = nullptr;
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        std::unique_ptr<az_tree> t(new az_tree());
+        t->e = e;
+        t->num_sims = num_sims; t->max_depth = max_depth; t->model_id = model_id; t->cpuct = cpuct;
+        uint64_t R = std::min<uint64_t>(reserve, reachable_slots(num_sims, AZ_MAX_PLIES));
+        t->th.create(n_games, R, hash_entries(num_sims, AZ_MAX_PLIES), 0);
+        t->d_root_states = t->mem.alloc<ulonglong2>(n_games);
+        t->d_pi = t->mem.alloc<float>((size_t)n_games * 7);
+        t->d_counts = t->mem.alloc<uint16_t>((size_t)n_games * 7);
+        t->d_q = t->mem.alloc<float>((size_t)n_games * 7);
+        launch_reset_trees(t->th.d, nullptr, e->stream);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        *out = t.release();
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+void az_tree_destroy(az_tree* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->e->device);
+    (void)hipStreamSynchronize(t->e->stream);
+    delete t;
+}
+
+az_status az_tree_record_evals(az_tree* t, int32_t cap) {
+    if (!t || cap < 0) return AZ_ERR_BAD_ARGUMENT;
+    try {
+        HIPCHK(hipSetDevice(t->e->device));
+        TreeDev& d = t->th.d;
+        d.log_cap = cap;
+        d.log_state = t->mem.alloc<ulonglong2>((size_t)d.G * cap);
+        d.log_pi = t->mem.alloc<float>((size_t)d.G * cap * 7);
+        d.log_v = t->mem.alloc<float>((size_t)d.G * cap);
+        HIPCHK(hipMemset(d.log_len, 0, d.G * sizeof(uint32_t)));
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(t->e, f); }
+}
+
+az_status az_tree_get_evals(az_tree* t, int32_t* rec_count, uint64_t* states, float* pis, float* vs) {
+    if (!t) return AZ_ERR_BAD_ARGUMENT;
+    try {
+        HIPCHK(hipSetDevice(t->e->device));
+        TreeDev& d = t->th.d;
+        size_t n = (size_t)d.G * d.log_cap;
+        if (rec_count) HIPCHK(hipMemcpy(rec_count, d.log_len, d.G * sizeof(uint32_t), hipMemcpyDefault));
+        if (states) HIPCHK(hipMemcpy(states, d.log_state, n * 16, hipMemcpyDefault));
+        if (pis) HIPCHK(hipMemcpy(pis, d.log_pi, n * 7 * sizeof(float), hipMemcpyDefault));
+        if (vs) HIPCHK(hipMemcpy(vs, d.log_v, n * sizeof(float), hipMemcpyDefault));
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(t->e, f); }
+}
+
+az_status az_tree_node_counts(az_tree* t, uint32_t* out) {
+    if (!t || !out) return AZ_ERR_BAD_ARGUMENT;
+    try {
+        HIPCHK(hipSetDevice(t->e->device));
+        HIPCHK(hipMemcpy(out, t->th.d.len, t->th.d.G * sizeof(uint32_t), hipMemcpyDefault));
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(t->e, f); }
+}
+
+az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp, uint64_t seed, uint64_t first_game_id,
+                                  float* pi, uint16_t* counts, float* q) {
+    if (!t || !states || !pi) return AZ_ERR_BAD_ARGUMENT;
+    az_engine* e = t->e;
+    NetModel* net;
+    az_status st = find_net(e, t->model_id, &net);
+    if (st) return st;
+    ScopedTimer timer{e};
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        TreeDev& d = t->th.d;
+        const int G = d.G;
+        HIPCHK(hipMemcpyAsync(t->d_root_states, states, (size_t)G * 16, hipMemcpyDefault, e->stream));
+        HIPCHK(hipMemsetAsync(d.active, 1, G, e->stream));
+        SearchParams sp{(uint32_t)t->max_depth, (float)t->cpuct};
+        run_search(e, t->th, t->d_root_states, t->num_sims, sp, *net);
+        launch_root_policy(d, temp, seed, first_game_id, t->d_pi, t->d_counts, t->d_q, e->stream);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        resolve_profile(e);
+        harvest_stats(e, t->th);
+        e->stats.moves += (uint64_t)G;
+        st = check_tree_errors(e, t->th);
+        if (st) return st;
+        HIPCHK(hipMemcpy(pi, t->d_pi, (size_t)G * 7 * sizeof(float), hipMemcpyDefault));
+        if (counts) HIPCHK(hipMemcpy(counts, t->d_counts, (size_t)G * 7 * sizeof(uint16_t), hipMemcpyDefault));
+        if (q) HIPCHK(hipMemcpy(q, t->d_q, (size_t)G * 7 * sizeof(float), hipMemcpyDefault));
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+// ---- Coach::execute_episode x many -----------------------------------------------------------
+az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out) {
+    if (!e || !p || !out) return AZ_ERR_BAD_ARGUMENT;
+    if (p->n_games <= 0 || p->num_sims <= 0 || p->max_depth < 0 || p->reserve < 8)
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: bad argument");
+    const int n_games = p->n_games;
+    const int C = (p->concurrent <= 0 || p->concurrent > n_games) ? n_games : p->concurrent;
+    if (C > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: at most 65536 concurrent games");
+    const int nsym = p->symmetries ? 2 : 1;
+    if (out->capacity < (int64_t)n_games * AZ_MAX_PLIES * nsym && out->capacity < 0)
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: negative capacity");
+    NetModel* net;
+    az_status st = find_net(e, p->model_id, &net);
+    if (st) return st;
+    ScopedTimer timer{e};
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        hipStream_t s = e->stream;
+        TreeHost th;
+        uint64_t R = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
+        th.create(C, R, hash_entries(p->num_sims, AZ_MAX_PLIES), p->record_evals);
+        DeviceMem mem;
+        GamesDev gd{};
+        gd.C = C;
+        gd.n_games = n_games;
+        gd.state = mem.alloc<ulonglong2>(C);
+        gd.player = mem.alloc<int8_t>(C);
+        gd.ply = mem.alloc<int32_t>(C);
+        gd.gid = mem.alloc<int32_t>(C);
+        gd.need_reset = mem.alloc<uint8_t>(C);
+        size_t ns = (size_t)n_games * 42;
+        gd.smp_state = mem.alloc<ulonglong2>(ns);
+        gd.smp_pi = mem.alloc<float>(ns * 7);
+        gd.smp_player = mem.alloc<int8_t>(ns);
+        gd.moves = mem.alloc<uint8_t>(ns);
+        gd.g_len = mem.alloc<int32_t>(n_games);
+        gd.g_result = mem.alloc<float>(n_games);
+        gd.g_final_player = mem.alloc<int8_t>(n_games);
+        gd.counters = mem.alloc<uint32_t>(4);
+        {
+            std::vector<int32_t> gid(C);
+            std::vector<int8_t> pl(C, 1);
+            for (int i = 0; i < C; ++i) gid[i] = i;
+            HIPCHK(hipMemcpy(gd.gid, gid.data(), C * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(gd.player, pl.data(), C, hipMemcpyHostToDevice));
+            HIPCHK(hipMemset(gd.state, 0, (size_t)C * 16));
+            HIPCHK(hipMemset(gd.ply, 0, C * sizeof(int32_t)));
+            HIPCHK(hipMemset(gd.need_reset, 0, C));
+            HIPCHK(hipMemset(gd.moves, 0, ns));
+            HIPCHK(hipMemset(gd.g_len, 0, n_games * sizeof(int32_t)));
+            uint32_t ctr[4] = {(uint32_t)C, 0u, (uint32_t)C, 0u};
+            HIPCHK(hipMemcpy(gd.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
+        }
+        // per-episode eval logs survive slot refills: they are copied out when the slot's episode ends.
+        // (record_evals is a test facility; it requires concurrent == n_games so that slot == episode.)
+        if (p->record_evals > 0 && C != n_games)
+            return fail(e, AZ_ERR_BAD_ARGUMENT, "record_evals needs concurrent == n_games");
+        launch_reset_trees(th.d, nullptr, s);
+        SearchParams sp{(uint32_t)p->max_depth, (float)p->cpuct};
+        SelfplayMoveParams mp{p->seed, p->first_game_id, p->temp_threshold, C < n_games ? 1 : 0};
+        uint32_t* h_ctr = nullptr;
+        HIPCHK(hipHostMalloc((void**)&h_ctr, 4 * sizeof(uint32_t)));
+        struct PinnedFree { uint32_t* p; ~PinnedFree() { (void)hipHostFree(p); } } pinned{h_ctr};
+        uint64_t moves = 0;
+        az_status result = AZ_OK;
+        for (int iter = 0;; ++iter) {
+            launch_selfplay_sync_active(th.d, gd, s);
+            run_search(e, th, gd.state, p->num_sims, sp, *net);
+            launch_selfplay_move(th.d, gd, mp, s);
+            if (mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
+            HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            resolve_profile(e);
+            ++moves;
+            if (h_ctr[1] >= (uint32_t)n_games) break;
+            if ((iter & 7) == 7 || h_ctr[2] == 0) {
+                result = check_tree_errors(e, th);
+                if (result) break;
+            }
+            if (iter > AZ_MAX_PLIES * (n_games / C + 2) + 8) {
+                result = fail(e, AZ_ERR_HIP, "az_selfplay: episode loop did not terminate");
+                break;
+            }
+        }
+        harvest_stats(e, th);
+        if (result == AZ_OK) result = check_tree_errors(e, th);
+        if (result) return result;
+        // offsets (host prefix sum over n_games plies) and emit
+        std::vector<int32_t> glen(n_games);
+        HIPCHK(hipMemcpy(glen.data(), gd.g_len, n_games * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<int64_t> off(n_games);
+        int64_t total = 0;
+        for (int i = 0; i < n_games; ++i) { off[i] = total; total += glen[i]; }
+        e->stats.games += (uint64_t)n_games;
+        e->stats.moves += (uint64_t)total;
+        e->stats.samples += (uint64_t)total;
+        out->count = total * nsym;
+        if (out->capacity < out->count) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: sample buffers too small");
+        if (out->pis && out->zs) {
+            int64_t* d_off = mem.alloc<int64_t>(n_games);
+            HIPCHK(hipMemcpy(d_off, off.data(), n_games * sizeof(int64_t), hipMemcpyHostToDevice));
+            size_t cnt = (size_t)out->count;
+            ulonglong2* d_states = out->states ? mem.alloc<ulonglong2>(cnt) : nullptr;
+            float* d_boards = out->boards ? mem.alloc<float>(cnt * 84) : nullptr;
+            float* d_pis = mem.alloc<float>(cnt * 7);
+            float* d_zs = mem.alloc<float>(cnt);
+            launch_emit_samples(gd, d_off, p->symmetries, d_states, d_boards, d_pis, d_zs, s);
+            HIPCHK(hipStreamSynchronize(s));
+            if (d_states) HIPCHK(hipMemcpy(out->states, d_states, cnt * 16, hipMemcpyDefault));
+            if (d_boards) HIPCHK(hipMemcpy(out->boards, d_boards, cnt * 84 * sizeof(float), hipMemcpyDefault));
+            HIPCHK(hipMemcpy(out->pis, d_pis, cnt * 7 * sizeof(float), hipMemcpyDefault));
+            HIPCHK(hipMemcpy(out->zs, d_zs, cnt * sizeof(float), hipMemcpyDefault));
+        }
+        if (out->game_len) HIPCHK(hipMemcpy(out->game_len, glen.data(), n_games * sizeof(int32_t), hipMemcpyDefault));
+        if (out->moves) HIPCHK(hipMemcpy(out->moves, gd.moves, ns, hipMemcpyDefault));
+        if (p->record_evals > 0) {
+            const int cap = p->record_evals;
+            e->sp_log_cap = cap;
+            e->sp_log_count.resize(n_games);
+            e->sp_log_states.resize((size_t)n_games * cap * 2);
+            e->sp_log_pi.resize((size_t)n_games * cap * 7);
+            e->sp_log_v.resize((size_t)n_games * cap);
+            HIPCHK(hipMemcpy(e->sp_log_count.data(), th.d.log_len, n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(e->sp_log_states.data(), th.d.log_state, e->sp_log_states.size() * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(e->sp_log_pi.data(), th.d.log_pi, e->sp_log_pi.size() * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(e->sp_log_v.data(), th.d.log_v, e->sp_log_v.size() * 4, hipMemcpyDeviceToHost));
+        }
+        (void)moves;
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_selfplay_get_evals(az_engine* e, int32_t* rec_count, uint64_t* states, float* pis, float* vs) {
+    if (!e || e->sp_log_cap <= 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "no eval log (run az_selfplay with record_evals > 0)");
+    if (rec_count) std::memcpy(rec_count, e->sp_log_count.data(), e->sp_log_count.size() * sizeof(int32_t));
+    if (states) std::memcpy(states, e->sp_log_states.data(), e->sp_log_states.size() * 8);
+    if (pis) std::memcpy(pis, e->sp_log_pi.data(), e->sp_log_pi.size() * 4);
+    if (vs) std::memcpy(vs, e->sp_log_v.data(), e->sp_log_v.size() * 4);
+    return AZ_OK;
+}
+
+az_status az_arena(az_engine* e, const az_arena_params*, uint64_t*, int8_t*) {
+    return fail(e, AZ_ERR_UNSUPPORTED, "az_arena: not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+// az_net.h -- NNet::predict on the device (src/nnet.rs:35-45).
+//
+// Three nets answer a leaf batch: the reference's stub (examples/connect_four.rs:12-43),
+// a deterministic test fixture, and the policy+value conv net of
+// connect_four_net.py:20-95 as bf16 MFMA kernels (az_net.hip).
+#pragma once
+#include "az_tree.h"
+
+namespace az {
+
+struct ConvNet;   // weights + activation workspace, az_net.hip
+
+struct NetProfile {          // filled when profiling is on
+    double conv2_ms = 0, conv2_flops = 0, total_ms = 0, total_flops = 0;
+    uint64_t launches = 0;
+};
+
+// pi = 1/7, v = +1 (kind 0) or the hash fixture (kind 1) for rows [0, *eb.n)
+void launch_net_fixture(const EvalBatch& eb, int kind, uint64_t salt, hipStream_t s);
+
+ConvNet* convnet_create(int channels, int max_batch, const char** err);
+void convnet_destroy(ConvNet* n);
+int64_t convnet_param_count(int channels);
+// raw f32 parameters (layout: DESIGN.md "weights file"); BN is folded and weights are
+// rounded to bf16 on upload.
+bool convnet_set_params(ConvNet* n, const float* host_params, int64_t count);
+bool convnet_get_params(const ConvNet* n, float* host_params, int64_t count);
+void convnet_init_random(ConvNet* n, uint64_t seed);
+// forward for rows [0, *eb.n); n_rows_hint = host-side upper bound used to size the grids.
+// If prof != nullptr the forward is bracketed with HIP events (synchronises the stream).
+void convnet_forward(ConvNet* n, const EvalBatch& eb, int n_rows_hint, hipStream_t s, NetProfile* prof);
+
+}  // namespace az

@@ -1,0 +1,540 @@
+// az_net.hip -- NNet::predict on the device (src/nnet.rs:40-44).
+//
+// The policy+value net of examples/connect_four_lib/connect_four_net.py:20-95 (repaired: 7 actions,
+// [B,2,6,7] input) at inference: conv3x3(2->C,same) -> conv3x3(C->C,same) -> conv3x3(C->C,valid) ->
+// conv3x3(C->C,valid) -> FC 6C->1024 -> FC 1024->512 -> {pi: FC 512->7 + softmax, v: FC 512->1 + tanh},
+// BatchNorm folded into the weights, ReLU fused into each producer's epilogue, bf16 activations and
+// weights with f32 accumulation.
+//
+// The only dense contraction of the hot path: conv2..4 and the two FCs run as ONE implicit-GEMM kernel
+// on the CDNA4 matrix cores (v_mfma_f32_16x16x32_bf16), channels-last activations so that a K-step of
+// 64 input channels of one filter tap is one contiguous 128-byte row segment; conv1 (K = 18) reads the
+// bitboards directly (to_features fused, connect_four_game.rs:219-237) on the VALU.
+#include "az_net.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace az {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- fixtures ------------------------------------------------------------------------------------
+// DumbConnectFourNnet (examples/connect_four.rs:34-41, S9): pi = 1/width, v = +1; or the hash fixture.
+__global__ void k_net_fixture(EvalBatch eb, int kind, uint64_t salt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *eb.n) return;
+    float pi[ACTIONS], v;
+    if (kind == 0) {
+#pragma unroll
+        for (int a = 0; a < ACTIONS; ++a) pi[a] = __fdiv_rn(1.0f, 7.0f);
+        v = 1.0f;
+    } else {
+        ulonglong2 s = eb.state[i];
+        hashnet_eval(s.x, s.y, salt, pi, &v);
+    }
+#pragma unroll
+    for (int a = 0; a < ACTIONS; ++a) eb.pi[(size_t)i * 8 + a] = pi[a];
+    eb.pi[(size_t)i * 8 + 7] = 0.0f;
+    eb.v[i] = v;
+}
+
+void launch_net_fixture(const EvalBatch& eb, int kind, uint64_t salt, hipStream_t s) {
+    hipLaunchKernelGGL(k_net_fixture, dim3((eb.cap + 255) / 256), dim3(256), 0, s, eb, kind, salt);
+}
+
+// ---- bf16 helpers ----------------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x7FFFFFu)) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);                                       // round to nearest even
+}
+AZ_D uint32_t pack_bf16x2(float lo, float hi) {
+    __bf16 a = (__bf16)lo, b = (__bf16)hi;       // v_cvt_pk_bf16_f32 (round to nearest even)
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
+// ---- conv1: 3x3 'same', 2 -> C, reading the bitboards (K4 + first conv fused) -------------------------
+// out: act1 [n][8][9][C] bf16, interior rows 1..6 / cols 1..7 (the zero halo is conv2's 'same' padding).
+// One thread = one board position x 8 output channels (one 16-byte store).
+__global__ __launch_bounds__(256) void k_conv1(const EvalBatch eb, const float* __restrict__ w /*[18][C]*/,
+                                               const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out, int C) {
+    const int cg = C / 8;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(*eb.n) * 42 * cg;
+    if (tid >= total) return;
+    const int c8 = (int)(tid % cg);
+    const int pos = (int)((tid / cg) % 42);
+    const size_t b = tid / ((size_t)cg * 42);
+    const int y = pos / 7, x = pos % 7;
+    const ulonglong2 s = eb.state[b];
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = y + ky - 1, ix = x + kx - 1;
+            if (iy < 0 || iy >= 6 || ix < 0 || ix >= 7) continue;
+            const uint64_t bit = 1ull << (ix * 7 + (5 - iy));
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                if (!((ci == 0 ? s.x : s.y) & bit)) continue;
+                const float4* wp = (const float4*)(w + (size_t)((ky * 3 + kx) * 2 + ci) * C + c8 * 8);
+                float4 w0 = wp[0], w1 = wp[1];
+                acc[0] += w0.x; acc[1] += w0.y; acc[2] += w0.z; acc[3] += w0.w;
+                acc[4] += w1.x; acc[5] += w1.y; acc[6] += w1.z; acc[7] += w1.w;
+            }
+        }
+    const float4* bp = (const float4*)(bias + c8 * 8);
+    float4 b0 = bp[0], b1 = bp[1];
+    float r[8] = {acc[0] + b0.x, acc[1] + b0.y, acc[2] + b0.z, acc[3] + b0.w,
+                  acc[4] + b1.x, acc[5] + b1.y, acc[6] + b1.z, acc[7] + b1.w};
+    uint4 o;
+    o.x = pack_bf16x2(fmaxf(r[0], 0.0f), fmaxf(r[1], 0.0f));
+    o.y = pack_bf16x2(fmaxf(r[2], 0.0f), fmaxf(r[3], 0.0f));
+    o.z = pack_bf16x2(fmaxf(r[4], 0.0f), fmaxf(r[5], 0.0f));
+    o.w = pack_bf16x2(fmaxf(r[6], 0.0f), fmaxf(r[7], 0.0f));
+    *(uint4*)(out + (((b * 8 + (y + 1)) * 9 + (x + 1)) * (size_t)C + c8 * 8)) = o;
+}
+
+// ---- implicit GEMM on MFMA: out[M,N] = relu(A_gather[M,K] * W[N,K]^T + bias) ---------------------------
+// Row m = (sample b, output position (y,x)); K index = tap * cin + c with tap = ky*tap_w + kx reading the
+// input at position (y+ky, x+kx) of an [in_h][in_w][in_c] channels-last image (the 'same' conv reads a
+// zero-haloed image, the 'valid' convs an un-padded one; the FCs are a single tap over cin = K).
+struct GemmDesc {
+    const uint16_t* A;      // bf16 activations
+    const uint16_t* W;      // bf16 [N][K]
+    const float* bias;      // f32 [N]
+    uint16_t* out;          // bf16 [M][N]
+    const uint32_t* n_dev;  // samples in the batch (device)
+    int rows_per_sample;    // out_h*out_w
+    int out_w;
+    int in_h, in_w, in_c;   // input image geometry (positions, channels per position)
+    int tap_w;              // 3 for the convs, 1 for the FCs
+    int cin;                // channels per tap
+    int K, N;
+    int relu;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+
+template <int LAYER>   // distinct kernel symbol per layer so profiles name the dominant kernel (1 = conv2)
+__global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
+    // [buf][A tile 128 rows x 128 B | W tile 128 rows x 128 B]; 16-byte chunk c of row r lives at slot c ^ (r & 7)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][(GBM + GBN) * 128];
+    const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int NT = d.N / GBN;
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the NT column tiles of one
+    // row tile are placed on the same XCD back to back and re-read the activation tile from that XCD's L2.
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int m0 = mtile * GBM, n0 = ntile * GBN;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // staging map: 16-byte item i = q*256 + tid -> tile row i>>3, LDS slot i&7, logical chunk slot ^ (row&7)
+    const int srow = tid >> 3;
+    const int chunk = (tid & 7) ^ (srow & 7);
+    uint32_t a_off[4], b_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int m = m0 + q * 32 + srow;
+        m = m < M ? m : M - 1;
+        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
+        const int y = r / d.out_w, x = r - y * d.out_w;
+        a_off[q] = (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
+        b_off[q] = (uint32_t)((n0 + q * 32 + srow) * d.K + chunk * 8);
+    }
+    uint4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int kk = kt * GBK;
+        const int tap = kk / d.cin, c0 = kk - tap * d.cin;
+        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;
+        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ra[q] = *(const uint4*)(d.A + a_off[q] + toff);
+            rb[q] = *(const uint4*)(d.W + b_off[q] + kk);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(uint4*)(smem[buf] + (q * 256 + tid) * 16) = ra[q];
+            *(uint4*)(smem[buf] + GBM * 128 + (q * 256 + tid) * 16) = rb[q];
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = d.K / GBK;
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* sA = smem[kt & 1];
+        const unsigned char* sB = sA + GBM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ fsw) << 4;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * 64 + mt * 16 + frow) * 128 + coff);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
+            // D[n][m] = sum_k W[n][k] * Act[m][k]: the weight fragment is the MFMA's A operand so that each lane
+            // ends up with 4 consecutive output channels of one activation row (an 8-byte packed store).
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+        if (kt + 1 < nk) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+    // epilogue: + bias, ReLU, bf16, out[m][n .. n+3]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wr * 64 + mt * 16 + frow;
+            if (m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
+// ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
+// one wave per sample; lane holds 8 of the 512 inputs.
+__global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_t* __restrict__ x /*[n][512] bf16*/,
+                                               const float* __restrict__ w /*[8][512]*/, const float* __restrict__ bias /*[8]*/) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if ((uint32_t)wave >= *eb.n) return;
+    const uint4 xv = *(const uint4*)(x + (size_t)wave * 512 + lane * 8);
+    float xf[8];
+    const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xf[2 * i] = __uint_as_float(xs[i] << 16);
+        xf[2 * i + 1] = __uint_as_float(xs[i] & 0xFFFF0000u);
+    }
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4* wp = (const float4*)(w + (size_t)k * 512 + lane * 8);
+        const float4 w0 = wp[0], w1 = wp[1];
+        float s = xf[0] * w0.x + xf[1] * w0.y + xf[2] * w0.z + xf[3] * w0.w + xf[4] * w1.x + xf[5] * w1.y + xf[6] * w1.z +
+                  xf[7] * w1.w;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        o[k] = s + bias[k];
+    }
+    if (lane == 0) {
+        float mx = o[0];
+#pragma unroll
+        for (int a = 1; a < ACTIONS; ++a) mx = fmaxf(mx, o[a]);
+        float e[ACTIONS], sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < ACTIONS; ++a) { e[a] = expf(o[a] - mx); sum += e[a]; }
+#pragma unroll
+        for (int a = 0; a < ACTIONS; ++a) eb.pi[(size_t)wave * 8 + a] = e[a] / sum;
+        eb.pi[(size_t)wave * 8 + 7] = 0.f;
+        eb.v[wave] = tanhf(o[7]);
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+// Parameter vector (f32), "weights file" order -- every conv/FC has a bias (tf.layers defaults) and a BatchNorm
+// (gamma, beta, moving_mean, moving_var; eps = 1e-3):
+//   conv1 W[3][3][2][C] b[C] bn[4][C] | conv2..4 W[3][3][C][C] b[C] bn[4][C] |
+//   fc1 W[6C][1024] b[1024] bn[4][1024] (input index = (y*3+x)*C + c of conv4's [2][3][C] output) |
+//   fc2 W[1024][512] b[512] bn[4][512] | pi W[512][7] b[7] | v W[512][1] b[1]
+struct Layout {
+    int C;
+    int64_t conv_w[4], conv_b[4], conv_bn[4], fc_w[2], fc_b[2], fc_bn[2], pi_w, pi_b, v_w, v_b, total;
+    explicit Layout(int c) : C(c) {
+        int64_t o = 0;
+        for (int l = 0; l < 4; ++l) {
+            int cin = l == 0 ? 2 : C;
+            conv_w[l] = o; o += 9ll * cin * C;
+            conv_b[l] = o; o += C;
+            conv_bn[l] = o; o += 4ll * C;
+        }
+        const int fin[2] = {6 * C, 1024}, fout[2] = {1024, 512};
+        for (int l = 0; l < 2; ++l) {
+            fc_w[l] = o; o += (int64_t)fin[l] * fout[l];
+            fc_b[l] = o; o += fout[l];
+            fc_bn[l] = o; o += 4ll * fout[l];
+        }
+        pi_w = o; o += 512 * 7; pi_b = o; o += 7;
+        v_w = o; o += 512; v_b = o; o += 1;
+        total = o;
+    }
+};
+
+struct ConvNet {
+    int C = 512, max_batch = 0;
+    std::vector<float> params;        // raw f32 parameters as set
+    std::vector<void*> dev;           // every device allocation
+    float *w1 = nullptr, *b1 = nullptr;              // conv1 folded f32 [18][C], [C]
+    uint16_t* wg[5] = {nullptr};                       // conv2,3,4, fc1, fc2 folded bf16 [N][K]
+    float* bg[5] = {nullptr};                          // folded bias f32 [N]
+    float *wh = nullptr, *bh = nullptr;              // heads f32 [8][512], [8]
+    uint16_t *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *fc1o = nullptr, *fc2o = nullptr;
+    // profiling: event quads per forward + pinned copies of the batch size
+    struct Rec { hipEvent_t e0, e1, e2, e3; uint32_t* n; };
+    std::vector<Rec> open;
+    std::vector<hipEvent_t> ev_pool;
+    uint32_t* pinned_n = nullptr;
+    int pinned_cap = 0, pinned_next = 0;
+    template <class T> T* dalloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+        dev.push_back(p);
+        return (T*)p;
+    }
+};
+
+int64_t convnet_param_count(int channels) { return Layout(channels).total; }
+
+ConvNet* convnet_create(int channels, int max_batch, const char** err) {
+    if (channels % 128 != 0 || channels < 128) { if (err) *err = "net_channels must be a multiple of 128"; return nullptr; }
+    ConvNet* n = new ConvNet();
+    n->C = channels;
+    n->max_batch = max_batch;
+    const int C = channels;
+    const size_t B = (size_t)max_batch;
+    bool ok = true;
+    ok &= (n->w1 = n->dalloc<float>(18 * (size_t)C)) != nullptr;
+    ok &= (n->b1 = n->dalloc<float>(C)) != nullptr;
+    const size_t wk[5] = {9 * (size_t)C, 9 * (size_t)C, 9 * (size_t)C, 6 * (size_t)C, 1024};
+    const size_t wn[5] = {(size_t)C, (size_t)C, (size_t)C, 1024, 512};
+    for (int l = 0; l < 5; ++l) {
+        ok &= (n->wg[l] = n->dalloc<uint16_t>(wk[l] * wn[l])) != nullptr;
+        ok &= (n->bg[l] = n->dalloc<float>(wn[l])) != nullptr;
+    }
+    ok &= (n->wh = n->dalloc<float>(8 * 512)) != nullptr;
+    ok &= (n->bh = n->dalloc<float>(8)) != nullptr;
+    ok &= (n->act1 = n->dalloc<uint16_t>(B * 72 * C)) != nullptr;
+    ok &= (n->act2 = n->dalloc<uint16_t>(B * 42 * C)) != nullptr;
+    ok &= (n->act3 = n->dalloc<uint16_t>(B * 20 * C)) != nullptr;
+    ok &= (n->act4 = n->dalloc<uint16_t>(B * 6 * C)) != nullptr;
+    ok &= (n->fc1o = n->dalloc<uint16_t>(B * 1024)) != nullptr;
+    ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
+    if (ok) ok = hipMemset(n->act1, 0, B * 72 * C * sizeof(uint16_t)) == hipSuccess;   // the zero halo
+    if (ok) ok = hipHostMalloc((void**)&n->pinned_n, 4096 * sizeof(uint32_t)) == hipSuccess;
+    n->pinned_cap = 4096;
+    if (!ok) {
+        if (err) *err = "convnet_create: device allocation failed";
+        convnet_destroy(n);
+        return nullptr;
+    }
+    return n;
+}
+
+void convnet_destroy(ConvNet* n) {
+    if (!n) return;
+    for (void* p : n->dev) (void)hipFree(p);
+    for (auto& r : n->open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); (void)hipEventDestroy(r.e3); }
+    for (auto e : n->ev_pool) (void)hipEventDestroy(e);
+    if (n->pinned_n) (void)hipHostFree(n->pinned_n);
+    delete n;
+}
+
+// fold BatchNorm (inference) into the producing layer: w' = w * g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps) + beta
+static void fold_scale(const float* bn, int n, int idx, float* scale, float* shift_mul_mean) {
+    const float gamma = bn[idx], beta = bn[n + idx], mean = bn[2 * n + idx], var = bn[3 * n + idx];
+    const float s = gamma / std::sqrt(var + 1e-3f);
+    *scale = s;
+    *shift_mul_mean = beta - mean * s;
+}
+
+bool convnet_set_params(ConvNet* net, const float* p, int64_t count) {
+    const Layout L(net->C);
+    if (count != L.total) return false;
+    net->params.assign(p, p + count);
+    const int C = net->C;
+    bool ok = true;
+    {   // conv1: f32 [18][C], k = (ky*3+kx)*2 + ci
+        std::vector<float> w(18 * (size_t)C), b(C);
+        for (int co = 0; co < C; ++co) {
+            float s, t;
+            fold_scale(p + L.conv_bn[0], C, co, &s, &t);
+            for (int k = 0; k < 18; ++k) w[(size_t)k * C + co] = p[L.conv_w[0] + (int64_t)k * C + co] * s;
+            b[co] = p[L.conv_b[0] + co] * s + t;
+        }
+        ok &= hipMemcpy(net->w1, w.data(), w.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        ok &= hipMemcpy(net->b1, b.data(), b.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    // conv2..4 and fc1, fc2: bf16 [N][K] (K index = tap*cin + ci = the raw weight's leading index)
+    const int64_t w_off[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
+    const int64_t b_off[5] = {L.conv_b[1], L.conv_b[2], L.conv_b[3], L.fc_b[0], L.fc_b[1]};
+    const int64_t bn_off[5] = {L.conv_bn[1], L.conv_bn[2], L.conv_bn[3], L.fc_bn[0], L.fc_bn[1]};
+    const int K[5] = {9 * C, 9 * C, 9 * C, 6 * C, 1024}, N[5] = {C, C, C, 1024, 512};
+    for (int l = 0; l < 5; ++l) {
+        std::vector<uint16_t> w((size_t)K[l] * N[l]);
+        std::vector<float> b(N[l]);
+        for (int nn = 0; nn < N[l]; ++nn) {
+            float s, t;
+            fold_scale(p + bn_off[l], N[l], nn, &s, &t);
+            b[nn] = p[b_off[l] + nn] * s + t;
+            for (int k = 0; k < K[l]; ++k) w[(size_t)nn * K[l] + k] = f32_to_bf16_host(p[w_off[l] + (int64_t)k * N[l] + nn] * s);
+        }
+        ok &= hipMemcpy(net->wg[l], w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+        ok &= hipMemcpy(net->bg[l], b.data(), b.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    {   // heads: f32 [8][512]
+        std::vector<float> w(8 * 512), b(8);
+        for (int k = 0; k < 512; ++k) {
+            for (int a = 0; a < 7; ++a) w[(size_t)a * 512 + k] = p[L.pi_w + (int64_t)k * 7 + a];
+            w[(size_t)7 * 512 + k] = p[L.v_w + k];
+        }
+        for (int a = 0; a < 7; ++a) b[a] = p[L.pi_b + a];
+        b[7] = p[L.v_b];
+        ok &= hipMemcpy(net->wh, w.data(), w.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        ok &= hipMemcpy(net->bh, b.data(), b.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    return ok;
+}
+
+bool convnet_get_params(const ConvNet* n, float* host_params, int64_t count) {
+    if (!n || (int64_t)n->params.size() != count) return false;
+    std::memcpy(host_params, n->params.data(), (size_t)count * sizeof(float));
+    return true;
+}
+
+// Glorot-uniform kernels, zero biases, BN gamma=1 beta=0 mean=0 var=1 (the tf.layers defaults the reference
+// would start from, connect_four_net.py:36-100).  Uniforms come from the build's counter RNG.
+void convnet_init_random(ConvNet* net, uint64_t seed) {
+    const Layout L(net->C);
+    const int C = net->C;
+    std::vector<float> p((size_t)L.total, 0.0f);
+    uint64_t ctr = 0;
+    auto fill = [&](int64_t off, int64_t n, int fan_in, int fan_out) {
+        const float lim = std::sqrt(6.0f / (float)(fan_in + fan_out));
+        for (int64_t i = 0; i < n; ++i) {
+            uint64_t r = rng_draw(seed, ctr++, 0, RNG_WEIGHTS);
+            float u = (float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f);   // [0,1)
+            p[(size_t)(off + i)] = (2.0f * u - 1.0f) * lim;
+        }
+    };
+    auto bn_default = [&](int64_t off, int n) {
+        for (int i = 0; i < n; ++i) { p[(size_t)(off + i)] = 1.0f; p[(size_t)(off + 3 * n + i)] = 1.0f; }
+    };
+    for (int l = 0; l < 4; ++l) {
+        int cin = l == 0 ? 2 : C;
+        fill(L.conv_w[l], 9ll * cin * C, 9 * cin, 9 * C);
+        bn_default(L.conv_bn[l], C);
+    }
+    fill(L.fc_w[0], 6ll * C * 1024, 6 * C, 1024); bn_default(L.fc_bn[0], 1024);
+    fill(L.fc_w[1], 1024ll * 512, 1024, 512); bn_default(L.fc_bn[1], 512);
+    fill(L.pi_w, 512 * 7, 512, 7);
+    fill(L.v_w, 512, 512, 1);
+    convnet_set_params(net, p.data(), L.total);
+}
+
+template <int LAYER>
+static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
+    const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
+    const int mt8 = (mt + 7) / 8 * 8;
+    const int grid = mt8 * (d.N / GBN);
+    hipLaunchKernelGGL(k_gemm_mfma<LAYER>, dim3(grid), dim3(256), 0, s, d);
+}
+
+static hipEvent_t net_event(ConvNet* n) {
+    if (!n->ev_pool.empty()) { hipEvent_t e = n->ev_pool.back(); n->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Resolve finished profile records (call after the stream is synchronised).
+void convnet_resolve_profile(ConvNet* n, NetProfile* prof) {
+    if (!n) return;
+    const int C = n->C;
+    const double f_conv = 2.0 * 9.0 * C * C;
+    const double per_sample = 2.0 * (42.0 * 18 * C) + f_conv * (42 + 20 + 6) + 2.0 * (6.0 * C * 1024 + 1024.0 * 512 + 512.0 * 8);
+    for (auto& r : n->open) {
+        float conv2 = 0, total = 0;
+        if (hipEventElapsedTime(&conv2, r.e1, r.e2) == hipSuccess && hipEventElapsedTime(&total, r.e0, r.e3) == hipSuccess && prof) {
+            const double rows = (double)*r.n;
+            prof->conv2_ms += conv2;
+            prof->conv2_flops += f_conv * 42.0 * rows;
+            prof->total_ms += total;
+            prof->total_flops += per_sample * rows;
+            prof->launches += 1;
+        }
+        n->ev_pool.push_back(r.e0); n->ev_pool.push_back(r.e1); n->ev_pool.push_back(r.e2); n->ev_pool.push_back(r.e3);
+    }
+    n->open.clear();
+    n->pinned_next = 0;
+}
+
+void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t s, NetProfile* prof) {
+    const int C = n->C;
+    if (rows_hint > n->max_batch) rows_hint = n->max_batch;
+    if (rows_hint <= 0) return;
+    ConvNet::Rec rec{};
+    const bool timed = prof != nullptr && n->pinned_next < n->pinned_cap;
+    if (timed) {
+        rec.e0 = net_event(n); rec.e1 = net_event(n); rec.e2 = net_event(n); rec.e3 = net_event(n);
+        rec.n = n->pinned_n + n->pinned_next++;
+        (void)hipMemcpyAsync(rec.n, eb.n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        (void)hipEventRecord(rec.e0, s);
+    }
+    {
+        const size_t threads = (size_t)rows_hint * 42 * (C / 8);
+        hipLaunchKernelGGL(k_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, eb, n->w1, n->b1, n->act1, C);
+    }
+    GemmDesc d{};
+    d.n_dev = eb.n;
+    d.relu = 1;
+    // conv2: 3x3 same over the haloed [8][9][C] image -> [6][7][C]
+    d.A = n->act1; d.W = n->wg[0]; d.bias = n->bg[0]; d.out = n->act2;
+    d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;
+    if (timed) (void)hipEventRecord(rec.e1, s);
+    launch_gemm<1>(d, rows_hint, s);
+    if (timed) (void)hipEventRecord(rec.e2, s);
+    // conv3: 3x3 valid [6][7][C] -> [4][5][C]
+    d.A = n->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = n->act3;
+    d.rows_per_sample = 20; d.out_w = 5; d.in_h = 6; d.in_w = 7;
+    launch_gemm<2>(d, rows_hint, s);
+    // conv4: 3x3 valid [4][5][C] -> [2][3][C]
+    d.A = n->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = n->act4;
+    d.rows_per_sample = 6; d.out_w = 3; d.in_h = 4; d.in_w = 5;
+    launch_gemm<3>(d, rows_hint, s);
+    // fc1: [6C] -> 1024
+    d.A = n->act4; d.W = n->wg[3]; d.bias = n->bg[3]; d.out = n->fc1o;
+    d.rows_per_sample = 1; d.out_w = 1; d.in_h = 1; d.in_w = 1; d.in_c = 6 * C; d.tap_w = 1; d.cin = 6 * C; d.K = 6 * C; d.N = 1024;
+    launch_gemm<4>(d, rows_hint, s);
+    // fc2: 1024 -> 512
+    d.A = n->fc1o; d.W = n->wg[4]; d.bias = n->bg[4]; d.out = n->fc2o;
+    d.in_c = 1024; d.cin = 1024; d.K = 1024; d.N = 512;
+    launch_gemm<5>(d, rows_hint, s);
+    hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, n->fc2o, n->wh, n->bh);
+    if (timed) {
+        (void)hipEventRecord(rec.e3, s);
+        n->open.push_back(rec);
+    }
+}
+
+}  // namespace az

@@ -1,0 +1,555 @@
+// az_tree.hip -- MCTS tree kernels for gfx950 (select / expand / compact / backup /
+// root policy / self-play move).  8 lanes serve one game: lane j evaluates child j
+// of the node being selected, so a node's <=7 contiguous child records are one
+// coalesced 16-byte-per-lane access and the PUCT arg-max is a 7-step in-register
+// fold over lane shuffles.  One simulation is in flight per tree (the reference's
+// deterministic mode, num_sim_threads = 1), so every counter update is a plain
+// read-modify-write by one lane: integer, order-free, bit-reproducible.
+//
+// Reference restated: src/async_mcts.rs:74-115, :219-371; src/node.rs:272-370;
+// src/coach.rs:104-157; with the repairs of SURVEY.md section 0.2 (tagged S#/B#).
+#include "az_tree.h"
+
+namespace az {
+
+// ---- 8-lane group primitives -----------------------------------------------------
+AZ_D uint32_t gshfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, LANES); }
+AZ_D float gshflf(float v, int src) { return __shfl(v, src, LANES); }
+AZ_D uint32_t gballot(bool p) {
+    unsigned long long m = __ballot(p);
+    int lane = threadIdx.x & 63;
+    return (uint32_t)(m >> (lane & ~(LANES - 1))) & 0xFFu;
+}
+AZ_D uint32_t nth_set_bit(uint32_t mask, uint32_t n) {
+    uint32_t a = 0;
+#pragma unroll
+    for (int c = 0; c < ACTIONS; ++c) {
+        bool set = (mask >> c) & 1u;
+        if (set && n == 0) a = (uint32_t)c;
+        if (set) --n;
+    }
+    return a;
+}
+
+// `seen.get(&s)` (src/node.rs:282): 8-wide linear probe.  found = node index or NONE;
+// ins = first empty position (where `seen.insert` will go, src/node.rs:320).
+AZ_D void hash_find(const TreeDev& t, int g, size_t base, uint64_t m, uint64_t th, int sub, uint32_t* found,
+                    uint32_t* ins) {
+    const uint32_t mask = t.H - 1;
+    const uint32_t h = c4_hash(m, th) & mask;
+    const uint32_t* tab = t.hash + (size_t)g * t.H;
+    for (uint32_t probe = 0; probe < t.H; probe += LANES) {
+        uint32_t pos = (h + probe + (uint32_t)sub) & mask;
+        uint32_t idx = tab[pos];
+        bool empty = idx == NONE;
+        bool match = false;
+        if (!empty) {
+            ulonglong2 s = t.state[base + idx];
+            match = s.x == m && s.y == th;
+        }
+        uint32_t em = gballot(empty), mm = gballot(match);
+        int fe = em ? (__ffs((int)em) - 1) : LANES;
+        uint32_t before = mm & ((1u << fe) - 1u);
+        if (before) {
+            *found = gshfl(idx, __ffs((int)before) - 1);
+            *ins = NONE;
+            return;
+        }
+        if (em) {
+            *found = NONE;
+            *ins = (h + probe + (uint32_t)fe) & mask;
+            return;
+        }
+    }
+    *found = NONE;
+    *ins = NONE;
+}
+
+// NodeStore::upgrade, `None` arm (src/node.rs:290-323): store s, e = -ended(s), push one
+// placeholder per valid move in ascending action order, insert into `seen`.
+// cbase = current bump pointer (children go to [cbase, cbase+nv)).  Returns false when the
+// arena is exhausted (assert!, src/node.rs:237).
+AZ_D bool node_upgrade(const TreeDev& t, int g, size_t base, uint32_t slot, uint64_t m, uint64_t th,
+                       uint32_t prior_bits, uint32_t a, uint32_t ins_pos, uint64_t ctr_value, uint32_t cbase, int sub,
+                       uint32_t* ecode_out) {
+    uint32_t ec = c4_ecode(m, th);
+    uint32_t vm = ec ? 0u : c4_valid_mask(m, th);
+    uint32_t nv = (uint32_t)__popc(vm);
+    if (cbase + nv > t.R || ins_pos == NONE) {
+        if (sub == 0) atomicOr(&t.err[ins_pos == NONE ? ERR_HASH_FULL : ERR_CAPACITY], 1u);
+        return false;
+    }
+    if (sub == 0) {
+        t.len[g] = cbase + nv;
+        t.state[base + slot] = make_ulonglong2(m, th);
+        t.rec[base + slot] =
+            make_uint4(NONE, prior_bits, a | (nv << META_NCHILD_SHIFT) | META_EXPANDED | (ec << META_ECODE_SHIFT), cbase);
+        t.ctr[base + slot] = ctr_value;
+        t.hash[(size_t)g * t.H + ins_pos] = slot;
+    }
+    if ((uint32_t)sub < nv) {
+        t.rec[base + cbase + sub] = make_uint4(NONE, 0u, nth_set_bit(vm, (uint32_t)sub), 0u);
+        t.ctr[base + cbase + sub] = CTR_INIT;
+    }
+    *ecode_out = ec;
+    return true;
+}
+
+// ---- NodeStore::new (src/node.rs:156-166): clear `seen`, push + upgrade the initial board ----
+__global__ __launch_bounds__(256) void k_reset_trees(TreeDev t, const uint8_t* flags, uint8_t* clear_flags) {
+    int g = blockIdx.x;
+    if (flags && !flags[g]) return;
+    uint32_t* tab = t.hash + (size_t)g * t.H;
+    for (uint32_t i = threadIdx.x; i < t.H; i += blockDim.x) tab[i] = NONE;
+    __syncthreads();
+    if (threadIdx.x < LANES) {
+        int sub = threadIdx.x;
+        size_t base = (size_t)g * t.R;
+        uint32_t ec;
+        uint32_t ins = c4_hash(0, 0) & (t.H - 1);
+        node_upgrade(t, g, base, 0u, 0ull, 0ull, 0u, 0u, ins, CTR_INIT, 1u, sub, &ec);
+        if (sub == 0) {
+            t.root[g] = 0;
+            t.log_len[g] = 0;
+            if (clear_flags) clear_flags[g] = 0;
+        }
+    }
+}
+
+// ---- get_action_prob prologue: root lookup (src/async_mcts.rs:81) + S10 + S1 -------------
+__global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, const ulonglong2* root_states) {
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid >> 3, sub = tid & 7;
+    if (g >= t.G) return;
+    if (!t.active[g]) {
+        if (sub == 0) t.leaf_kind[g] = LEAF_NONE;
+        return;
+    }
+    size_t base = (size_t)g * t.R;
+    ulonglong2 s = root_states[g];
+    uint32_t found, ins;
+    hash_find(t, g, base, s.x, s.y, sub, &found, &ins);
+    uint32_t kind = LEAF_NONE;
+    uint32_t root = found;
+    uint32_t n_exp = 0;
+    if (found == NONE) {
+        // S10 (A11): unseen root -> push + upgrade a fresh node, as NodeStore::from_root (src/node.rs:168-177)
+        uint32_t idx = t.len[g];
+        uint32_t ec;
+        if (idx + 1 > t.R) {
+            if (sub == 0) atomicOr(&t.err[ERR_CAPACITY], 1u);
+        } else if (node_upgrade(t, g, base, idx, s.x, s.y, 0u, 0u, ins, CTR_INIT, idx + 1, sub, &ec)) {
+            root = idx;
+            n_exp = 1;
+        }
+    }
+    if (root != NONE) {
+        uint32_t meta = (found == NONE) ? 0u : t.rec[base + root].z;
+        uint32_t ec = (found == NONE) ? c4_ecode(s.x, s.y) : ((meta >> META_ECODE_SHIFT) & 3u);
+        if (ec != E_NONE) {
+            // terminal root: the reference panics at root.mu.p.unwrap() (src/async_mcts.rs:85)
+            if (sub == 0) atomicOr(&t.err[ERR_TERMINAL_ROOT], 1u);
+        } else if (!(meta & META_HAS_PRIOR)) {
+            kind = LEAF_EVAL;  // S1 (A1): evaluate the root once so best_child has a prior
+        }
+    }
+    if (sub == 0) {
+        t.root[g] = (root == NONE) ? 0u : root;
+        t.leaf[g] = (root == NONE) ? 0u : root;
+        t.leaf_kind[g] = kind;
+        t.path_len[g] = 0;
+        if (root == NONE || kind == LEAF_NONE) {
+            // nothing to evaluate; a failed root also deactivates the tree for this search
+            if (root == NONE) t.active[g] = 0;
+        }
+        t.stat[(size_t)g * ST_COUNT + ST_EXPANSIONS] += n_exp;
+    }
+}
+
+// ---- search_iteration: select + expand (src/async_mcts.rs:226-299, Appendix A of SURVEY.md) ----
+__global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid >> 3, sub = tid & 7;
+    if (g >= t.G) return;
+    if (!t.active[g]) {
+        if (sub == 0) t.leaf_kind[g] = LEAF_NONE;
+        return;
+    }
+    const size_t base = (size_t)g * t.R;
+    uint32_t* path = t.path + (size_t)g * PATH_CAP;
+    const uint32_t len_g = t.len[g];
+    uint32_t cur = t.root[g];
+    uint32_t depth = 0, plen = 0, kind = LEAF_NONE;
+    float val = 0.0f;
+    uint32_t n_exp = 0, n_link = 0, n_term = 0, n_depth = 0;
+    for (;;) {
+        uint4 pr = t.rec[base + cur];
+        uint64_t pc = t.ctr[base + cur] + CTR_VISIT;            // visit(), src/node.rs:77-80; S5: before the checks
+        if (sub == 0) t.ctr[base + cur] = pc;
+        uint32_t ec = (pr.z >> META_ECODE_SHIFT) & 3u;
+        if (depth > sp.max_depth) { val = 0.0f; kind = LEAF_VALUE; break; }   // src/async_mcts.rs:241-244 (B10)
+        if (ec != E_NONE) { val = ecode_value(ec); kind = LEAF_VALUE; ++n_term; break; }  // :246-249
+        // best_child, src/node.rs:343-370
+        const uint32_t nchild = (pr.z >> META_NCHILD_SHIFT) & 7u, cb = pr.w;
+        const float sq = puct_sqrt_parent(ctr_n(pc));
+        uint4 cr = make_uint4(NONE, 0u, 0u, 0u);
+        float u = 0.0f;
+        if ((uint32_t)sub < nchild) {
+            cr = t.rec[base + cb + sub];
+            uint32_t r = cr.x != NONE ? cr.x : cb + (uint32_t)sub;     // resolve(), src/node.rs:179-193
+            u = puct(t.ctr[base + r], __uint_as_float(cr.y), sq, sp.cpuct_f);
+        }
+        uint32_t best = 0;
+        float bu = gshflf(u, 0);
+#pragma unroll
+        for (int j = 1; j < ACTIONS; ++j) {                     // max_by: later element wins unless earlier is Greater (C7)
+            float uj = gshflf(u, j);
+            if ((uint32_t)j < nchild && !(bu > uj)) { best = (uint32_t)j; bu = uj; }
+        }
+        ++n_depth;
+        const uint32_t clink = gshfl(cr.x, (int)best), cmeta = gshfl(cr.z, (int)best), cprior = gshfl(cr.y, (int)best);
+        const uint32_t cslot = cb + best;
+        if (plen >= (uint32_t)PATH_CAP) {
+            if (sub == 0) atomicOr(&t.err[ERR_PATH], 1u);
+            kind = LEAF_NONE;
+            break;
+        }
+        if (sub == 0) path[plen] = cur;                         // node_path.push, S3 / :270
+        ++plen;
+        if (clink != NONE) { cur = clink; ++depth; continue; }  // Exists(false): follow the link (S2: one level per iteration)
+        if (cmeta & META_EXPANDED) { cur = cslot; ++depth; continue; }   // Exists(true)
+        // PlaceHolder (:261-268, S3): expand it.  B1: play the child's own action.
+        ulonglong2 ps = t.state[base + cur];
+        uint64_t m2, t2;
+        c4_play(ps.x, ps.y, (int)(cmeta & META_A_MASK), &m2, &t2);       // :284-287 (B5)
+        uint32_t found, ins;
+        hash_find(t, g, base, m2, t2, sub, &found, &ins);
+        if (found != NONE) {                                    // upgrade -> Some(false): become a link (src/node.rs:285-289)
+            if (sub == 0) t.rec[base + cslot].x = found;
+            cur = found;
+            ++n_link;
+            continue;                                           // :297-298
+        }
+        uint32_t ec2;
+        // the placeholder is visited right after the upgrade (:309): its counter becomes INIT + VISIT
+        if (!node_upgrade(t, g, base, cslot, m2, t2, cprior, cmeta & META_A_MASK, ins, CTR_INIT + CTR_VISIT, len_g, sub,
+                          &ec2)) {
+            kind = LEAF_NONE;
+            break;
+        }
+        ++n_exp;
+        cur = cslot;
+        if (ec2 != E_NONE) { val = ecode_value(ec2); kind = LEAF_VALUE; break; }   // S4 (A5)
+        kind = LEAF_EVAL;                                       // :303-315: goes to the net
+        break;
+    }
+    if (sub == 0) {
+        t.leaf[g] = cur;
+        t.leaf_kind[g] = kind;
+        t.leaf_val[g] = val;
+        t.path_len[g] = plen;
+        uint64_t* st = t.stat + (size_t)g * ST_COUNT;
+        st[ST_SIMS] += 1;
+        st[ST_EXPANSIONS] += n_exp;
+        st[ST_LINK_HITS] += n_link;
+        st[ST_TERMINAL_HITS] += n_term;
+        st[ST_DEPTH_SUM] += n_depth;
+    }
+}
+
+// ---- inference batch assembly (src/async_mcts.rs:137-151 restated): deterministic compaction ----
+__global__ __launch_bounds__(1024) void k_compact(TreeDev t, EvalBatch eb) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (t.G + 1023) / 1024;
+    const int g0 = tid * per;
+    uint32_t cnt = 0;
+    for (int i = 0; i < per; ++i) {
+        int g = g0 + i;
+        if (g < t.G && t.leaf_kind[g] == LEAF_EVAL) ++cnt;
+    }
+    part[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele inclusive scan
+        uint32_t v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t slot = part[tid] - cnt;
+    for (int i = 0; i < per; ++i) {
+        int g = g0 + i;
+        if (g >= t.G) break;
+        if (t.leaf_kind[g] == LEAF_EVAL) {
+            t.slot_of[g] = (int32_t)slot;
+            eb.tree[slot] = (uint32_t)g;
+            eb.state[slot] = t.state[(size_t)g * t.R + t.leaf[g]];
+            ++slot;
+        } else {
+            t.slot_of[g] = -1;
+        }
+    }
+    if (tid == 1023) *eb.n = part[1023];
+}
+
+// ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
+__global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, int apply_only) {
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid >> 3, sub = tid & 7;
+    if (g >= t.G) return;
+    const uint32_t kind = t.leaf_kind[g];
+    if (kind == LEAF_NONE) return;
+    const size_t base = (size_t)g * t.R;
+    const uint32_t leaf = t.leaf[g];
+    float val;
+    if (kind == LEAF_EVAL) {
+        const int slot = t.slot_of[g];
+        float p = sub < ACTIONS ? eb.pi[(size_t)slot * 8 + sub] : 0.0f;
+        const float v = eb.v[slot];
+        const ulonglong2 s = t.state[base + leaf];
+        if (t.log_cap > 0) {
+            uint32_t n = t.log_len[g];
+            if (n < (uint32_t)t.log_cap) {
+                size_t li = (size_t)g * t.log_cap + n;
+                if (sub < ACTIONS) t.log_pi[li * 7 + sub] = p;
+                if (sub == 0) { t.log_v[li] = v; t.log_state[li] = s; }
+            }
+            if (sub == 0) t.log_len[g] = n + 1;
+        }
+        const uint32_t vm = c4_valid_mask(s.x, s.y);
+        const bool valid = sub < ACTIONS && ((vm >> sub) & 1u);
+        if (!valid) p = 0.0f;                                       // :322-326
+        float sum = 0.0f;
+#pragma unroll
+        for (int a = 0; a < ACTIONS; ++a) sum = __fadd_rn(sum, gshflf(p, a));   // :328 (sequential, C10)
+        if (sum > 0.0f) {
+            p = __fdiv_rn(p, sum);                                  // :331
+        } else {
+            p = __fadd_rn(p, valid ? 1.0f : 0.0f);                  // :340-342
+            float s2 = 0.0f;
+#pragma unroll
+            for (int a = 0; a < ACTIONS; ++a) s2 = __fadd_rn(s2, gshflf(p, a));
+            p = __fdiv_rn(p, s2);                                   // :344
+        }
+        const uint4 lr = t.rec[base + leaf];
+        const uint32_t nchild = (lr.z >> META_NCHILD_SHIFT) & 7u, cb = lr.w;
+        const uint32_t myact = (uint32_t)sub < nchild ? nth_set_bit(vm, (uint32_t)sub) : 0u;
+        const float pa = gshflf(p, (int)myact);
+        if ((uint32_t)sub < nchild) t.rec[base + cb + sub].y = __float_as_uint(pa);   // set_policy, :348
+        if (sub == 0) {
+            t.rec[base + leaf].z = lr.z | META_HAS_PRIOR;
+            t.stat[(size_t)g * ST_COUNT + ST_LEAF_EVALS] += 1;
+        }
+        val = -v;                                                   // :353 (C9)
+    } else {
+        val = t.leaf_val[g];
+    }
+    if (apply_only) return;
+    // unvisit() leaf -> root along node_path; B2: the sign alternates toward the root.
+    // A Connect Four line never repeats a node, so the lanes update distinct counters.
+    const uint32_t plen = t.path_len[g];
+    const uint32_t* path = t.path + (size_t)g * PATH_CAP;
+    for (uint32_t i = (uint32_t)sub; i <= plen; i += LANES) {
+        uint32_t node = i == 0 ? leaf : path[plen - i];
+        float x = (i & 1u) ? -val : val;
+        t.ctr[base + node] -= ctr_unvisit_delta(x);                 // src/node.rs:83-92
+    }
+}
+
+// ---- get_action_prob epilogue (src/async_mcts.rs:84-114): counts -> pi ----------------------
+struct RootPolicy {
+    float pi;        // this lane's action (sub < 7)
+    uint32_t count;
+    float q;
+};
+AZ_D RootPolicy root_policy(const TreeDev& t, int g, int sub, float temp, uint64_t seed, uint64_t game_id, uint64_t ply) {
+    const size_t base = (size_t)g * t.R;
+    const uint4 pr = t.rec[base + t.root[g]];
+    const uint32_t nchild = (pr.z >> META_NCHILD_SHIFT) & 7u, cb = pr.w;
+    uint32_t ca = 0, cn = 0;
+    float cq = 0.0f;
+    if ((uint32_t)sub < nchild) {
+        uint4 cr = t.rec[base + cb + sub];
+        uint32_t r = cr.x != NONE ? cr.x : cb + (uint32_t)sub;
+        uint64_t cc = t.ctr[base + r];
+        ca = cr.z & META_A_MASK;                                    // B3: the slot's own action
+        cn = ctr_n(cc);
+        cq = ctr_q(cc);
+    }
+    RootPolicy out{0.0f, 0u, 0.0f};
+#pragma unroll
+    for (int j = 0; j < ACTIONS; ++j) {                             // counts[a] = n, :88-94
+        uint32_t aj = gshfl(ca, j), nj = gshfl(cn, j);
+        float qj = gshflf(cq, j);
+        if ((uint32_t)j < nchild && aj == (uint32_t)sub) { out.count = nj; out.q = qj; }
+    }
+    if (temp == 0.0f) {                                             // :97-107
+        uint32_t mx = 0;
+#pragma unroll
+        for (int a = 0; a < ACTIONS; ++a) { uint32_t ca2 = gshfl(out.count, a); mx = ca2 > mx ? ca2 : mx; }
+        uint32_t ties = gballot(sub < ACTIONS && out.count == mx) & 0x7Fu;
+        uint64_t r = rng_draw(seed, game_id, ply, RNG_TIEBREAK);
+        uint32_t pick = nth_set_bit(ties, rng_choose(r, (uint32_t)__popc(ties)));
+        out.pi = ((uint32_t)sub == pick) ? 1.0f : 0.0f;
+    } else {                                                        // S6 (A7): counts^(1/temp) / sum
+        float inv_t = __fdiv_rn(1.0f, temp);
+        float x = (inv_t == 1.0f) ? (float)out.count : powf((float)out.count, inv_t);   // :109
+        if (sub >= ACTIONS) x = 0.0f;
+        float sum = 0.0f;
+#pragma unroll
+        for (int a = 0; a < ACTIONS; ++a) sum = __fadd_rn(sum, gshflf(x, a));           // :110
+        out.pi = __fdiv_rn(x, sum);
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(64) void k_root_policy(TreeDev t, float temp, uint64_t seed, uint64_t first_game_id,
+                                                    float* pi, uint16_t* counts, float* q) {
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid >> 3, sub = tid & 7;
+    if (g >= t.G || !t.active[g]) return;
+    const ulonglong2 s = t.state[(size_t)g * t.R + t.root[g]];
+    RootPolicy rp = root_policy(t, g, sub, temp, seed, first_game_id + (uint64_t)g, (uint64_t)__popcll(s.x | s.y));
+    if (sub < ACTIONS) {
+        pi[(size_t)g * 7 + sub] = rp.pi;
+        if (counts) counts[(size_t)g * 7 + sub] = (uint16_t)rp.count;
+        if (q) q[(size_t)g * 7 + sub] = rp.q;
+    }
+}
+
+// ---- Coach::execute_episode, one ply for every slot (src/coach.rs:118-156) -------------------
+__global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, SelfplayMoveParams mp) {
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid >> 3, sub = tid & 7;
+    if (g >= t.G) return;
+    const int gi = gd.gid[g];
+    if (gi < 0 || !t.active[g]) return;
+    const int ply = gd.ply[g];
+    const int8_t player = gd.player[g];
+    const ulonglong2 s = gd.state[g];
+    const uint64_t game_id = mp.first_game_id + (uint64_t)gi;
+    const float temp = (ply + 1 < mp.temp_threshold) ? 1.0f : 0.0f;         // :122-126 (episode_step = ply + 1)
+    RootPolicy rp = root_policy(t, g, sub, temp, mp.seed, game_id, (uint64_t)ply);   // :128
+    const size_t so = (size_t)gi * 42 + ply;
+    if (sub < ACTIONS) gd.smp_pi[so * 7 + sub] = rp.pi;                     // :130-135 (symmetries regenerated at emit)
+    // choose_weighted, :137-138
+    float w[ACTIONS];
+#pragma unroll
+    for (int a = 0; a < ACTIONS; ++a) w[a] = gshflf(rp.pi, a);
+    float total = 0.0f;
+#pragma unroll
+    for (int a = 0; a < ACTIONS; ++a) total = __fadd_rn(total, w[a]);
+    const uint64_t r = rng_draw(mp.seed, game_id, (uint64_t)ply, RNG_MOVE);
+    const float uu = (float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f);
+    const float target = __fmul_rn(uu, total);
+    float acc = 0.0f;
+    int action = -1, last = -1;
+#pragma unroll
+    for (int a = 0; a < ACTIONS; ++a) {
+        if (w[a] > 0.0f) {
+            acc = __fadd_rn(acc, w[a]);
+            last = a;
+            if (action < 0 && target < acc) action = a;
+        }
+    }
+    if (action < 0) action = last;
+    if (action < 0) action = 0;
+    uint64_t m2, t2;
+    c4_play(s.x, s.y, action, &m2, &t2);                                    // :140-142
+    const uint32_t ec = c4_ecode(m2, t2);                                   // r = get_game_ended(cur_player), :144
+    if (sub == 0) {
+        gd.smp_state[so] = s;
+        gd.smp_player[so] = player;
+        gd.moves[so] = (uint8_t)action;
+        if (ec != E_NONE) {
+            // canonical ended(s') = -e: -1 when the side to move has lost, DRAW_EPS on a full board
+            gd.g_result[gi] = -ecode_value(ec);
+            gd.g_final_player[gi] = (int8_t)-player;
+            gd.g_len[gi] = ply + 1;
+            atomicAdd(&gd.counters[1], 1u);
+            int next = -1;
+            if (mp.refill) {
+                uint32_t nx = atomicAdd(&gd.counters[0], 1u);
+                if (nx < (uint32_t)gd.n_games) next = (int)nx;
+            }
+            gd.gid[g] = next;
+            if (next >= 0) {
+                gd.state[g] = make_ulonglong2(0ull, 0ull);
+                gd.player[g] = 1;
+                gd.ply[g] = 0;
+                gd.need_reset[g] = 1;
+            } else {
+                t.active[g] = 0;
+                atomicSub(&gd.counters[2], 1u);
+            }
+        } else {
+            gd.state[g] = make_ulonglong2(m2, t2);
+            gd.player[g] = (int8_t)-player;
+            gd.ply[g] = ply + 1;
+        }
+    }
+}
+
+// ---- training tuples (TrainingSample, src/nnet.rs:22-27; z per B4, src/coach.rs:146-154) -----
+__global__ __launch_bounds__(256) void k_emit_samples(GamesDev gd, const int64_t* offsets, int symmetries,
+                                                      ulonglong2* out_states, float* out_boards, float* out_pis,
+                                                      float* out_zs) {
+    const int gi = blockIdx.x;
+    const int len = gd.g_len[gi];
+    const int nsym = symmetries ? 2 : 1;
+    const float r = gd.g_result[gi];
+    const int8_t fin = gd.g_final_player[gi];
+    for (int item = threadIdx.x; item < len * nsym * 84; item += blockDim.x) {
+        const int f = item % 84, rest = item / 84;
+        const int sym = rest % nsym, ply = rest / nsym;
+        const size_t so = (size_t)gi * 42 + ply;
+        const int64_t o = (offsets[gi] + ply) * nsym + sym;
+        ulonglong2 s = gd.smp_state[so];
+        if (sym) s = make_ulonglong2(c4_mirror(s.x), c4_mirror(s.y));          // get_symmetries, connect_four_game.rs:205-211
+        if (out_boards) out_boards[o * 84 + f] = c4_feature(s.x, s.y, f / 42, (f % 42) / 7, f % 7);
+        if (f < 7) out_pis[o * 7 + f] = gd.smp_pi[so * 7 + (sym ? 6 - f : f)];
+        if (f == 7) out_zs[o] = __fmul_rn(r, gd.smp_player[so] == fin ? 1.0f : -1.0f);   // B4
+        if (f == 8 && out_states) out_states[o] = s;
+    }
+}
+
+__global__ void k_sync_active(TreeDev t, GamesDev gd) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < t.G) t.active[g] = gd.gid[g] >= 0 ? 1 : 0;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+static inline int group_blocks(int G) { return (G * LANES + 63) / 64; }
+
+void launch_reset_trees(const TreeDev& t, const uint8_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_trees, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags));
+}
+void launch_root_prepare(const TreeDev& t, const ulonglong2* root_states, hipStream_t s) {
+    hipLaunchKernelGGL(k_root_prepare, dim3(group_blocks(t.G)), dim3(64), 0, s, t, root_states);
+}
+void launch_select(const TreeDev& t, SearchParams sp, hipStream_t s) {
+    hipLaunchKernelGGL(k_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, sp);
+}
+void launch_compact(const TreeDev& t, const EvalBatch& eb, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, t, eb);
+}
+void launch_backup(const TreeDev& t, const EvalBatch& eb, int apply_only, hipStream_t s) {
+    hipLaunchKernelGGL(k_backup, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, apply_only);
+}
+void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
+                        uint16_t* counts, float* q, hipStream_t s) {
+    hipLaunchKernelGGL(k_root_policy, dim3(group_blocks(t.G)), dim3(64), 0, s, t, temp, seed, first_game_id, pi, counts, q);
+}
+void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s) {
+    hipLaunchKernelGGL(k_selfplay_move, dim3(group_blocks(t.G)), dim3(64), 0, s, t, gd, mp);
+}
+void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s) {
+    hipLaunchKernelGGL(k_sync_active, dim3((t.G + 255) / 256), dim3(256), 0, s, t, gd);
+}
+void launch_emit_samples(const GamesDev& gd, const int64_t* offsets, int symmetries, ulonglong2* out_states,
+                         float* out_boards, float* out_pis, float* out_zs, hipStream_t s) {
+    hipLaunchKernelGGL(k_emit_samples, dim3(gd.n_games), dim3(256), 0, s, gd, offsets, symmetries, out_states,
+                       out_boards, out_pis, out_zs);
+}
+
+}  // namespace az

@@ -1,0 +1,344 @@
+"""ctypes mirror of the C ABI in include/az_engine.h.
+
+Names follow the reference's surface: `Engine.net_*` is the `NNet` trait
+(src/nnet.rs:35-45), `TreeBatch` is n x `AsyncMcts` (src/async_mcts.rs:14-115),
+`Engine.selfplay` is `Coach::execute_episode` x many (src/coach.rs:104-157) and
+`Engine.arena` is `arena::play_games` (src/arena.rs:62-99).
+
+The HIP library is mandatory: if it has not been built this module raises at
+import -- there is no CPU path.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libaz_engine.so")
+
+ACTIONS = 7
+FEATURES = 84
+MAX_PLIES = 42
+
+AZ_OK = 0
+STATUS_NAMES = {
+    0: "AZ_OK", 1: "AZ_ERR_BAD_ARGUMENT", 2: "AZ_ERR_CAPACITY", 3: "AZ_ERR_HIP", 4: "AZ_ERR_INVALID_MOVE",
+    5: "AZ_ERR_TERMINAL_ROOT", 6: "AZ_ERR_NO_MODEL", 7: "AZ_ERR_IO", 8: "AZ_ERR_UNSUPPORTED",
+}
+NET_STUB, NET_HASH, NET_CONV = 0, 1, 2
+
+
+class AzError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
+        self.status = status
+
+
+class az_config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_batch", C.c_int32), ("net_channels", C.c_int32), ("profile", C.c_int32)]
+
+
+class az_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("games", "moves", "simulations", "expansions", "leaf_evals", "link_hits",
+                                          "terminal_hits", "depth_sum", "samples", "net_launches")] + \
+               [(n, C.c_double) for n in ("net_conv2_ms", "net_conv2_flops", "net_total_ms", "net_total_flops",
+                                          "tree_ms", "tree_bytes", "device_ms")]
+
+
+class az_selfplay_params(C.Structure):
+    _fields_ = [("n_games", C.c_int32), ("concurrent", C.c_int32), ("num_sims", C.c_int32),
+                ("temp_threshold", C.c_int32), ("max_depth", C.c_int32), ("cpuct", C.c_int32),
+                ("model_id", C.c_int32), ("symmetries", C.c_int32), ("reserve", C.c_uint64), ("seed", C.c_uint64),
+                ("first_game_id", C.c_uint64), ("record_evals", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class az_samples(C.Structure):
+    _fields_ = [("capacity", C.c_int64), ("count", C.c_int64), ("states", C.c_void_p), ("boards", C.c_void_p),
+                ("pis", C.c_void_p), ("zs", C.c_void_p), ("game_len", C.c_void_p), ("moves", C.c_void_p)]
+
+
+class az_arena_params(C.Structure):
+    _fields_ = [("num_games", C.c_int32), ("num_sims", C.c_int32), ("max_depth", C.c_int32), ("cpuct", C.c_int32),
+                ("new_model_id", C.c_int32), ("old_model_id", C.c_int32), ("reserve", C.c_uint64), ("seed", C.c_uint64)]
+
+
+# every symbol include/az_engine.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "az_create", "az_destroy", "az_last_error", "az_get_stats", "az_reset_stats", "az_net_set_kind",
+    "az_net_init_random", "az_net_load", "az_net_save", "az_net_param_count", "az_net_set_params",
+    "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_tree_create",
+    "az_tree_destroy", "az_tree_get_action_prob", "az_tree_record_evals", "az_tree_get_evals",
+    "az_tree_node_counts", "az_selfplay", "az_selfplay_get_evals", "az_arena",
+]
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP engine has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32, u64, i64, f32 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64, C.c_float
+    sigs = {
+        "az_create": (i32, [C.POINTER(az_config), C.POINTER(vp)]),
+        "az_destroy": (None, [vp]),
+        "az_last_error": (C.c_char_p, [vp]),
+        "az_get_stats": (i32, [vp, C.POINTER(az_stats)]),
+        "az_reset_stats": (i32, [vp]),
+        "az_net_set_kind": (i32, [vp, i32, i32, u64]),
+        "az_net_init_random": (i32, [vp, i32, u64]),
+        "az_net_load": (i32, [vp, i32, C.c_char_p]),
+        "az_net_save": (i32, [vp, i32, C.c_char_p]),
+        "az_net_param_count": (i64, [vp]),
+        "az_net_set_params": (i32, [vp, i32, vp, i64]),
+        "az_net_get_params": (i32, [vp, i32, vp, i64]),
+        "az_net_predict": (i32, [vp, i32, vp, i32, vp, vp]),
+        "az_net_predict_states": (i32, [vp, i32, vp, i32, vp, vp]),
+        "az_net_train": (i32, [vp, i32, i32, vp, vp, vp, i64]),
+        "az_tree_create": (i32, [vp, i32, u64, i32, i32, i32, i32, C.POINTER(vp)]),
+        "az_tree_destroy": (None, [vp]),
+        "az_tree_get_action_prob": (i32, [vp, vp, f32, u64, u64, vp, vp, vp]),
+        "az_tree_record_evals": (i32, [vp, i32]),
+        "az_tree_get_evals": (i32, [vp, vp, vp, vp, vp]),
+        "az_tree_node_counts": (i32, [vp, vp]),
+        "az_selfplay": (i32, [vp, C.POINTER(az_selfplay_params), C.POINTER(az_samples)]),
+        "az_selfplay_get_evals": (i32, [vp, vp, vp, vp, vp]),
+        "az_arena": (i32, [vp, C.POINTER(az_arena_params), vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = load_library()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _as_ptr(x):
+    """numpy array -> host pointer; torch tensor -> its data_ptr() (device or host); int passes through."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+class Engine:
+    """az_engine handle.  One per process per GPU (one HIP stream)."""
+
+    def __init__(self, device=0, max_batch=8192, net_channels=512, profile=False):
+        cfg = az_config(device, max_batch, net_channels, 1 if profile else 0)
+        h = C.c_void_p()
+        st = _lib.az_create(C.byref(cfg), C.byref(h))
+        if st != AZ_OK:
+            raise AzError(st, "az_create failed (no usable HIP device?)")
+        self._h = h
+        self.net_channels = net_channels
+        self._trees = weakref.WeakSet()
+
+    def close(self):
+        if self._h:
+            for t in list(self._trees):   # a tree must not outlive its engine (it borrows the stream)
+                t.close()
+            _lib.az_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != AZ_OK:
+            raise AzError(st, _lib.az_last_error(self._h).decode())
+
+    # ---- NNet ----
+    def net_set_kind(self, model_id, kind, salt=0):
+        self._check(_lib.az_net_set_kind(self._h, model_id, kind, salt))
+
+    def net_init_random(self, model_id, seed):
+        self._check(_lib.az_net_init_random(self._h, model_id, seed))
+
+    def net_param_count(self):
+        return int(_lib.az_net_param_count(self._h))
+
+    def net_set_params(self, model_id, params):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        self._check(_lib.az_net_set_params(self._h, model_id, _ptr(p), p.size))
+
+    def net_get_params(self, model_id):
+        p = np.empty(self.net_param_count(), np.float32)
+        self._check(_lib.az_net_get_params(self._h, model_id, _ptr(p), p.size))
+        return p
+
+    def net_save(self, model_id, path):
+        self._check(_lib.az_net_save(self._h, model_id, os.fsencode(path)))
+
+    def net_load(self, model_id, path):
+        self._check(_lib.az_net_load(self._h, model_id, os.fsencode(path)))
+
+    def predict(self, boards, model_id):
+        """NNet::predict: boards [B,2,6,7] f32 -> (pi [B,7], v [B])."""
+        b = np.ascontiguousarray(boards, dtype=np.float32).reshape(-1, FEATURES)
+        pi = np.empty((b.shape[0], ACTIONS), np.float32)
+        v = np.empty(b.shape[0], np.float32)
+        self._check(_lib.az_net_predict(self._h, model_id, _ptr(b), b.shape[0], _ptr(pi), _ptr(v)))
+        return pi, v
+
+    def predict_states(self, states, model_id):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 2)
+        pi = np.empty((s.shape[0], ACTIONS), np.float32)
+        v = np.empty(s.shape[0], np.float32)
+        self._check(_lib.az_net_predict_states(self._h, model_id, _ptr(s), s.shape[0], _ptr(pi), _ptr(v)))
+        return pi, v
+
+    def train(self, prev_id, model_id, boards, pis, vs):
+        b = np.ascontiguousarray(boards, dtype=np.float32)
+        p = np.ascontiguousarray(pis, dtype=np.float32)
+        v = np.ascontiguousarray(vs, dtype=np.float32)
+        self._check(_lib.az_net_train(self._h, prev_id, model_id, _ptr(b), _ptr(p), _ptr(v), v.size))
+
+    # ---- stats ----
+    def stats(self):
+        s = az_stats()
+        self._check(_lib.az_get_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in az_stats._fields_}
+
+    def reset_stats(self):
+        self._check(_lib.az_reset_stats(self._h))
+
+    # ---- AsyncMcts ----
+    def tree_create(self, n_games, reserve, num_sims, max_depth, model_id, cpuct):
+        return TreeBatch(self, n_games, reserve, num_sims, max_depth, model_id, cpuct)
+
+    # ---- Coach::execute_episode x many ----
+    def selfplay(self, n_games, num_sims, model_id, seed=0, first_game_id=0, concurrent=0, temp_threshold=15,
+                 max_depth=1000, cpuct=1, reserve=1000000, symmetries=True, want_boards=True, want_states=True,
+                 record_evals=0, out=None):
+        """Plays n_games episodes; returns dict(states, boards, pis, zs, game_len, moves, count).
+
+        `out` may hold pre-allocated torch CUDA tensors / numpy arrays for states/boards/pis/zs
+        (the library writes device or host memory alike)."""
+        nsym = 2 if symmetries else 1
+        cap = n_games * MAX_PLIES * nsym
+        out = dict(out or {})
+        if "pis" not in out:
+            out["pis"] = np.zeros((cap, ACTIONS), np.float32)
+        if "zs" not in out:
+            out["zs"] = np.zeros(cap, np.float32)
+        if want_states and "states" not in out:
+            out["states"] = np.zeros((cap, 2), np.uint64)
+        if want_boards and "boards" not in out:
+            out["boards"] = np.zeros((cap, 2, 6, 7), np.float32)
+        game_len = np.zeros(n_games, np.int32)
+        moves = np.zeros((n_games, MAX_PLIES), np.uint8)
+        p = az_selfplay_params(n_games, concurrent, num_sims, temp_threshold, max_depth, cpuct, model_id,
+                               1 if symmetries else 0, reserve, seed, first_game_id, record_evals, 0)
+        s = az_samples(cap, 0, _as_ptr(out.get("states")), _as_ptr(out.get("boards")), _as_ptr(out["pis"]),
+                       _as_ptr(out["zs"]), _ptr(game_len), _ptr(moves))
+        self._check(_lib.az_selfplay(self._h, C.byref(p), C.byref(s)))
+        n = int(s.count)
+        res = {"count": n, "game_len": game_len, "moves": moves}
+        for k in ("states", "boards", "pis", "zs"):
+            if k in out:
+                res[k] = out[k][:n]
+        return res
+
+    def selfplay_get_evals(self, n_games, cap):
+        cnt = np.zeros(n_games, np.int32)
+        states = np.zeros((n_games, cap, 2), np.uint64)
+        pis = np.zeros((n_games, cap, ACTIONS), np.float32)
+        vs = np.zeros((n_games, cap), np.float32)
+        self._check(_lib.az_selfplay_get_evals(self._h, _ptr(cnt), _ptr(states), _ptr(pis), _ptr(vs)))
+        return cnt, states, pis, vs
+
+    # ---- arena::play_games ----
+    def arena(self, num_games, num_sims, new_model_id, old_model_id, seed=0, max_depth=1000, cpuct=1,
+              reserve=1000000):
+        p = az_arena_params(num_games, num_sims, max_depth, cpuct, new_model_id, old_model_id, reserve, seed)
+        wld = np.zeros(3, np.uint64)
+        results = np.zeros(max(num_games, 1), np.int8)
+        self._check(_lib.az_arena(self._h, C.byref(p), _ptr(wld), _ptr(results)))
+        return wld, results[: 2 * (num_games // 2)]
+
+
+class TreeBatch:
+    """n_games x AsyncMcts::default(..) rooted at the initial board (src/async_mcts.rs:27-48)."""
+
+    def __init__(self, engine, n_games, reserve, num_sims, max_depth, model_id, cpuct):
+        self.engine = engine
+        self.n_games = n_games
+        h = C.c_void_p()
+        engine._check(_lib.az_tree_create(engine._h, n_games, reserve, num_sims, max_depth, model_id, cpuct, C.byref(h)))
+        self._h = h
+        self._log_cap = 0
+        engine._trees.add(self)
+
+    def close(self):
+        if self._h and self.engine._h:
+            _lib.az_tree_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_action_prob(self, states, temp, seed=0, first_game_id=0):
+        """states [G,2] uint64 canonical bitboards -> (pi [G,7] f32, counts [G,7] u16, q [G,7] f32)."""
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(self.n_games, 2)
+        pi = np.empty((self.n_games, ACTIONS), np.float32)
+        counts = np.empty((self.n_games, ACTIONS), np.uint16)
+        q = np.empty((self.n_games, ACTIONS), np.float32)
+        self.engine._check(_lib.az_tree_get_action_prob(self._h, _ptr(s), temp, seed, first_game_id, _ptr(pi),
+                                                        _ptr(counts), _ptr(q)))
+        return pi, counts, q
+
+    def record_evals(self, cap):
+        self.engine._check(_lib.az_tree_record_evals(self._h, cap))
+        self._log_cap = cap
+
+    def get_evals(self):
+        cap = self._log_cap
+        cnt = np.zeros(self.n_games, np.int32)
+        states = np.zeros((self.n_games, cap, 2), np.uint64)
+        pis = np.zeros((self.n_games, cap, ACTIONS), np.float32)
+        vs = np.zeros((self.n_games, cap), np.float32)
+        self.engine._check(_lib.az_tree_get_evals(self._h, _ptr(cnt), _ptr(states), _ptr(pis), _ptr(vs)))
+        return cnt, states, pis, vs
+
+    def node_counts(self):
+        out = np.zeros(self.n_games, np.uint32)
+        self.engine._check(_lib.az_tree_node_counts(self._h, _ptr(out)))
+        return out
+
+
+# ---- host-side helpers on canonical bitboards (mirror of the Game trait for Connect Four) ----
+def c4_play(mine, theirs, a):
+    """get_next_state(1, a) then get_canonical_form(next_player) (connect_four_game.rs:90-103, :198-203)."""
+    mask = mine | theirs
+    nb = (mask + (1 << (a * 7))) & (0x3F << (a * 7))
+    return theirs, mine | nb
+
+
+def c4_features(mine, theirs):
+    """to_features: [2,6,7] f32 (connect_four_game.rs:219-237, NCHW per repair S8)."""
+    f = np.zeros((2, 6, 7), np.float32)
+    for r in range(6):
+        for c in range(7):
+            bit = 1 << (c * 7 + (5 - r))
+            if mine & bit:
+                f[0, r, c] = 1.0
+            if theirs & bit:
+                f[1, r, c] = 1.0
+    return f

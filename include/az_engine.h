@@ -1,0 +1,187 @@
+/* az_engine.h -- C ABI of the MI355X-native AlphaZero self-play engine.
+ *
+ * Drop-in boundary for the async_mcts + arena hot path of AnimatedRNG/alphazero-rs.
+ * The reference has no FFI: its engine is reached through generic Rust traits
+ * (`Game`, src/game.rs:10-28; `NNet`, src/nnet.rs:35-45) consumed by
+ * `AsyncMcts<G>` (src/async_mcts.rs:14-115), whose callers are
+ * `Coach::execute_episode` (src/coach.rs:104-157) and `arena::play_games`
+ * (src/arena.rs:62-99).  The entry points below are what a Rust `extern "C"`
+ * block would bind to keep `Coach`/`arena` and swap the engine; each cites the
+ * reference item it replaces.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - Plain C types only; opaque handles; every output buffer is allocated and
+ *     owned by the caller; inputs are borrowed for the duration of the call.
+ *   - Every call returns an az_status (0 = ok).  The reference panics instead
+ *     (unwrap/assert!); the panic sites map onto the status codes below.
+ *   - A handle is used by one host thread at a time; calls are synchronous on
+ *     return.  One HIP stream per engine.
+ *   - Game state: Connect Four as two 7x6 bitboards in canonical form
+ *     {mine, theirs} (side to move = mine); bit(col,row) = col*7 + row with
+ *     row 0 = bottom; bit col*7+6 is always clear.
+ *   - Feature tensors are NCHW [B,2,6,7] f32, plane 0 = side to move, plane 1 =
+ *     opponent, row 0 = top (connect_four_game.rs:219-237 with repair S8).
+ *   - Pointers may be host or device memory unless stated otherwise (the
+ *     library copies with hipMemcpyDefault).
+ */
+#ifndef AZ_ENGINE_H
+#define AZ_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_ACTIONS 7       /* connect_four_game.rs:14 */
+#define AZ_FEATURES 84     /* 2*6*7, connect_four_game.rs:86-88 */
+#define AZ_MAX_PLIES 42
+
+typedef enum az_status {
+    AZ_OK = 0,
+    AZ_ERR_BAD_ARGUMENT = 1,   /* contract violations the reference asserts (src/async_mcts.rs:192, src/coach.rs:83) */
+    AZ_ERR_CAPACITY = 2,       /* node arena exhausted: assert!(idx < buf.len()), src/node.rs:237 */
+    AZ_ERR_HIP = 3,            /* HIP runtime / launch failure */
+    AZ_ERR_INVALID_MOVE = 4,   /* arena validity assert, src/arena.rs:31-35 */
+    AZ_ERR_TERMINAL_ROOT = 5,  /* get_action_prob on a finished game: p.unwrap() panic, src/async_mcts.rs:85 */
+    AZ_ERR_NO_MODEL = 6,       /* model_id was never initialised / loaded */
+    AZ_ERR_IO = 7,             /* checkpoint read/write */
+    AZ_ERR_UNSUPPORTED = 8
+} az_status;
+
+/* Which network answers NNet::predict for a model id. */
+typedef enum az_net_kind {
+    AZ_NET_STUB = 0,   /* DumbConnectFourNnet, examples/connect_four.rs:12-43: pi = 1/7, v = +1 */
+    AZ_NET_HASH = 1,   /* deterministic pseudo-random net (test fixture, exact in f32) */
+    AZ_NET_CONV = 2    /* policy+value conv net, connect_four_net.py:20-95, bf16 MFMA */
+} az_net_kind;
+
+typedef struct az_engine az_engine;
+typedef struct az_tree az_tree;
+
+typedef struct az_config {
+    int32_t device;        /* HIP device ordinal */
+    int32_t max_batch;     /* largest leaf batch the conv net is sized for (0 = 8192) */
+    int32_t net_channels;  /* conv width; 0 = 512 (connect_four_net.py:21) */
+    int32_t profile;       /* !=0: bracket the dominant kernels with HIP events (az_get_stats) */
+} az_config;
+
+/* Counters (SURVEY.md 8b "Introspection"); all cumulative since az_create / az_reset_stats. */
+typedef struct az_stats {
+    uint64_t games;          /* finished self-play / arena games */
+    uint64_t moves;          /* get_action_prob calls */
+    uint64_t simulations;    /* search_iteration calls, src/async_mcts.rs:219 */
+    uint64_t expansions;     /* upgrade -> Some(true), src/node.rs:290-323 */
+    uint64_t leaf_evals;     /* NNet::predict rows (root priors included) */
+    uint64_t link_hits;      /* upgrade -> Some(false), src/node.rs:285-289 */
+    uint64_t terminal_hits;  /* simulations that ended on an existing terminal node */
+    uint64_t depth_sum;      /* best_child calls (selection levels) */
+    uint64_t samples;        /* training tuples emitted (before symmetries) */
+    uint64_t net_launches;   /* conv2 launches timed (profile mode) */
+    double net_conv2_ms;     /* summed conv2 kernel time (profile mode) */
+    double net_conv2_flops;  /* summed conv2 algorithmic flops (profile mode) */
+    double net_total_ms;     /* summed whole-forward time (profile mode) */
+    double net_total_flops;  /* summed whole-forward algorithmic flops (profile mode) */
+    double tree_ms;          /* summed select+backup kernel time (profile mode) */
+    double tree_bytes;       /* summed algorithmic tree bytes, SURVEY.md 8d (profile mode) */
+    double device_ms;        /* summed wall time spent inside engine calls */
+} az_stats;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+az_status az_create(const az_config* cfg, az_engine** out);
+void az_destroy(az_engine* e);
+const char* az_last_error(const az_engine* e);
+az_status az_get_stats(az_engine* e, az_stats* out);
+az_status az_reset_stats(az_engine* e);
+
+/* ---- NNet trait, src/nnet.rs:35-45 -------------------------------------- */
+/* NNet::new for the stub / hash nets (no weights). salt only matters for AZ_NET_HASH. */
+az_status az_net_set_kind(az_engine* e, int32_t model_id, az_net_kind kind, uint64_t salt);
+/* NNet::new with random init: Glorot-uniform kernels, zero bias, BN gamma=1 beta=0 mean=0 var=1 eps=1e-3. */
+az_status az_net_init_random(az_engine* e, int32_t model_id, uint64_t seed);
+/* NNet::new(checkpoint) / save: flat f32 file, layout in DESIGN.md "weights file". */
+az_status az_net_load(az_engine* e, int32_t model_id, const char* path);
+az_status az_net_save(az_engine* e, int32_t model_id, const char* path);
+/* Raw f32 parameter exchange (same order as the weights file); count from az_net_param_count. */
+int64_t az_net_param_count(const az_engine* e);
+az_status az_net_set_params(az_engine* e, int32_t model_id, const float* params, int64_t n);
+az_status az_net_get_params(az_engine* e, int32_t model_id, float* params, int64_t n);
+/* NNet::predict(board [B,2,6,7], model_id) -> (pi [B,7], v [B]), src/nnet.rs:40-44 */
+az_status az_net_predict(az_engine* e, int32_t model_id, const float* boards, int32_t B, float* pi, float* v);
+/* Same on canonical bitboards [B,2] (what the search feeds the net). */
+az_status az_net_predict_states(az_engine* e, int32_t model_id, const uint64_t* states, int32_t B, float* pi, float* v);
+/* NNet::train(examples, previous_model_id, model_id), src/nnet.rs:38 -- next tier; returns AZ_ERR_UNSUPPORTED. */
+az_status az_net_train(az_engine* e, int32_t prev_id, int32_t id, const float* boards, const float* pis,
+                       const float* vs, int64_t n);
+
+/* ---- AsyncMcts, src/async_mcts.rs:14-115 -------------------------------- */
+/* n_games independent AsyncMcts::default(reserve, num_sims, 1, max_depth, model_id, cpuct, ..)
+ * (src/async_mcts.rs:27-48), each rooted at the initial board (NodeStore::new, src/node.rs:156-166).
+ * num_threads is fixed at 1 (one simulation in flight per tree: the deterministic mode). */
+az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_t num_sims, int32_t max_depth,
+                         int32_t model_id, int32_t cpuct, az_tree** out);
+void az_tree_destroy(az_tree* t);
+/* get_action_prob(&self, s, temp, episode_id, rng) for every tree at once (src/async_mcts.rs:74-115).
+ * states [G,2]; outputs pi [G,7], counts [G,7] (child N), q [G,7] (child Q); counts/q may be NULL.
+ * RNG (temp == 0 tie-break) = stream (seed, first_game_id + g, ply = stones on board). */
+az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp, uint64_t seed,
+                                  uint64_t first_game_id, float* pi, uint16_t* counts, float* q);
+/* Record every NNet::predict the search issues, per tree, in order (replay parity). cap = records per tree. */
+az_status az_tree_record_evals(az_tree* t, int32_t cap);
+/* Copy out the record log: rec_count [G]; states [G,cap,2], pis [G,cap,7], vs [G,cap] (any may be NULL). */
+az_status az_tree_get_evals(az_tree* t, int32_t* rec_count, uint64_t* states, float* pis, float* vs);
+/* Node count (NodeStore::len, src/node.rs:372-374) per tree, [G]. */
+az_status az_tree_node_counts(az_tree* t, uint32_t* out);
+
+/* ---- Coach::execute_episode x many, src/coach.rs:104-157 ------------------ */
+typedef struct az_selfplay_params {
+    int32_t n_games;         /* episodes to play in this call (global ids first_game_id .. +n_games) */
+    int32_t concurrent;      /* game slots resident at once (0 = n_games); finished slots are refilled */
+    int32_t num_sims;        /* src/coach.rs:30 */
+    int32_t temp_threshold;  /* src/coach.rs:22 */
+    int32_t max_depth;       /* src/coach.rs:32 */
+    int32_t cpuct;           /* src/coach.rs:33 */
+    int32_t model_id;
+    int32_t symmetries;      /* !=0: emit identity + mirror per position (get_symmetries), else identity only */
+    uint64_t reserve;        /* mcts_reserve_size, src/coach.rs:20 (clamped to the reachable bound) */
+    uint64_t seed;
+    uint64_t first_game_id;
+    int32_t record_evals;    /* records per game kept for az_selfplay_get_evals (0 = off) */
+    int32_t reserved0;
+} az_selfplay_params;
+
+/* Training tuples (s, pi, z) in game-id order then ply order; TrainingSample, src/nnet.rs:22-27. */
+typedef struct az_samples {
+    int64_t capacity;     /* in: tuples the arrays can hold (n_games*42, x2 with symmetries, always suffices) */
+    int64_t count;        /* out */
+    uint64_t* states;     /* [capacity,2] canonical bitboards (may be NULL) */
+    float* boards;        /* [capacity,2,6,7] features (may be NULL) */
+    float* pis;           /* [capacity,7] */
+    float* zs;            /* [capacity] */
+    int32_t* game_len;    /* [n_games] plies per game (may be NULL) */
+    uint8_t* moves;       /* [n_games,42] actions played (may be NULL) */
+} az_samples;
+
+az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out);
+/* Eval log of the last az_selfplay with record_evals > 0: rec_count [n_games], states [n_games,cap,2], ... */
+az_status az_selfplay_get_evals(az_engine* e, int32_t* rec_count, uint64_t* states, float* pis, float* vs);
+
+/* ---- arena::play_games, src/arena.rs:62-99 + gate, src/coach.rs:377-390 ---- */
+typedef struct az_arena_params {
+    int32_t num_games;      /* num/2 per seating, src/arena.rs:83 */
+    int32_t num_sims;
+    int32_t max_depth;
+    int32_t cpuct;
+    int32_t new_model_id;   /* first listed player ("new", nmcts, src/coach.rs:345-354) */
+    int32_t old_model_id;   /* second listed player ("old", pmcts, src/coach.rs:333-343) */
+    uint64_t reserve;
+    uint64_t seed;
+} az_arena_params;
+/* out_wld[3] = {Win, Loss, Draw} for the new model (GameResult, src/arena.rs:54-59);
+ * results [num_games] (may be NULL): +1 first seat won, -1 second seat won, 0 draw (play_game, src/arena.rs:51). */
+az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], int8_t* results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZ_ENGINE_H */

@@ -1,0 +1,230 @@
+"""GPU parity: the HIP tree kernels against the CPU oracle, through the C ABI.
+
+Bit-exact bar (integer / index work and f32 in the reference's operation order):
+visit counts, chosen moves, pi, Q and z must be identical to the oracle's on the same
+seeds.  The nets used here are the reference's stub (examples/connect_four.rs:12-43)
+and the exact-in-f32 hash fixture, so no net numerics enter (the bf16 conv net is
+covered by test_net_gpu.py: numerics alone + replay parity).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HASH_SALT = 1234
+MODEL_SALT = 0x51ED27
+
+
+def oracle_salt(model_id):
+    return HASH_SALT + model_id * MODEL_SALT
+
+
+def play_episode_lockstep(engine, oracle, n_games, sims, model_id, okind, osalt, temp_schedule, seed, max_moves=42):
+    """Drives az_tree_get_action_prob move by move for n_games trees and the oracle's AsyncMcts alongside;
+    every move compares pi / counts / Q, then plays the oracle-agreed move."""
+    tb = engine.tree_create(n_games, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=1000,
+                            model_id=model_id, cpuct=1)
+    trees = [oracle.Tree(sims, net_kind=okind, salt=osalt) for _ in range(n_games)]
+    states = [(0, 0)] * n_games
+    alive = [True] * n_games
+    rng = np.random.default_rng(seed)
+    for move in range(max_moves):
+        if not any(alive):
+            break
+        temp = temp_schedule(move)
+        # finished games keep searching their last non-terminal position on both sides (the tree keeps growing)
+        pi, counts, q = tb.get_action_prob(np.array(states, dtype=np.uint64), temp, seed=seed, first_game_id=100)
+        for g in range(n_games):
+            opi, ocnt, oq = trees[g].get_action_prob(states[g][0], states[g][1], temp, seed=seed, game_id=100 + g)
+            assert np.array_equal(counts[g], ocnt), (move, g, counts[g], ocnt)
+            assert np.array_equal(pi[g], opi), (move, g, pi[g], opi)
+            assert np.array_equal(q[g], oq), (move, g, q[g], oq)
+            if not alive[g]:
+                continue
+            legal = [a for a in range(7) if opi[a] > 0]
+            a = int(rng.choice(legal))
+            nxt = oracle.c4_play(states[g][0], states[g][1], a)
+            if oracle.c4_ended(*nxt) != 0.0:
+                alive[g] = False        # keep the old state so the engine never sees a terminal root
+            else:
+                states[g] = nxt
+    return tb, trees, tb.node_counts()
+
+
+@pytest.mark.parametrize("n_games,sims", [(1, 25), (5, 25), (16, 100)])
+def test_get_action_prob_stub_net(engine, oracle, n_games, sims):
+    """config 1 semantics (stub net, cpuct 1): every move of whole games, counts / pi / Q bit-exact."""
+    play_episode_lockstep(engine, oracle, n_games, sims, 0, oracle.NET_STUB, 0, lambda m: 1.0 if m < 14 else 0.0, 3)
+
+
+@pytest.mark.parametrize("n_games,sims", [(3, 25), (33, 100), (8, 400)])
+def test_get_action_prob_hash_net(engine, oracle, n_games, sims):
+    play_episode_lockstep(engine, oracle, n_games, sims, 10, oracle.NET_HASH, oracle_salt(10),
+                          lambda m: 1.0 if m < 14 else 0.0, 11)
+
+
+def test_get_action_prob_temp0_tiebreak(engine, oracle):
+    """temp == 0 from the first move: the uniform pick among equal max counts uses the build's RNG stream."""
+    play_episode_lockstep(engine, oracle, 24, 25, 0, oracle.NET_STUB, 0, lambda m: 0.0, 99)
+
+
+def test_node_counts_and_stats_match(engine, oracle):
+    """NodeStore::len and the expansion / link / terminal counters agree with the oracle."""
+    sims, n = 100, 6
+    engine.reset_stats()
+    tb, trees, nodes = play_episode_lockstep(engine, oracle, n, sims, 10, oracle.NET_HASH, oracle_salt(10),
+                                             lambda m: 1.0, 5)
+    ost = [t.stats() for t in trees]
+    assert [int(x) for x in nodes] == [s["nodes"] for s in ost]
+    st = engine.stats()
+    for mine, theirs in (("simulations", "sims"), ("expansions", "expansions"), ("leaf_evals", "leaf_evals"),
+                         ("link_hits", "link_hits"), ("terminal_hits", "terminal_hits"), ("depth_sum", "depth_sum")):
+        assert st[mine] == sum(s[theirs] for s in ost), (mine, st[mine])
+
+
+def _compare_selfplay(got, ref):
+    assert got["count"] == ref["count"]
+    assert np.array_equal(got["game_len"], ref["game_len"])
+    assert np.array_equal(got["moves"], ref["moves"])
+    assert np.array_equal(got["boards"].reshape(-1, 84), ref["boards"].reshape(-1, 84))
+    assert np.array_equal(got["pis"], ref["pis"])
+    assert np.array_equal(got["zs"], ref["zs"])
+
+
+@pytest.mark.parametrize("n_games,sims,model_id", [(1, 25, 0), (7, 25, 0), (64, 100, 10), (256, 25, 10)])
+def test_selfplay_matches_execute_episode(engine, oracle, n_games, sims, model_id):
+    """az_selfplay == Coach::execute_episode per game id: moves, (s, pi, z) tuples incl. symmetries."""
+    okind = oracle.NET_STUB if model_id == 0 else oracle.NET_HASH
+    got = engine.selfplay(n_games=n_games, num_sims=sims, model_id=model_id, seed=42, first_game_id=7)
+    ref = oracle.selfplay(n_games, sims, net_kind=okind, salt=oracle_salt(model_id) if model_id else 0, seed=42,
+                          first_game_id=7, threads=8)
+    _compare_selfplay(got, ref)
+    # decoded bitboards agree with the feature planes
+    from alphazero_rs_amd import engine as azeng
+    for i in range(0, got["count"], max(1, got["count"] // 16)):
+        m, t = (int(x) for x in got["states"][i])
+        assert np.array_equal(azeng.c4_features(m, t), got["boards"][i])
+
+
+def test_selfplay_refill_is_slot_independent(engine, oracle):
+    """Finished slots are refilled with the next episode id; results depend on the episode id only."""
+    n, sims = 96, 25
+    ref = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=8, threads=8)
+    for concurrent in (96, 32, 5):
+        got = engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=8, concurrent=concurrent)
+        _compare_selfplay(got, ref)
+
+
+def test_selfplay_shard_invariance(engine, oracle):
+    """Sharding by global game id (multi-GPU partitioning) changes nothing: two half-ranges == one full range."""
+    n, sims = 64, 25
+    full = engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=21, first_game_id=1000)
+    lo = engine.selfplay(n_games=n // 2, num_sims=sims, model_id=10, seed=21, first_game_id=1000)
+    hi = engine.selfplay(n_games=n // 2, num_sims=sims, model_id=10, seed=21, first_game_id=1000 + n // 2)
+    assert full["count"] == lo["count"] + hi["count"]
+    assert np.array_equal(full["pis"], np.concatenate([lo["pis"], hi["pis"]]))
+    assert np.array_equal(full["zs"], np.concatenate([lo["zs"], hi["zs"]]))
+    assert np.array_equal(full["states"], np.concatenate([lo["states"], hi["states"]]))
+
+
+def test_selfplay_no_symmetries_and_temp_threshold(engine, oracle):
+    got = engine.selfplay(n_games=16, num_sims=25, model_id=10, seed=3, symmetries=False, temp_threshold=4)
+    ref = oracle.selfplay(16, 25, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=3, temp_threshold=4, threads=8)
+    assert got["count"] * 2 == ref["count"]
+    assert np.array_equal(got["pis"], ref["pis"][0::2])
+    assert np.array_equal(got["zs"], ref["zs"][0::2])
+    assert np.array_equal(got["moves"], ref["moves"])
+
+
+def test_from_arbitrary_root_s10(engine, oracle):
+    """S10: a root state the tree has never seen (arena's second player) is pushed + upgraded, then searched."""
+    sims = 50
+    # position after 1. d1 c1 2. d2: side to move has stones at c1
+    s = (0, 0)
+    for a in (3, 2, 3):
+        s = oracle.c4_play(s[0], s[1], a)
+    tb = engine.tree_create(4, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=1000, model_id=10, cpuct=1)
+    pi, counts, q = tb.get_action_prob(np.array([s] * 4, dtype=np.uint64), 1.0, seed=1, first_game_id=0)
+    t = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10))
+    opi, ocnt, oq = t.get_action_prob(s[0], s[1], 1.0, seed=1, game_id=0)
+    for g in range(4):
+        assert np.array_equal(counts[g], ocnt) and np.array_equal(pi[g], opi) and np.array_equal(q[g], oq)
+    assert int(tb.node_counts()[0]) == t.stats()["nodes"]
+
+
+def test_terminal_and_near_terminal_roots(engine, oracle, engine_mod):
+    """Edge cases: a root one move from a win / a full board (terminal expansions, S4), and the
+    terminal-root error (the reference panics at src/async_mcts.rs:85)."""
+    sims = 100
+    # three in a column for the side to move, opponent scattered: a win is one ply away
+    s = (0, 0)
+    for a in (0, 1, 0, 2, 0, 4):
+        s = oracle.c4_play(s[0], s[1], a)
+    tb = engine.tree_create(2, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=1000, model_id=10, cpuct=1)
+    pi, counts, q = tb.get_action_prob(np.array([s, s], dtype=np.uint64), 1.0)
+    t = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10))
+    opi, ocnt, oq = t.get_action_prob(s[0], s[1], 1.0)
+    assert np.array_equal(counts[0], ocnt) and np.array_equal(pi[1], opi) and np.array_equal(q[0], oq)
+    # finished game as root -> AZ_ERR_TERMINAL_ROOT
+    w = oracle.c4_play(s[0], s[1], 0)
+    assert oracle.c4_ended(*w) == -1.0
+    tb2 = engine.tree_create(1, reserve=1000, num_sims=10, max_depth=1000, model_id=0, cpuct=1)
+    with pytest.raises(engine_mod.AzError) as ei:
+        tb2.get_action_prob(np.array([w], dtype=np.uint64), 1.0)
+    assert ei.value.status == 5
+
+
+def test_draw_value_and_full_board(engine, oracle):
+    """Play a game to a nearly full board with no winner, then search: DRAW_EPS leaves (e = -1e-4) back up
+    as 0 / +0.01 per the packed counter's arithmetic (C4)."""
+    # column order that fills the board without any four-in-a-row
+    seq = [0, 1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0,  2, 3, 2, 3, 3, 2, 2, 3, 2, 3, 3, 2,
+           4, 5, 4, 5, 5, 4, 4, 5, 4, 5, 5, 4,  6, 6, 6]
+    s = (0, 0)
+    for a in seq:
+        s = oracle.c4_play(s[0], s[1], a)
+        assert oracle.c4_ended(*s) == 0.0
+    sims = 30
+    tb = engine.tree_create(1, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=1000, model_id=10, cpuct=1)
+    pi, counts, q = tb.get_action_prob(np.array([s], dtype=np.uint64), 1.0)
+    t = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10))
+    opi, ocnt, oq = t.get_action_prob(s[0], s[1], 1.0)
+    assert np.array_equal(counts[0], ocnt) and np.array_equal(pi[0], opi) and np.array_equal(q[0], oq)
+    assert int(ocnt.sum()) == sims
+
+
+def test_capacity_error(engine, engine_mod):
+    """reserve too small -> AZ_ERR_CAPACITY (the reference asserts at src/node.rs:237)."""
+    tb = engine.tree_create(2, reserve=40, num_sims=100, max_depth=1000, model_id=0, cpuct=1)
+    with pytest.raises(engine_mod.AzError) as ei:
+        tb.get_action_prob(np.zeros((2, 2), np.uint64), 1.0)
+    assert ei.value.status == 2
+
+
+def test_bad_arguments(engine, engine_mod):
+    with pytest.raises(engine_mod.AzError):
+        engine.tree_create(0, reserve=100, num_sims=10, max_depth=10, model_id=0, cpuct=1)
+    with pytest.raises(engine_mod.AzError) as ei:
+        engine.tree_create(1, reserve=100, num_sims=10, max_depth=10, model_id=999, cpuct=1).get_action_prob(
+            np.zeros((1, 2), np.uint64), 1.0)
+    assert ei.value.status == 6
+
+
+def test_full_size_properties(engine):
+    """BASELINE config-2 concurrency (8192 games, 100 sims/move) with the stub net: size-independent
+    properties -- every pi is a distribution over legal moves, z in {-1, +1, +-1e-4}, every game ends with
+    a win or a full board, sample count == 2 * total plies, and simulations == 100 * plies."""
+    engine.reset_stats()
+    n = 8192
+    got = engine.selfplay(n_games=n, num_sims=100, model_id=0, seed=1, want_boards=False)
+    plies = got["game_len"].astype(np.int64)
+    assert plies.min() >= 7 and plies.max() <= 42
+    assert got["count"] == 2 * plies.sum()
+    pis, zs = got["pis"], got["zs"]
+    assert np.all(np.abs(pis.sum(axis=1) - 1.0) < 1e-5)
+    assert np.all((np.abs(zs) == 1.0) | (np.abs(np.abs(zs) - 1e-4) < 1e-9))
+    st = engine.stats()
+    assert st["games"] == n and st["simulations"] == 100 * plies.sum()
+    # mirror symmetry: odd rows are the mirrored twin of even rows
+    assert np.array_equal(pis[0::2], pis[1::2, ::-1])
+    assert np.array_equal(zs[0::2], zs[1::2])
