@@ -46,7 +46,7 @@ struct NetModel {
 };
 
 // timed regions (profile mode): event pairs recorded on the engine stream, resolved at sync points
-enum Region { RG_TREE = 0, RG_NET = 1, RG_COUNT };
+enum Region { RG_TREE = 0, RG_NET = 1, RG_COUNT };   // RG_NET brackets the whole predict (kept for stub nets)
 struct Profiler {
     bool on = false;
     std::vector<hipEvent_t> pool;
@@ -210,7 +210,8 @@ void resolve_profile(az_engine* e) {
     double ms[RG_COUNT] = {0, 0};
     e->prof.resolve(ms);
     e->stats.tree_ms += ms[RG_TREE];
-    e->stats.net_total_ms += ms[RG_NET];
+    for (auto& kv : e->nets)
+        if (kv.second.conv) convnet_resolve_profile(kv.second.conv, &e->netprof);
 }
 
 // fold the per-tree counters into the engine stats and clear them
@@ -306,6 +307,7 @@ az_status az_get_stats(az_engine* e, az_stats* out) {
     out->net_launches = e->netprof.launches;
     out->net_conv2_ms = e->netprof.conv2_ms;
     out->net_conv2_flops = e->netprof.conv2_flops;
+    out->net_total_ms = e->netprof.total_ms;
     out->net_total_flops = e->netprof.total_flops;
     return AZ_OK;
 }

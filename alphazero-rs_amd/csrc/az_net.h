@@ -26,8 +26,10 @@ int64_t convnet_param_count(int channels);
 bool convnet_set_params(ConvNet* n, const float* host_params, int64_t count);
 bool convnet_get_params(const ConvNet* n, float* host_params, int64_t count);
 void convnet_init_random(ConvNet* n, uint64_t seed);
+// fold finished profile records into *prof (call after the stream has been synchronised)
+void convnet_resolve_profile(ConvNet* n, NetProfile* prof);
 // forward for rows [0, *eb.n); n_rows_hint = host-side upper bound used to size the grids.
-// If prof != nullptr the forward is bracketed with HIP events (synchronises the stream).
+// If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
 void convnet_forward(ConvNet* n, const EvalBatch& eb, int n_rows_hint, hipStream_t s, NetProfile* prof);
 
 }  // namespace az

@@ -141,35 +141,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
     // staging map: 16-byte item i = q*256 + tid -> tile row i>>3, LDS slot i&7, logical chunk slot ^ (row&7)
     const int srow = tid >> 3;
     const int chunk = (tid & 7) ^ (srow & 7);
-    uint32_t a_off[4], b_off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    auto row_off = [&](int q) -> uint32_t {
         int m = m0 + q * 32 + srow;
         m = m < M ? m : M - 1;
         const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
         const int y = r / d.out_w, x = r - y * d.out_w;
-        a_off[q] = (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
-        b_off[q] = (uint32_t)((n0 + q * 32 + srow) * d.K + chunk * 8);
+        return (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
+    };
+    const uint32_t a_off0 = row_off(0), a_off1 = row_off(1), a_off2 = row_off(2), a_off3 = row_off(3);
+    const uint32_t b_off0 = (uint32_t)((n0 + srow) * d.K + chunk * 8), b_off1 = b_off0 + 32u * (uint32_t)d.K,
+                   b_off2 = b_off0 + 64u * (uint32_t)d.K, b_off3 = b_off0 + 96u * (uint32_t)d.K;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    // global -> registers for K-step kt (no lambdas / arrays: keeps everything in VGPRs, no scratch)
+#define AZ_GLOAD(kt_)                                                                           \
+    {                                                                                           \
+        const int kk = (kt_) * GBK;                                                             \
+        const int tap = kk / d.cin, c0 = kk - tap * d.cin;                                      \
+        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                  \
+        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                     \
+        ra0 = *(const uint4*)(d.A + a_off0 + toff); ra1 = *(const uint4*)(d.A + a_off1 + toff); \
+        ra2 = *(const uint4*)(d.A + a_off2 + toff); ra3 = *(const uint4*)(d.A + a_off3 + toff); \
+        rb0 = *(const uint4*)(d.W + b_off0 + kk); rb1 = *(const uint4*)(d.W + b_off1 + kk);     \
+        rb2 = *(const uint4*)(d.W + b_off2 + kk); rb3 = *(const uint4*)(d.W + b_off3 + kk);     \
     }
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-        const int kk = kt * GBK;
-        const int tap = kk / d.cin, c0 = kk - tap * d.cin;
-        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;
-        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[q] = *(const uint4*)(d.A + a_off[q] + toff);
-            rb[q] = *(const uint4*)(d.W + b_off[q] + kk);
-        }
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *(uint4*)(smem[buf] + (q * 256 + tid) * 16) = ra[q];
-            *(uint4*)(smem[buf] + GBM * 128 + (q * 256 + tid) * 16) = rb[q];
-        }
-    };
+#define AZ_SWRITE(buf_)                                                                         \
+    {                                                                                           \
+        unsigned char* sa_ = smem[buf_] + tid * 16;                                             \
+        unsigned char* sb_ = sa_ + GBM * 128;                                                   \
+        *(uint4*)(sa_) = ra0; *(uint4*)(sa_ + 4096) = ra1; *(uint4*)(sa_ + 8192) = ra2; *(uint4*)(sa_ + 12288) = ra3; \
+        *(uint4*)(sb_) = rb0; *(uint4*)(sb_ + 4096) = rb1; *(uint4*)(sb_ + 8192) = rb2; *(uint4*)(sb_ + 12288) = rb3; \
+    }
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -177,11 +178,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
         for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = d.K / GBK;
     const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
-    gload(0);
-    swrite(0);
+    AZ_GLOAD(0);
+    AZ_SWRITE(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) AZ_GLOAD(kt + 1);
         const unsigned char* sA = smem[kt & 1];
         const unsigned char* sB = sA + GBM * 128;
 #pragma unroll
@@ -200,9 +201,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
         }
-        if (kt + 1 < nk) swrite((kt + 1) & 1);
+        if (kt + 1 < nk) AZ_SWRITE((kt + 1) & 1);
         __syncthreads();
     }
+#undef AZ_GLOAD
+#undef AZ_SWRITE
     // epilogue: + bias, ReLU, bf16, out[m][n .. n+3]
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {

@@ -19,6 +19,7 @@ struct TreeBase {
                                 float* pi, uint16_t* counts, float* q) = 0;
     virtual SearchStats stats() = 0;
     virtual size_t n_nodes() = 0;
+    virtual ReplayNet* replay_net() = 0;
 };
 
 C4Array array_from_bits(uint64_t mine, uint64_t theirs, bool literal) {
@@ -74,6 +75,7 @@ struct TreeImpl : TreeBase {
     }
     SearchStats stats() override { return mcts->stats; }
     size_t n_nodes() override { return mcts->nodes->size(); }
+    ReplayNet* replay_net() override { return &nets.replay; }
 };
 
 Quirks quirks_from_bits(uint32_t b) {
@@ -178,6 +180,12 @@ int azo_tree_get_action_prob(void* t, uint64_t mine, uint64_t theirs, float temp
                              float* pi, uint16_t* counts, float* q) {
     return ((TreeBase*)t)->get_action_prob(mine, theirs, temp, seed, game_id, pi, counts, q);
 }
+// replay records for a tree created with net_kind 2 (borrowed pointers; must outlive the calls)
+void azo_tree_set_replay(void* t, const uint64_t* states, const float* pis, const float* vs, uint64_t n) {
+    ReplayNet* r = ((TreeBase*)t)->replay_net();
+    r->states = states; r->pis = pis; r->vs = vs; r->n = (size_t)n; r->pos = 0; r->mismatch = false;
+}
+int azo_tree_replay_bad(void* t) { return ((TreeBase*)t)->replay_net()->mismatch ? 1 : 0; }
 void azo_tree_stats(void* t, uint64_t* out7) {
     SearchStats s = ((TreeBase*)t)->stats();
     out7[0] = s.sims; out7[1] = s.expansions; out7[2] = s.leaf_evals; out7[3] = s.link_hits;
