@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the async_mcts hot path on MI355X.
+
+Metric (BASELINE.json): self-play games/sec (+ MCTS node-expansions/sec) on connect_four at 100 sims/move,
+8192 concurrent games per GPU, bf16 policy+value net (C=512), random-init weights, synthetic = self-generated
+positions from the empty board.
+
+A "step" = one episode batch through the hot path: `--episodes` self-play games per GPU played to completion on
+`--games` concurrent slots (finished slots are refilled), then the RCCL gather of the (s, pi, z) tuples to rank 0
+when N > 1.  Weak scaling: per-GPU work is fixed; `value` = all ranks' games / max-over-ranks time.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (conv2's implicit-GEMM MFMA kernel, timed
+live with HIP events on the engine's stream) and "cpu_baseline" (the CPU oracle driving the same search with the
+same f32 net on torch-CPU, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK_GBS = 8000.0
+FLOP_PER_LEAF = 328_986_624
+
+
+def cpu_baseline(params, channels, sims, mean_plies=None, budget_s=20.0, seed=1):
+    """The oracle (port of the reference semantics) running the SAME workload on the host cores:
+    100 sims/move self-play, NNet::predict = the textbook f32 net on torch-CPU at inference batch 1
+    (the reference's own configuration: inference_batch_size 1, examples/connect_four.rs:61)."""
+    import numpy as np
+    import torch
+    from oracle import oracle_py as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from net_ref import unpack, BN_EPS
+    import torch.nn.functional as F
+
+    P = unpack(np.asarray(params, np.float32), channels)
+    convs = []
+    for l in range(4):
+        bn = P[f"conv{l+1}_bn"]
+        convs.append((P[f"conv{l+1}_w"].permute(3, 2, 0, 1).contiguous(), P[f"conv{l+1}_b"], bn, 1 if l < 2 else 0))
+
+    def predict(boards, model_id):
+        with torch.no_grad():
+            x = torch.from_numpy(np.ascontiguousarray(boards))
+            for w, b, bn, pad in convs:
+                x = torch.relu(F.batch_norm(F.conv2d(x, w, b, padding=pad), bn[2], bn[3], bn[0], bn[1], False, 0.0, BN_EPS))
+            x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+            for l in range(2):
+                bn = P[f"fc{l+1}_bn"]
+                x = torch.relu(F.batch_norm(x @ P[f"fc{l+1}_w"] + P[f"fc{l+1}_b"], bn[2], bn[3], bn[0], bn[1], False, 0.0, BN_EPS))
+            pi = torch.softmax(x @ P["pi_w"] + P["pi_b"], dim=1)
+            v = torch.tanh(x @ P["v_w"] + P["v_b"]).reshape(-1)
+        return pi.numpy(), v.numpy()
+
+    orc.set_predict_callback(predict)
+    share = min(os.cpu_count() or 1, 16)          # the box's CPU share for one GPU
+    torch.set_num_threads(share)
+    # Bounded sample: the opening plies of one episode, move by move, until ~budget_s of CPU work is done.
+    tree = orc.Tree(sims, net_kind=orc.NET_CALLBACK)
+    s, ply, gid, plies, games_done = (0, 0), 0, 0, 0, 0
+    st = {"leaf_evals": 0, "expansions": 0, "sims": 0}
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        temp = 1.0 if ply + 1 < 15 else 0.0
+        pi, counts, q = tree.get_action_prob(s[0], s[1], temp, seed=seed, game_id=gid)
+        a = orc.lib().azo_rng_choose_weighted(orc.lib().azo_rng_draw(seed, gid, ply, 2), pi.ctypes.data, 7)
+        s = orc.c4_play(s[0], s[1], a)
+        ply += 1
+        plies += 1
+        if orc.c4_ended(*s) != 0.0:          # episode over: start the next one on a fresh tree
+            for k in st:
+                st[k] += tree.stats()[k]
+            tree, s, ply, gid, games_done = orc.Tree(sims, net_kind=orc.NET_CALLBACK), (0, 0), 0, gid + 1, games_done + 1
+    dt = time.perf_counter() - t0
+    for k in st:
+        st[k] += tree.stats()[k]
+    ply = plies
+    plies_per_game = mean_plies if mean_plies else 22.6
+    # tree-only rate (stub net), one game per thread, for context
+    t1 = time.perf_counter()
+    rs = orc.selfplay(8 * share, sims, net_kind=orc.NET_STUB, seed=seed, threads=share, want_samples=False)
+    dts = time.perf_counter() - t1
+    return {
+        "value": ply / dt / plies_per_game, "unit": "games/s", "cores": share, "kind": "port",
+        "sample": f"{ply} plies ({games_done} finished episodes + the opening of the next) x {sims} sims/move = {st['leaf_evals']} leaf evals of the f32 "
+                  f"C={channels} net on torch-CPU ({share} threads, inference batch 1 as examples/connect_four.rs:61) in "
+                  f"{dt:.1f} s; games/s = plies/s / {plies_per_game:.1f} mean plies per game of the GPU run",
+        "node_expansions_per_sec": st["expansions"] / dt, "simulations_per_sec": st["sims"] / dt,
+        "tree_only": {"value": 8 * share / dts, "unit": "games/s", "cores": share,
+                      "sample": f"{8 * share} episodes, stub net (pi=1/7, v=+1), one game per thread, {dts:.2f} s",
+                      "sims_per_sec": rs["stats"]["sims"] / dts},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=8192, help="concurrent game slots per GPU")
+    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU per step (0 = 2 x --games)")
+    ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--net", default="conv", choices=["conv", "stub"])
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    episodes = args.episodes or 2 * args.games
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from alphazero_rs_amd import engine as azeng
+    from alphazero_rs_amd import dist as azdist
+    e = azeng.Engine(device=local_rank, max_batch=args.games, net_channels=args.channels, profile=not args.no_profile)
+    if args.net == "conv":
+        e.net_init_random(0, seed=args.seed)       # identical weights on every rank (replicated, 21.5 MB bf16)
+    else:
+        e.net_set_kind(0, azeng.NET_STUB)
+
+    cap = episodes * 42
+    out = {"states": torch.empty((cap, 2), dtype=torch.int64, device=dev),
+           "pis": torch.empty((cap, 7), dtype=torch.float32, device=dev),
+           "zs": torch.empty(cap, dtype=torch.float32, device=dev)}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        first = (i * world + rank) * episodes          # global game ids: disjoint per (step, rank)
+        r = e.selfplay(n_games=episodes, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
+                       first_game_id=first, symmetries=False, want_boards=False, out=out)
+        n = r["count"]
+        if world > 1:
+            packed = azdist.pack_samples(out["states"][:n], out["pis"][:n], out["zs"][:n])
+            azdist.gather_samples(packed, dst=0)
+        return n, int(r["game_len"].sum())
+
+    for i in range(args.warmup):
+        step(i)
+    e.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    samples = plies = 0
+    for i in range(args.steps):
+        n, p = step(args.warmup + i)
+        samples += n
+        plies += p
+    barrier()
+    dt = time.perf_counter() - t0
+    st = e.stats()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        agg = torch.tensor([st["expansions"], st["simulations"], st["leaf_evals"], plies], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        expansions, simulations, leaf_evals, plies_all = (float(x) for x in agg.tolist())
+    else:
+        expansions, simulations, leaf_evals, plies_all = st["expansions"], st["simulations"], st["leaf_evals"], plies
+
+    if rank == 0:
+        games = episodes * args.steps * world
+        line = {
+            "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.net == "conv" else "u64", "data": "synthetic",
+            "config": {"workload": f"connect_four self-play, {args.games} concurrent games/GPU, {episodes} episodes/GPU/step, "
+                                   f"{args.sims} sims/move, temp_threshold 15, cpuct 1, "
+                                   + (f"bf16 policy+value net C={args.channels} (random init)" if args.net == "conv" else "stub net"),
+                       "concurrent_games_per_gpu": args.games, "episodes_per_gpu_per_step": episodes,
+                       "sims_per_move": args.sims, "net": args.net, "parallelism": f"games-sharded x{world}"},
+            "node_expansions_per_sec": expansions / dt, "simulations_per_sec": simulations / dt,
+            "leaf_evals_per_sec": leaf_evals / dt, "mean_plies": plies_all / games,
+            "mfma_fraction_end_to_end": (leaf_evals / dt) * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12 * world) if args.net == "conv" else None,
+        }
+        roof = None
+        if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:
+            ach = st["net_conv2_flops"] / (st["net_conv2_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_gemm_mfma<1> (conv2: 3x3 same, 512->512, implicit GEMM)",
+                    "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                    "traffic": None, "launches": st["net_launches"],
+                    "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"],
+                    "avg_flop_per_launch": st["net_conv2_flops"] / st["net_launches"],
+                    "net_forward_tflops": st["net_total_flops"] / (st["net_total_ms"] * 1e-3) / 1e12}
+        elif not args.no_profile and st["tree_ms"] > 0:
+            ach = st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_select + k_backup (tree traversal)", "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        line["roofline"] = roof
+        if not args.no_profile and st["tree_ms"] > 0:
+            line["tree_hbm"] = {"achieved_GBps": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                                "frac": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_sim": st["tree_bytes"] / max(1, st["simulations"]),
+                                "mean_depth": st["depth_sum"] / max(1, st["simulations"])}
+        if world == 1 and not args.no_cpu_baseline and args.net == "conv":
+            try:
+                line["cpu_baseline"] = cpu_baseline(e.net_get_params(0), args.channels, args.sims, mean_plies=plies_all / games)
+            except Exception as ex:          # the baseline is reported, never required for the GPU number
+                line["cpu_baseline"] = {"error": repr(ex)}
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

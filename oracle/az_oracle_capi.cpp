@@ -11,7 +11,17 @@ using namespace azo;
 
 namespace {
 
-enum NetKind { NET_STUB = 0, NET_HASH = 1, NET_REPLAY = 2 };
+enum NetKind { NET_STUB = 0, NET_HASH = 1, NET_REPLAY = 2, NET_CALLBACK = 3 };
+
+// NNet::predict supplied by the caller (bench.py's cpu_baseline leg: the f32 conv net on torch-CPU).
+typedef void (*azo_predict_cb)(const float* boards, int B, int model_id, float* pi, float* v);
+azo_predict_cb g_predict_cb = nullptr;
+struct CallbackNet : NNet {
+    void predict(const float* boards, int B, int model_id, float* pi, float* v) override {
+        if (!g_predict_cb) throw std::runtime_error("no predict callback set");
+        g_predict_cb(boards, B, model_id, pi, v);
+    }
+};
 
 struct TreeBase {
     virtual ~TreeBase() = default;
@@ -45,9 +55,11 @@ struct NetBox {
     StubNet stub;
     HashNet hash;
     ReplayNet replay;
+    CallbackNet callback;
     NNet* get(int kind) {
         if (kind == NET_STUB) return &stub;
         if (kind == NET_HASH) return &hash;
+        if (kind == NET_CALLBACK) return &callback;
         return &replay;
     }
 };
@@ -106,6 +118,8 @@ TreeBase* make_tree(int has_root, uint64_t mine, uint64_t theirs, size_t reserve
 }  // namespace
 
 extern "C" {
+
+void azo_set_predict_callback(azo_predict_cb cb) { g_predict_cb = cb; }
 
 // ---- packed counter, src/node.rs:16-93 -----------------------------------
 uint64_t azo_ctr_init() { return 0x7FFFFFFF00000000ull; }

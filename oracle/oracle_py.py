@@ -13,7 +13,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "libaz_oracle.so")
 TEST_BIN = os.path.join(_DIR, "test_oracle")
 
-NET_STUB, NET_HASH, NET_REPLAY = 0, 1, 2
+NET_STUB, NET_HASH, NET_REPLAY, NET_CALLBACK = 0, 1, 2, 3
 GAME_BITS, GAME_ARRAY = 0, 1
 QUIRK_B1, QUIRK_B2, QUIRK_B4, QUIRK_B6 = 1, 2, 4, 8
 
@@ -170,6 +170,26 @@ def arena(num, sims, net_kind=NET_HASH, salt=0, seed=0, new_model_id=1, old_mode
     if rc != 0:
         raise RuntimeError("oracle arena failed")
     return wld, results[: 2 * (num // 2)]
+
+
+_cb_keepalive = None
+
+
+def set_predict_callback(fn):
+    """fn(boards [B,2,6,7] f32, model_id) -> (pi [B,7], v [B]); used by net_kind NET_CALLBACK (single thread)."""
+    global _cb_keepalive
+    CB = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+    def tramp(boards, B, model_id, pi, v):
+        b = np.ctypeslib.as_array(boards, shape=(B, 2, 6, 7))
+        p, vv = fn(b, model_id)
+        np.ctypeslib.as_array(pi, shape=(B, 7))[:] = p
+        np.ctypeslib.as_array(v, shape=(B,))[:] = vv
+
+    _cb_keepalive = CB(tramp)
+    lib().azo_set_predict_callback.restype = None
+    lib().azo_set_predict_callback.argtypes = [CB]
+    lib().azo_set_predict_callback(_cb_keepalive)
 
 
 def c4_play(mine, theirs, a):
