@@ -708,8 +708,79 @@ az_status az_selfplay_get_evals(az_engine* e, int32_t* rec_count, uint64_t* stat
     return AZ_OK;
 }
 
-az_status az_arena(az_engine* e, const az_arena_params*, uint64_t*, int8_t*) {
-    return fail(e, AZ_ERR_UNSUPPORTED, "az_arena: not built yet");
+az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], int8_t* results) {
+    if (!e || !p || !out_wld) return AZ_ERR_BAD_ARGUMENT;
+    if (p->num_games < 0 || p->num_sims <= 0 || p->max_depth < 0 || p->reserve < 8)
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: bad argument");
+    const int half = p->num_games / 2;               // num/2 games per seating, src/arena.rs:83
+    const int G = 2 * half;
+    out_wld[0] = out_wld[1] = out_wld[2] = 0;
+    if (G == 0) return AZ_OK;
+    if (G > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: at most 65536 games");
+    NetModel *net_new, *net_old;
+    az_status st = find_net(e, p->new_model_id, &net_new);
+    if (st) return st;
+    st = find_net(e, p->old_model_id, &net_old);
+    if (st) return st;
+    ScopedTimer timer{e};
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        hipStream_t s = e->stream;
+        // one tree PAIR per game (B8 repair): the reference shares one nmcts / one pmcts across all games
+        // (src/coach.rs:333-354) and their u16 root counters would wrap at 65536 visits.
+        const int calls = AZ_MAX_PLIES / 2 + 1;
+        const uint64_t R = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, calls));
+        TreeHost tn, to;
+        tn.create(G, R, hash_entries(p->num_sims, calls), 0);
+        to.create(G, R, hash_entries(p->num_sims, calls), 0);
+        DeviceMem mem;
+        ArenaDev ad{};
+        ad.G = G; ad.half = half;
+        ad.state = mem.alloc<ulonglong2>(G);
+        ad.player = mem.alloc<int8_t>(G);
+        ad.alive = mem.alloc<uint8_t>(G);
+        ad.results = mem.alloc<int8_t>(G);
+        ad.counters = mem.alloc<uint32_t>(2);
+        HIPCHK(hipMemset(ad.state, 0, (size_t)G * 16));
+        HIPCHK(hipMemset(ad.player, 1, G));
+        HIPCHK(hipMemset(ad.alive, 1, G));
+        HIPCHK(hipMemset(ad.results, 0, G));
+        uint32_t ctr[2] = {(uint32_t)G, 0u};
+        HIPCHK(hipMemcpy(ad.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
+        launch_reset_trees(tn.d, nullptr, s);
+        launch_reset_trees(to.d, nullptr, s);
+        SearchParams sp{(uint32_t)p->max_depth, (float)p->cpuct};
+        az_status result = AZ_OK;
+        for (int ply = 0; ply <= AZ_MAX_PLIES; ++ply) {
+            launch_arena_sync(tn.d, to.d, ad, s);
+            run_search(e, tn, ad.state, p->num_sims, sp, *net_new);
+            run_search(e, to, ad.state, p->num_sims, sp, *net_old);
+            launch_arena_move(tn.d, ad, p->seed, s);
+            launch_arena_move(to.d, ad, p->seed, s);
+            HIPCHK(hipMemcpyAsync(ctr, ad.counters, sizeof ctr, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            resolve_profile(e);
+            if (ctr[1]) { result = fail(e, AZ_ERR_INVALID_MOVE, "arena: action is not valid (src/arena.rs:31-35)"); break; }
+            if (ctr[0] == 0) break;
+        }
+        harvest_stats(e, tn);
+        harvest_stats(e, to);
+        if (result == AZ_OK) result = check_tree_errors(e, tn);
+        if (result == AZ_OK) result = check_tree_errors(e, to);
+        if (result) return result;
+        if (ctr[0] != 0) return fail(e, AZ_ERR_HIP, "az_arena: games did not finish");
+        std::vector<int8_t> res(G);
+        HIPCHK(hipMemcpy(res.data(), ad.results, G, hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; ++g) {
+            const int win_cond = g < half ? 1 : -1, lose_cond = -win_cond;      // src/arena.rs:80-81
+            if (res[g] == win_cond) out_wld[0]++;
+            else if (res[g] == lose_cond) out_wld[1]++;
+            else out_wld[2]++;
+        }
+        if (results) HIPCHK(hipMemcpy(results, res.data(), G, hipMemcpyDefault));
+        e->stats.games += (uint64_t)G;
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
 }
 
 }  // extern "C"

@@ -86,6 +86,16 @@ struct SelfplayMoveParams {
     int32_t refill;          // hand finished slots the next episode
 };
 
+// arena::play_games state (src/arena.rs:7-99): game g < half is seated (new, old), g >= half (old, new)
+struct ArenaDev {
+    int32_t G, half;
+    ulonglong2* state;     // [G] canonical board of the position to move
+    int8_t* player;        // [G] cur_player: +1 = first seat to move
+    uint8_t* alive;        // [G]
+    int8_t* results;       // [G] play_game's return: +1 first seat won, -1 second seat won, 0 draw (src/arena.rs:51)
+    uint32_t* counters;    // [0] games still running, [1] invalid-move flag (src/arena.rs:31-35)
+};
+
 // ---- launchers (all asynchronous on `s`) --------------------------------------
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s);
 void launch_root_prepare(const TreeDev& t, const ulonglong2* root_states, hipStream_t s);
@@ -96,6 +106,8 @@ void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t fi
                         uint16_t* counts, float* q, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s);
+void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDev& ad, hipStream_t s);
+void launch_arena_move(const TreeDev& t, const ArenaDev& ad, uint64_t seed, hipStream_t s);
 void launch_emit_samples(const GamesDev& gd, const int64_t* offsets, int symmetries, ulonglong2* out_states,
                          float* out_boards, float* out_pis, float* out_zs, hipStream_t s);
 

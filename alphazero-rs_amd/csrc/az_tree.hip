@@ -513,6 +513,51 @@ __global__ __launch_bounds__(256) void k_emit_samples(GamesDev gd, const int64_t
     }
 }
 
+// ---- arena::play_game, one ply for every running game (src/arena.rs:18-41) ------------------------
+// Which model moves: seat 0 moves when cur_player == +1; games g < half seat (new, old), the rest (old, new).
+__global__ void k_arena_sync(TreeDev tn, TreeDev to, ArenaDev ad) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ad.G) return;
+    const bool alive = ad.alive[g] != 0;
+    const int first_model = g < ad.half ? 0 : 1;                       // 0 = new, 1 = old
+    const int mover = ad.player[g] == 1 ? first_model : 1 - first_model;
+    tn.active[g] = alive && mover == 0;
+    to.active[g] = alive && mover == 1;
+}
+
+// The searching tree's owner plays argmax(get_action_prob(s, temp = 0)) (src/coach.rs:356-372).
+__global__ __launch_bounds__(64) void k_arena_move(TreeDev t, ArenaDev ad, uint64_t seed) {
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid >> 3, sub = tid & 7;
+    if (g >= t.G || !t.active[g]) return;
+    const ulonglong2 s = ad.state[g];
+    const int8_t player = ad.player[g];
+    RootPolicy rp = root_policy(t, g, sub, 0.0f, seed, (uint64_t)g, (uint64_t)__popcll(s.x | s.y));
+    // argmax with max_by (last max) over the one-hot pi = the index of the 1
+    const uint32_t hot = gballot(sub < ACTIONS && rp.pi == 1.0f) & 0x7Fu;
+    const int action = hot ? (31 - __clz((int)hot)) : 0;
+    const bool valid = (c4_valid_mask(s.x, s.y) >> action) & 1u;      // src/arena.rs:29-35
+    uint64_t m2, t2;
+    c4_play(s.x, s.y, action, &m2, &t2);
+    const uint32_t ec = c4_ecode(m2, t2);
+    if (sub == 0) {
+        if (!valid || !hot) {
+            atomicOr(&ad.counters[1], 1u);
+            ad.alive[g] = 0;
+            atomicSub(&ad.counters[0], 1u);
+        } else if (ec != E_NONE) {
+            // cur_player' = -player; result = cur_player' * round(get_game_ended(cur_player')) (src/arena.rs:51):
+            // ended = -1 -> the player who just moved won; DRAW_EPS rounds to 0
+            ad.results[g] = (ec == E_PLUS1) ? player : (ec == E_MINUS1 ? (int8_t)-player : (int8_t)0);
+            ad.alive[g] = 0;
+            atomicSub(&ad.counters[0], 1u);
+        } else {
+            ad.state[g] = make_ulonglong2(m2, t2);
+            ad.player[g] = (int8_t)-player;
+        }
+    }
+}
+
 __global__ void k_sync_active(TreeDev t, GamesDev gd) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < t.G) t.active[g] = gd.gid[g] >= 0 ? 1 : 0;
@@ -545,6 +590,12 @@ void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMovePara
 }
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s) {
     hipLaunchKernelGGL(k_sync_active, dim3((t.G + 255) / 256), dim3(256), 0, s, t, gd);
+}
+void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDev& ad, hipStream_t s) {
+    hipLaunchKernelGGL(k_arena_sync, dim3((ad.G + 255) / 256), dim3(256), 0, s, t_new, t_old, ad);
+}
+void launch_arena_move(const TreeDev& t, const ArenaDev& ad, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_arena_move, dim3(group_blocks(t.G)), dim3(64), 0, s, t, ad, seed);
 }
 void launch_emit_samples(const GamesDev& gd, const int64_t* offsets, int symmetries, ulonglong2* out_states,
                          float* out_boards, float* out_pis, float* out_zs, hipStream_t s) {

@@ -228,3 +228,33 @@ def test_full_size_properties(engine):
     # mirror symmetry: odd rows are the mirrored twin of even rows
     assert np.array_equal(pis[0::2], pis[1::2, ::-1])
     assert np.array_equal(zs[0::2], zs[1::2])
+
+
+# ---- arena::play_games (C16) -----------------------------------------------------------------------
+@pytest.mark.parametrize("num,sims", [(2, 25), (12, 50), (64, 100)])
+def test_arena_matches_play_games(engine, oracle, engine_mod, num, sims):
+    """az_arena == play_games with per-game tree pairs: every game's result and the W/L/D tally for the new
+    model, both seatings, temp 0 with the RNG tie-break, S10 fresh roots for the second player's tree."""
+    engine.net_set_kind(31, engine_mod.NET_HASH, 555 - 31 * MODEL_SALT)      # "new": oracle model id 1, salt 555
+    engine.net_set_kind(30, engine_mod.NET_HASH, 555 + MODEL_SALT - 30 * MODEL_SALT)
+    # oracle: HashNet salt = 555 + model_id * MODEL_SALT with new_model_id = 0 -> 555, old_model_id = 1 -> 555 + MODEL_SALT
+    wld, results = engine.arena(num, sims, new_model_id=31, old_model_id=30, seed=13)
+    owld, oresults = oracle.arena(num, sims, net_kind=oracle.NET_HASH, salt=555, seed=13, new_model_id=0, old_model_id=1, threads=8)
+    assert np.array_equal(results, oresults)
+    assert wld.tolist() == owld.tolist() and int(wld.sum()) == 2 * (num // 2)
+
+
+def test_arena_golden(engine, engine_mod):
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arena.json")))
+    engine.net_set_kind(33, engine_mod.NET_HASH, g["salt"] + g["new_model_id"] * MODEL_SALT - 33 * MODEL_SALT)
+    engine.net_set_kind(32, engine_mod.NET_HASH, g["salt"] + g["old_model_id"] * MODEL_SALT - 32 * MODEL_SALT)
+    wld, results = engine.arena(g["num"], g["sims"], new_model_id=33, old_model_id=32, seed=g["seed"])
+    assert wld.tolist() == g["wld"] and results.tolist() == g["results"]
+
+
+def test_arena_odd_and_empty(engine, engine_mod):
+    wld, results = engine.arena(1, 10, new_model_id=0, old_model_id=0)       # num/2 == 0 games per seating
+    assert wld.tolist() == [0, 0, 0] and len(results) == 0
+    wld, results = engine.arena(5, 10, new_model_id=0, old_model_id=0)       # 2 per seating, the odd one is dropped
+    assert int(wld.sum()) == 4 and len(results) == 4
