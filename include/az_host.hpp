@@ -1,0 +1,241 @@
+// az_host.hpp -- C++ host-side mirror of the reference's plugin interface above the C ABI.
+//
+// The reference is Rust; no Rust toolchain exists in this build environment, so the host side of the
+// drop-in is written in C++ with the reference's names, argument meaning and error behaviour (a Rust
+// `panic!` becomes a thrown az_host::Panic):
+//   Game trait            src/game.rs:10-28           -> ConnectFourGame (connect_four_game.rs:81-238)
+//   NNet trait            src/nnet.rs:35-45           -> NNet, Mi355xNNet (az_net_* entry points)
+//   AsyncMcts<G>          src/async_mcts.rs:14-115    -> AsyncMcts (az_tree_* entry points, one tree)
+//   arena::play_game(s)   src/arena.rs:7-99           -> play_game, play_games (closures, Heap's order)
+//   Coach::execute_episode src/coach.rs:104-157       -> execute_episode
+// Header-only; links against libaz_engine.so.  Nothing here touches oracle/.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "az_engine.h"
+
+namespace az_host {
+
+struct Panic : std::runtime_error { using std::runtime_error::runtime_error; };
+
+using Policy = std::vector<float>;          // nnet.rs:17
+using BoardFeatures = std::vector<float>;   // nnet.rs:9, [2,6,7] row-major
+struct TrainingSample { BoardFeatures board; Policy pi; float v; };   // nnet.rs:22-27
+
+// ---- Game: Connect Four on absolute bitboards (player +1 / -1) ------------------------------------------
+class ConnectFourGame {
+  public:
+    uint64_t plus = 0, minus = 0;           // stones of player +1 / -1; bit(col,row) = col*7+row, row 0 = bottom
+    static constexpr int H = 6, W = 7;      // connect_four_game.rs:13-14
+    static constexpr float DRAW_EPS = 1e-4f;
+
+    static ConnectFourGame get_init_board() { return {}; }
+    static std::vector<size_t> get_feature_shape() { return {2, 6, 7}; }
+    std::pair<ConnectFourGame, int8_t> get_next_state(int8_t player, uint8_t action) const {
+        const uint64_t mask = plus | minus;
+        const uint64_t nb = (mask + (1ull << (action * 7))) & (0x3Full << (action * 7));
+        if (!nb) throw Panic("C4 move into a full column");           // debug_assert, connect_four_game.rs:98
+        ConnectFourGame n = *this;
+        (player == 1 ? n.plus : n.minus) |= nb;
+        return {n, (int8_t)-player};
+    }
+    std::array<uint8_t, 7> get_valid_moves(int8_t) const {
+        std::array<uint8_t, 7> v{};
+        for (int c = 0; c < W; ++c) v[c] = ((plus | minus) >> (c * 7 + 5)) & 1 ? 0 : 1;
+        return v;
+    }
+    float get_game_ended(int8_t player) const {
+        if (four(plus)) return player == 1 ? 1.f : -1.f;
+        if (four(minus)) return player == -1 ? 1.f : -1.f;
+        for (int c = 0; c < W; ++c) if (!(((plus | minus) >> (c * 7 + 5)) & 1)) return 0.f;
+        return DRAW_EPS;
+    }
+    ConnectFourGame get_canonical_form(int8_t player) const {         // side to move becomes +1 (B5)
+        ConnectFourGame n;
+        n.plus = player == 1 ? plus : minus;
+        n.minus = player == 1 ? minus : plus;
+        return n;
+    }
+    std::vector<std::pair<ConnectFourGame, Policy>> get_symmetries(const Policy& pi) const {
+        ConnectFourGame f;
+        for (int c = 0; c < W; ++c) {
+            f.plus |= ((plus >> (c * 7)) & 0x7F) << ((6 - c) * 7);
+            f.minus |= ((minus >> (c * 7)) & 0x7F) << ((6 - c) * 7);
+        }
+        return {{*this, pi}, {f, Policy(pi.rbegin(), pi.rend())}};
+    }
+    float eval_heuristic() const { return 0.f; }
+    BoardFeatures to_features() const {                                // [2,6,7], row 0 = top (S8)
+        BoardFeatures f(84, 0.f);
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c) {
+                const uint64_t bit = 1ull << (c * 7 + (5 - r));
+                if (plus & bit) f[r * 7 + c] = 1.f;
+                if (minus & bit) f[42 + r * 7 + c] = 1.f;
+            }
+        return f;
+    }
+    bool operator==(const ConnectFourGame& o) const { return plus == o.plus && minus == o.minus; }
+
+  private:
+    static bool four(uint64_t b) {
+        for (int d : {1, 7, 6, 8}) { uint64_t m = b & (b >> d); if (m & (m >> (2 * d))) return true; }
+        return false;
+    }
+};
+
+// ---- engine handle + NNet ----------------------------------------------------------------------------------
+class Engine {
+  public:
+    explicit Engine(int device = 0, int max_batch = 8192, int channels = 512) {
+        az_config cfg{device, max_batch, channels, 0};
+        if (az_create(&cfg, &e_) != AZ_OK) throw Panic("az_create failed");
+    }
+    ~Engine() { az_destroy(e_); }
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+    az_engine* raw() const { return e_; }
+    void check(int rc) const { if (rc != AZ_OK) throw Panic(std::string(az_last_error(e_))); }
+
+  private:
+    az_engine* e_ = nullptr;
+};
+
+class NNet {                                                            // src/nnet.rs:35-45
+  public:
+    virtual ~NNet() = default;
+    virtual void train(const float* boards, const float* pis, const float* vs, int64_t n, size_t prev_id, size_t id) = 0;
+    virtual void predict(const float* boards, int batch, size_t model_id, float* pi, float* v) const = 0;
+};
+class Mi355xNNet : public NNet {
+  public:
+    explicit Mi355xNNet(Engine& e) : e_(e) {}
+    void train(const float* b, const float* p, const float* v, int64_t n, size_t prev_id, size_t id) override {
+        e_.check(az_net_train(e_.raw(), (int)prev_id, (int)id, b, p, v, n));
+    }
+    void predict(const float* boards, int batch, size_t model_id, float* pi, float* v) const override {
+        e_.check(az_net_predict(e_.raw(), (int)model_id, boards, batch, pi, v));
+    }
+
+  private:
+    Engine& e_;
+};
+
+// ---- AsyncMcts: one tree behind az_tree_* ----------------------------------------------------------------------
+class AsyncMcts {
+  public:
+    // AsyncMcts::default(reserve_space, num_sims, num_threads, max_depth, model_id, cpuct, ..), src/async_mcts.rs:27-48
+    static AsyncMcts default_(Engine& e, size_t reserve_space, size_t num_sims, size_t num_threads, size_t max_depth,
+                              size_t model_id, int32_t cpuct) {
+        if (num_threads != 1 || num_sims % num_threads != 0)
+            throw Panic("num_sims % num_threads == 0 with num_threads == 1");   // src/async_mcts.rs:192
+        return AsyncMcts(e, reserve_space, num_sims, max_depth, model_id, cpuct);
+    }
+    AsyncMcts(AsyncMcts&& o) noexcept : e_(o.e_), t_(o.t_) { o.t_ = nullptr; }
+    ~AsyncMcts() { if (t_) az_tree_destroy(t_); }
+    // get_action_prob(&self, s, temp, episode_id, rng): `s` canonical; rng = (seed, episode_id) stream (B7)
+    Policy get_action_prob(const ConnectFourGame& s, float temp, size_t episode_id, uint64_t seed,
+                           std::array<uint16_t, 7>* counts = nullptr, std::array<float, 7>* q = nullptr) const {
+        const uint64_t st[2] = {s.plus, s.minus};
+        Policy pi(7);
+        e_.check(az_tree_get_action_prob(t_, st, temp, seed, (uint64_t)episode_id, pi.data(),
+                                         counts ? counts->data() : nullptr, q ? q->data() : nullptr));
+        return pi;
+    }
+
+  private:
+    AsyncMcts(Engine& e, size_t reserve, size_t sims, size_t max_depth, size_t model_id, int32_t cpuct) : e_(e) {
+        e_.check(az_tree_create(e.raw(), 1, reserve, (int)sims, (int)max_depth, (int)model_id, cpuct, &t_));
+    }
+    Engine& e_;
+    az_tree* t_ = nullptr;
+};
+
+// ---- arena (src/arena.rs:7-99) ------------------------------------------------------------------------------------
+using PlayerAction = std::function<uint8_t(const ConnectFourGame&)>;
+
+inline int8_t play_game(const std::array<const PlayerAction*, 2>& player_actions, const ConnectFourGame* board0) {
+    int8_t cur_player = 1;
+    ConnectFourGame board = board0 ? *board0 : ConnectFourGame::get_init_board();
+    while (board.get_game_ended(cur_player) == 0.f) {                          // :18
+        const ConnectFourGame canonical = board.get_canonical_form(cur_player); // :25
+        const uint8_t action = (*player_actions[cur_player == 1 ? 0 : 1])(canonical);
+        if (canonical.get_valid_moves(1)[action] == 0) throw Panic("Action is not valid!");   // :31-35
+        auto nx = board.get_next_state(cur_player, action);
+        board = nx.first;
+        cur_player = nx.second;
+    }
+    return (int8_t)(cur_player * (int8_t)std::lround(board.get_game_ended(cur_player)));      // :51
+}
+
+struct GameResultCounter { size_t win = 0, loss = 0, draw = 0; };             // Counter<GameResult>, :54-59
+
+inline GameResultCounter play_games(size_t num, const std::array<const PlayerAction*, 2>& player_actions,
+                                    const ConnectFourGame* board) {
+    GameResultCounter all;
+    for (int ordering = 0; ordering < 2; ++ordering) {                         // Heap's permutations of 2: (0,1), (1,0)
+        const std::array<const PlayerAction*, 2> seated = {player_actions[ordering], player_actions[1 - ordering]};
+        const int win_cond = ordering == 0 ? 1 : -1, lose_cond = -win_cond;    // :80-81
+        for (size_t i = 0; i < num / 2; ++i) {                                 // :83
+            const int8_t r = play_game(seated, board);
+            if (r == win_cond) ++all.win; else if (r == lose_cond) ++all.loss; else ++all.draw;
+        }
+    }
+    return all;
+}
+
+// ---- Coach::execute_episode (src/coach.rs:104-157) with the engine's RNG stream --------------------------------------
+inline uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint8_t choose_weighted(uint64_t seed, uint64_t episode_id, uint64_t ply, const Policy& pi) {
+    const uint64_t r = mix64(mix64(mix64(mix64(seed) ^ episode_id) ^ ply) ^ 2ull);
+    float total = 0.f;
+    for (float p : pi) total = total + p;
+    const float target = (float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f) * total;
+    float acc = 0.f;
+    int last = 0;
+    for (int a = 0; a < (int)pi.size(); ++a)
+        if (pi[a] > 0.f) { acc = acc + pi[a]; last = a; if (target < acc) return (uint8_t)a; }
+    return (uint8_t)last;
+}
+
+inline std::vector<TrainingSample> execute_episode(const AsyncMcts& mcts, size_t temp_threshold, size_t episode_id,
+                                                   uint64_t seed, std::vector<uint8_t>* moves = nullptr) {
+    struct Ex { BoardFeatures f; int8_t player; Policy pi; };
+    std::vector<Ex> train_examples;
+    ConnectFourGame board = ConnectFourGame::get_init_board();
+    int8_t cur_player = 1;
+    size_t episode_step = 0;
+    for (;;) {
+        ++episode_step;
+        const ConnectFourGame canonical = board.get_canonical_form(cur_player);
+        const float temp = episode_step < temp_threshold ? 1.f : 0.f;             // :122-126
+        const Policy pi = mcts.get_action_prob(canonical, temp, episode_id, seed);   // :128
+        for (auto& bp : canonical.get_symmetries(pi)) train_examples.push_back({bp.first.to_features(), cur_player, bp.second});
+        const uint8_t action = choose_weighted(seed, episode_id, episode_step - 1, pi);   // :137-138
+        if (moves) moves->push_back(action);
+        auto nx = board.get_next_state(cur_player, action);
+        board = nx.first;
+        cur_player = nx.second;
+        const float r = board.get_game_ended(cur_player);                            // :144
+        if (r != 0.f) {
+            std::vector<TrainingSample> out;
+            for (auto& ex : train_examples) out.push_back({ex.f, ex.pi, r * (ex.player == cur_player ? 1.f : -1.f)});   // B4
+            return out;
+        }
+    }
+}
+
+}  // namespace az_host
