@@ -301,6 +301,15 @@ void az_destroy(az_engine* e) {
 
 const char* az_last_error(const az_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
+az_status az_set_option(az_engine* e, const char* key, int64_t value) {
+    if (!e || !key) return AZ_ERR_BAD_ARGUMENT;
+    if (std::strcmp(key, "gemm_variant") == 0 && (value == 0 || value == 1)) {
+        convnet_set_variant((int)value);
+        return AZ_OK;
+    }
+    return fail(e, AZ_ERR_BAD_ARGUMENT, std::string("unknown option or value: ") + key);
+}
+
 az_status az_get_stats(az_engine* e, az_stats* out) {
     if (!e || !out) return AZ_ERR_BAD_ARGUMENT;
     *out = e->stats;

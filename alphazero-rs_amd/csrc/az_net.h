@@ -30,6 +30,8 @@ void convnet_init_random(ConvNet* n, uint64_t seed);
 void convnet_resolve_profile(ConvNet* n, NetProfile* prof);
 // forward for rows [0, *eb.n); n_rows_hint = host-side upper bound used to size the grids.
 // If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
+// kernel-variant switch for A/B measurements (0 = 128x128 tiles everywhere, 1 = default)
+void convnet_set_variant(int v);
 void convnet_forward(ConvNet* n, const EvalBatch& eb, int n_rows_hint, hipStream_t s, NetProfile* prof);
 
 }  // namespace az

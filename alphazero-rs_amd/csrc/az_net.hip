@@ -226,6 +226,110 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
     }
 }
 
+// ---- 256x256 tile variant for the big layers (conv2, conv3): LDS-DMA staging ------------------------------
+// 8 waves (2 x 4), each wave a 128(m) x 64(n) sub-tile = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16.
+// Both operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write): one wave-instruction
+// writes 1 KiB = 8 tile rows x 128 B linearly, so the XOR swizzle (chunk c of row r at slot c ^ (r&7)) is applied
+// to the per-lane SOURCE address and again on the fragment reads.  Two 64 KiB LDS buffers; the next K-step's DMA is
+// issued before this K-step's MFMAs and retired by vmcnt(0) + barrier at the end of the step.
+constexpr int HBM_ = 256, HBN_ = 256;
+
+template <int LAYER>
+__global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
+    const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int NT = d.N / HBN_;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // DMA map: instruction q of wave w fills tile rows (q*8+w)*8 .. +7; lane -> row (lane>>3), slot (lane&7)
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    auto row_off = [&](int q) -> uint32_t {
+        int m = m0 + (q * 8 + wave) * 8 + lrow;
+        m = m < M ? m : M - 1;
+        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
+        const int y = r / d.out_w, x = r - y * d.out_w;
+        return (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
+    };
+    const uint32_t a_off0 = row_off(0), a_off1 = row_off(1), a_off2 = row_off(2), a_off3 = row_off(3);
+    const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
+    const uint32_t b_step = 64u * (uint32_t)d.K;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define AZ_DMA(kt_, buf_)                                                                               \
+    {                                                                                                   \
+        const int kk = (kt_) * GBK;                                                                     \
+        const int tap = kk / d.cin, c0 = kk - tap * d.cin;                                              \
+        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                          \
+        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                             \
+        unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
+        unsigned char* lb = la + 32768;                                                                 \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off0 + toff), (lds_ptr)(la), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off1 + toff), (lds_ptr)(la + 8192), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off2 + toff), (lds_ptr)(la + 16384), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off3 + toff), (lds_ptr)(la + 24576), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + kk), (lds_ptr)(lb), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + kk), (lds_ptr)(lb + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 2 * b_step + kk), (lds_ptr)(lb + 16384), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 3 * b_step + kk), (lds_ptr)(lb + 24576), 16, 0, 0); \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = d.K / GBK;
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    AZ_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
+        const unsigned char* sA = smem + (kt & 1) * 65536;
+        const unsigned char* sB = sA + 32768;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ fsw) << 4;
+            bf16x8 fa[8], fb[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * 128 + mt * 16 + frow) * 128 + coff);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef AZ_DMA
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wr * 128 + mt * 16 + frow;
+            if (m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
 // ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
 // one wave per sample; lane holds 8 of the 512 inputs.
 __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_t* __restrict__ x /*[n][512] bf16*/,
@@ -455,8 +559,17 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
     convnet_set_params(net, p.data(), L.total);
 }
 
+int g_gemm_variant = 1;   // 0: 128x128 everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3 (tools/net_bench.py A/Bs them)
+
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
+    const bool big = g_gemm_variant == 1 && (LAYER == 1 || LAYER == 2) && d.N % HBN_ == 0;
+    if (big) {
+        const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
+        const int mt8 = (mt + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_gemm256<LAYER>, dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        return;
+    }
     const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
     const int mt8 = (mt + 7) / 8 * 8;
     const int grid = mt8 * (d.N / GBN);
@@ -491,6 +604,8 @@ void convnet_resolve_profile(ConvNet* n, NetProfile* prof) {
     n->open.clear();
     n->pinned_next = 0;
 }
+
+void convnet_set_variant(int v) { g_gemm_variant = v; }
 
 void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t s, NetProfile* prof) {
     const int C = n->C;

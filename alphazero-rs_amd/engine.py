@@ -65,7 +65,7 @@ class az_arena_params(C.Structure):
 
 # every symbol include/az_engine.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "az_create", "az_destroy", "az_last_error", "az_get_stats", "az_reset_stats", "az_net_set_kind",
+    "az_create", "az_destroy", "az_last_error", "az_set_option", "az_get_stats", "az_reset_stats", "az_net_set_kind",
     "az_net_init_random", "az_net_load", "az_net_save", "az_net_param_count", "az_net_set_params",
     "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_tree_create",
     "az_tree_destroy", "az_tree_get_action_prob", "az_tree_record_evals", "az_tree_get_evals",
@@ -84,6 +84,7 @@ def load_library(path=LIB_PATH):
         "az_create": (i32, [C.POINTER(az_config), C.POINTER(vp)]),
         "az_destroy": (None, [vp]),
         "az_last_error": (C.c_char_p, [vp]),
+        "az_set_option": (i32, [vp, C.c_char_p, i64]),
         "az_get_stats": (i32, [vp, C.POINTER(az_stats)]),
         "az_reset_stats": (i32, [vp]),
         "az_net_set_kind": (i32, [vp, i32, i32, u64]),
@@ -206,6 +207,9 @@ class Engine:
         p = np.ascontiguousarray(pis, dtype=np.float32)
         v = np.ascontiguousarray(vs, dtype=np.float32)
         self._check(_lib.az_net_train(self._h, prev_id, model_id, _ptr(b), _ptr(p), _ptr(v), v.size))
+
+    def set_option(self, key, value):
+        self._check(_lib.az_set_option(self._h, key.encode(), int(value)))
 
     # ---- stats ----
     def stats(self):

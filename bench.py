@@ -5,7 +5,7 @@ Metric (BASELINE.json): self-play games/sec (+ MCTS node-expansions/sec) on conn
 8192 concurrent games per GPU, bf16 policy+value net (C=512), random-init weights, synthetic = self-generated
 positions from the empty board.
 
-A "step" = one episode batch through the hot path: `--episodes` self-play games per GPU played to completion on
+A "step" = one episode batch through the hot path: `--episodes` (default 4 x --games) self-play games per GPU played to completion on
 `--games` concurrent slots (finished slots are refilled), then the RCCL gather of the (s, pi, z) tuples to rank 0
 when N > 1.  Weak scaling: per-GPU work is fixed; `value` = all ranks' games / max-over-ranks time.
 
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=8192, help="concurrent game slots per GPU")
-    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU per step (0 = 2 x --games)")
+    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU per step (0 = 4 x --games)")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--net", default="conv", choices=["conv", "stub"])
     ap.add_argument("--channels", type=int, default=512)
@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
-    episodes = args.episodes or 2 * args.games
+    episodes = args.episodes or 4 * args.games
 
     import torch
     import torch.distributed as dist
@@ -200,7 +200,7 @@ def main():
         roof = None
         if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:
             ach = st["net_conv2_flops"] / (st["net_conv2_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "k_gemm_mfma<1> (conv2: 3x3 same, 512->512, implicit GEMM)",
+            roof = {"bound": "mfma", "kernel": "k_gemm256<1> (conv2: 3x3 same, 512->512, implicit GEMM on MFMA)",
                     "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                     "traffic": None, "launches": st["net_launches"],
                     "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"],
