@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
     // [buf][A tile 128 rows x 128 B | W tile 128 rows x 128 B]; 16-byte chunk c of row r lives at slot c ^ (r & 7)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][(GBM + GBN) * 128];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int ntaps = d.K / d.cin;
     const int NT = d.N / GBN;
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the NT column tiles of one
     // row tile are placed on the same XCD back to back and re-read the activation tile from that XCD's L2.
@@ -155,8 +156,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
     // global -> registers for K-step kt (no lambdas / arrays: keeps everything in VGPRs, no scratch)
 #define AZ_GLOAD(kt_)                                                                           \
     {                                                                                           \
-        const int kk = (kt_) * GBK;                                                             \
-        const int tap = kk / d.cin, c0 = kk - tap * d.cin;                                      \
+        /* K order: channel block outer, filter tap inner -> the 9 taps of one 64-channel block re-read   \
+           the same 128-B segments back to back (L2-resident) instead of sweeping the whole image per tap */ \
+        const int cb_ = (kt_) / ntaps, tap = (kt_) - cb_ * ntaps;                               \
+        const int c0 = cb_ * GBK, kk = tap * d.cin + c0;                                        \
         const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                  \
         const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                     \
         ra0 = *(const uint4*)(d.A + a_off0 + toff); ra1 = *(const uint4*)(d.A + a_off1 + toff); \
@@ -234,10 +237,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
 // issued before this K-step's MFMAs and retired by vmcnt(0) + barrier at the end of the step.
 constexpr int HBM_ = 256, HBN_ = 256;
 
-template <int LAYER>
+template <int LAYER, int PIPE>
 __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int ntaps = d.K / d.cin;
     const int NT = d.N / HBN_;
     const int id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
 #define AZ_DMA(kt_, buf_)                                                                               \
     {                                                                                                   \
-        const int kk = (kt_) * GBK;                                                                     \
-        const int tap = kk / d.cin, c0 = kk - tap * d.cin;                                              \
+        const int cb_ = (kt_) / ntaps, tap = (kt_) - cb_ * ntaps;                                       \
+        const int c0 = cb_ * GBK, kk = tap * d.cin + c0;                                                \
         const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                          \
         const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                             \
         unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
@@ -289,27 +293,66 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     AZ_DMA(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // LDS byte offsets of this lane's fragment rows (row-major 128-B rows, XOR-swizzled 16-B slots)
+    const int a_row0 = (wr * 128 + frow) * 128, b_row0 = 32768 + (wc * 64 + frow) * 128;
+    const int coff0 = ((0 + fq) ^ fsw) << 4, coff1 = ((4 + fq) ^ fsw) << 4;
+#define AZ_LDA(dst_, base_, mt0_, coff_)                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+        dst_[i_] = *(const bf16x8*)((base_) + a_row0 + ((mt0_) + i_) * 2048 + (coff_));
+#define AZ_LDB(dst_, base_, coff_)                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+        dst_[i_] = *(const bf16x8*)((base_) + b_row0 + i_ * 2048 + (coff_));
+#define AZ_MMA(mt0_, fb_, fa_)                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                     \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
         const unsigned char* sA = smem + (kt & 1) * 65536;
-        const unsigned char* sB = sA + 32768;
+        if constexpr (PIPE == 0) {
+            const unsigned char* sB = sA + 32768;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fq) ^ fsw) << 4;
-            bf16x8 fa[8], fb[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((ks * 4 + fq) ^ fsw) << 4;
+                bf16x8 fa[8], fb[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
+                for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * 128 + mt * 16 + frow) * 128 + coff);
+                for (int mt = 0; mt < 8; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * 128 + mt * 16 + frow) * 128 + coff);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+                for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            }
+        } else {
+            // 4 phases of 16 MFMAs; the fragments of phase p+1 are requested before the MFMAs of phase p issue,
+            // so an LDS round trip is exposed once per K-step (after the barrier) instead of eight times.
+            bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+            AZ_LDB(fbX, sA, coff0);
+            AZ_LDA(faX, sA, 0, coff0);
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_LDA(faY, sA, 4, coff0);
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_MMA(0, fbX, faX);
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_LDB(fbY, sA, coff1);
+            AZ_LDA(faX, sA, 0, coff1);
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_MMA(4, fbX, faY);
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_LDA(faY, sA, 4, coff1);
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_MMA(0, fbY, faX);
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_MMA(4, fbY, faY);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#undef AZ_LDA
+#undef AZ_LDB
+#undef AZ_MMA
 #undef AZ_DMA
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -559,15 +602,16 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
     convnet_set_params(net, p.data(), L.total);
 }
 
-int g_gemm_variant = 1;   // 0: 128x128 everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3 (tools/net_bench.py A/Bs them)
+int g_gemm_variant = 2;   // 0: 128x128 everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3; 2: + phased fragment prefetch
 
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
-    const bool big = g_gemm_variant == 1 && (LAYER == 1 || LAYER == 2) && d.N % HBN_ == 0;
+    const bool big = g_gemm_variant >= 1 && (LAYER == 1 || LAYER == 2) && d.N % HBN_ == 0;
     if (big) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
-        hipLaunchKernelGGL(k_gemm256<LAYER>, dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        if (g_gemm_variant == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
     const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;

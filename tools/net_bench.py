@@ -11,15 +11,17 @@ e = azeng.Engine(device=0, max_batch=B, profile=True)
 e.net_init_random(0, 1)
 uniq = random_states(orc, 512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, B)]
+VARS = (0, 1, 2)
 outs = {}
-for v in (0, 1):
+for v in VARS:
     e.set_option("gemm_variant", v)
     outs[v] = e.predict_states(states, 0)
-print("variants agree: max|dpi|", np.abs(outs[0][0] - outs[1][0]).max(), "max|dv|", np.abs(outs[0][1] - outs[1][1]).max(),
-      "bitwise", np.array_equal(outs[0][0], outs[1][0]))
-res = {0: [], 1: []}
+for v in VARS[1:]:
+    print("variant", v, "vs 0: max|dpi|", np.abs(outs[0][0] - outs[v][0]).max(), "max|dv|", np.abs(outs[0][1] - outs[v][1]).max(),
+          "bitwise", np.array_equal(outs[0][0], outs[v][0]) and np.array_equal(outs[0][1], outs[v][1]))
+res = {v: [] for v in VARS}
 for r in range(rounds):
-    for v in (0, 1):
+    for v in VARS:
         e.set_option("gemm_variant", v)
         e.reset_stats()
         for _ in range(4):
@@ -27,7 +29,7 @@ for r in range(rounds):
         st = e.stats()
         res[v].append((st['net_conv2_flops'] / st['net_conv2_ms'] / 1e9, st['net_total_flops'] / st['net_total_ms'] / 1e9,
                        st['net_conv2_ms'] / st['net_launches'], st['net_total_ms'] / st['net_launches']))
-for v in (0, 1):
+for v in VARS:
     a = np.array(res[v])
     print(f"variant {v}: conv2 TFLOP/s median {np.median(a[:,0]):.1f} max {a[:,0].max():.1f} | forward TFLOP/s median {np.median(a[:,1]):.1f} "
           f"| conv2 ms {np.median(a[:,2]):.3f} forward ms {np.median(a[:,3]):.3f}")
