@@ -237,15 +237,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
 // issued before this K-step's MFMAs and retired by vmcnt(0) + barrier at the end of the step.
 constexpr int HBM_ = 256, HBN_ = 256;
 
-template <int LAYER, int PIPE>
+template <int LAYER, int PIPE, int ABLATE = 0, int XCDMAP = 0>   // ABLATE (timing experiments only): 1 = no DMA in the loop, 2 = no MFMA
 __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
     const int ntaps = d.K / d.cin;
     const int NT = d.N / HBN_;
+    // XCD-aware order (blocks b and b+8 share an XCD): every XCD sweeps its row tiles for column tile 0, then for
+    // column tile 1, ...: the weight slice all of an XCD's CUs stream at a time is N/NT x K = 2.4 MB (fits the 4 MB L2);
+    // the activation tile is re-read once per column tile instead (from the Infinity Cache / HBM, 0.6 GB per pass).
     const int id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int per_xcd = (int)(gridDim.x >> 3) / NT;
+    const int ntile = XCDMAP ? j / per_xcd : j % NT;
+    const int mtile = (XCDMAP ? j % per_xcd : j / NT) * 8 + xcd;
     const int m0 = mtile * HBM_, n0 = ntile * HBN_;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -304,10 +309,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
         dst_[i_] = *(const bf16x8*)((base_) + b_row0 + i_ * 2048 + (coff_));
 #define AZ_MMA(mt0_, fb_, fa_)                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                     \
-            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
+            if constexpr (ABLATE == 2) { asm volatile("" :: "v"(fb_[j_]), "v"(fa_[i_])); }   \
+            else acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0); \
+        }
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
+        if (ABLATE != 1 && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
         const unsigned char* sA = smem + (kt & 1) * 65536;
         if constexpr (PIPE == 0) {
             const unsigned char* sB = sA + 32768;
@@ -354,6 +361,137 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
 #undef AZ_LDB
 #undef AZ_MMA
 #undef AZ_DMA
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wr * 128 + mt * 16 + frow;
+            if (m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
+// ---- 256x256 tile, 4-stage LDS ring of 32-deep K stages ("ring" variant) ------------------------------------
+// Same tile and wave layout as k_gemm256, but the K loop advances in stages of 32 (one MFMA K-step) through a ring
+// of four 32 KiB LDS slots filled by LDS-DMA three stages ahead.  Per stage ONE raw s_barrier: the wave first
+// waits (counted vmcnt, never 0 in steady state) until ITS pieces of stage s+1 have landed, so after the barrier
+// stage s+1 is complete for everybody and the slot of stage s-1 is free; the fragments of stage s+1 are then
+// requested while the MFMAs of stage s issue, so no LDS round trip and no DMA wait sits between two MFMA
+// clusters.  Rows are 64 B (4 slots of 16 B); slot = chunk ^ 3*((row>>2)&1) keeps ds_read_b128 conflict-free.
+template <int LAYER>
+__global__ __launch_bounds__(512, 2) void k_gemm256r(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32768];
+    const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int ntaps = d.K / d.cin;
+    const int NT = d.N / HBN_;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // DMA map: instruction q of wave w fills rows (q*8+w)*16 .. +15 of a stage; lane -> row (lane>>2), slot (lane&3)
+    const int lrow = lane >> 2;
+    const int chunk = (lane & 3) ^ (3 * ((lane >> 4) & 1));
+    auto row_off = [&](int q) -> uint32_t {
+        int m = m0 + (q * 8 + wave) * 16 + lrow;
+        m = m < M ? m : M - 1;
+        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
+        const int y = r / d.out_w, x = r - y * d.out_w;
+        return (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
+    };
+    const uint32_t a_off0 = row_off(0), a_off1 = row_off(1);
+    const uint32_t b_off0 = (uint32_t)((n0 + wave * 16 + lrow) * d.K + chunk * 8);
+    const uint32_t b_step = 128u * (uint32_t)d.K;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const int ns = d.K / 32;
+#define AZ_RDMA(s_)                                                                                        \
+    {                                                                                                      \
+        const int t2_ = (s_) >> 1, cb_ = t2_ / ntaps, tap = t2_ - cb_ * ntaps;                             \
+        const int c0 = cb_ * 64 + ((s_) & 1) * 32, kk = tap * d.cin + c0;                                  \
+        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                             \
+        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                                \
+        unsigned char* la = smem + ((s_) & 3) * 32768 + wave * 1024;                                       \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off0 + toff), (lds_ptr)(la), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off1 + toff), (lds_ptr)(la + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + kk), (lds_ptr)(la + 16384), 16, 0, 0);      \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + kk), (lds_ptr)(la + 24576), 16, 0, 0); \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fslot = (fq ^ (3 * ((frow >> 2) & 1))) << 4;
+    const int a_row0 = (wr * 128 + frow) * 64 + fslot, b_row0 = 16384 + (wc * 64 + frow) * 64 + fslot;
+#define AZ_RLDA(dst_, s_, mt0_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
+        dst_[i_] = *(const bf16x8*)(smem + ((s_) & 3) * 32768 + a_row0 + ((mt0_) + i_) * 1024);
+#define AZ_RLDB(dst_, s_)                                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
+        dst_[i_] = *(const bf16x8*)(smem + ((s_) & 3) * 32768 + b_row0 + i_ * 1024);
+#define AZ_RMMA(mt0_, fb_, fa_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                   \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+    // one stage: wait for stage s+1, barrier, refill the freed slot, MFMAs of stage s with stage s+1's fragments in flight
+#define AZ_RSTAGE(s_, fbC_, fbN_)                                                                          \
+    {                                                                                                      \
+        if ((s_) + 1 < ns) {                                                                               \
+            if ((s_) + 2 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+        }                                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if ((s_) + 3 < ns) AZ_RDMA((s_) + 3);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        AZ_RMMA(0, fbC_, faX);                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if ((s_) + 1 < ns) {                                                                               \
+            AZ_RLDB(fbN_, (s_) + 1);                                                                       \
+            AZ_RLDA(faX, (s_) + 1, 0);                                                                     \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        AZ_RMMA(4, fbC_, faY);                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        /* the second half of stage s+1's A fragments: requested now, their latency rides out the wait + */ \
+        /* barrier at the top of the next stage (stage s+1 is already complete in LDS)                   */ \
+        if ((s_) + 1 < ns) AZ_RLDA(faY, (s_) + 1, 4);                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+    bf16x8 fb0[4], fb1[4], faX[4], faY[4];
+    AZ_RDMA(0);
+    AZ_RDMA(1);
+    AZ_RDMA(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    AZ_RLDB(fb0, 0);
+    AZ_RLDA(faX, 0, 0);
+    AZ_RLDA(faY, 0, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s2 = 0; s2 < ns; s2 += 2) {     // ns is even (K is a multiple of 64)
+        AZ_RSTAGE(s2, fb0, fb1);
+        AZ_RSTAGE(s2 + 1, fb1, fb0);
+    }
+#undef AZ_RDMA
+#undef AZ_RLDA
+#undef AZ_RLDB
+#undef AZ_RMMA
+#undef AZ_RSTAGE
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wc * 64 + nt * 16 + fq * 4;
@@ -611,7 +749,11 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
         if (g_gemm_variant == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 2) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 4) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 11) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 12) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 2>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else hipLaunchKernelGGL((k_gemm256r<LAYER>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
     const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;

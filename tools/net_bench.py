@@ -11,14 +11,15 @@ e = azeng.Engine(device=0, max_batch=B, profile=True)
 e.net_init_random(0, 1)
 uniq = random_states(orc, 512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, B)]
-VARS = (0, 1, 2)
+VARS = tuple(int(x) for x in os.environ.get('VARS', '0,2,3').split(','))
 outs = {}
 for v in VARS:
     e.set_option("gemm_variant", v)
     outs[v] = e.predict_states(states, 0)
+v0 = VARS[0]
 for v in VARS[1:]:
-    print("variant", v, "vs 0: max|dpi|", np.abs(outs[0][0] - outs[v][0]).max(), "max|dv|", np.abs(outs[0][1] - outs[v][1]).max(),
-          "bitwise", np.array_equal(outs[0][0], outs[v][0]) and np.array_equal(outs[0][1], outs[v][1]))
+    print("variant", v, "vs", v0, ": max|dpi|", np.abs(outs[v0][0] - outs[v][0]).max(), "max|dv|", np.abs(outs[v0][1] - outs[v][1]).max(),
+          "bitwise", np.array_equal(outs[v0][0], outs[v][0]) and np.array_equal(outs[v0][1], outs[v][1]))
 res = {v: [] for v in VARS}
 for r in range(rounds):
     for v in VARS:
