@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
 // issued before this K-step's MFMAs and retired by vmcnt(0) + barrier at the end of the step.
 constexpr int HBM_ = 256, HBN_ = 256;
 
-template <int LAYER, int PIPE, int ABLATE = 0, int XCDMAP = 0>   // ABLATE (timing experiments only): 1 = no DMA in the loop, 2 = no MFMA
+template <int LAYER, int PIPE, int ABLATE = 0, int XCDMAP = 0, int LATE_DMA = 0>   // ABLATE (timing experiments only): 1 = no DMA in the loop, 2 = no MFMA
 __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
             else acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0); \
         }
     for (int kt = 0; kt < nk; ++kt) {
-        if (ABLATE != 1 && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
+        if (ABLATE != 1 && !LATE_DMA && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
         const unsigned char* sA = smem + (kt & 1) * 65536;
         if constexpr (PIPE == 0) {
             const unsigned char* sB = sA + 32768;
@@ -342,6 +342,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
             AZ_LDA(faY, sA, 4, coff0);
             __builtin_amdgcn_sched_barrier(0);
             AZ_MMA(0, fbX, faX);
+            __builtin_amdgcn_sched_barrier(0);
+            // LATE_DMA: the next tile's DMA is issued behind the first MFMA cluster, off the K-step's start-up path
+            if (LATE_DMA && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             AZ_LDB(fbY, sA, coff1);
             AZ_LDA(faX, sA, 0, coff1);
@@ -500,6 +503,181 @@ __global__ __launch_bounds__(512, 2) void k_gemm256r(const GemmDesc d) {
         for (int mt = 0; mt < 8; ++mt) {
             const int m = m0 + wr * 128 + mt * 16 + frow;
             if (m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
+// ---- conv2 as an IMAGE-RESIDENT implicit GEMM ("img" variant) ------------------------------------------------
+// The 9 filter taps of one 64-channel block read overlapping shifted windows of the same activations.  With an M tile
+// of 6 whole boards (252 output rows) the 64-channel slice of those boards is 6 x 42 x 128 B = 31.5 KiB: it is DMA'd
+// into LDS ONCE per channel block (double-buffered, landing during the previous block's taps) and the A fragments of
+// tap (ky,kx) are read from it at row m + (ky-1)*7 + (kx-1); out-of-board taps read a zero row ('same' padding).
+// Only the weight tile (32 KiB) still streams every K-step, so L2->LDS traffic falls from 64 KiB to 35.5 KiB per
+// K-step.  Same K order (channel block outer, tap inner) and per-row accumulation order as the other variants.
+constexpr int IMG_NB = 6, IMG_ROWS = IMG_NB * 42, IMG_ZERO_ROW = 252;
+
+template <int LAYER, int WBUF>   // WBUF = weight buffers in LDS: 2 (prefetch 1 K-step ahead) or 3 (2 ahead, all 160 KiB)
+__global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 + WBUF) * 32768];   // img[2] | w[WBUF]
+    const int n_boards = (int)(*d.n_dev);
+    const int M = n_boards * 42;
+    const int C = d.cin;
+    const int NT = d.N / HBN_;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * IMG_NB, n0 = ntile * HBN_;
+    if (b0 >= n_boards) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    if (tid < 16) *(uint4*)(smem + (tid >> 3) * 32768 + IMG_ZERO_ROW * 128 + (tid & 7) * 16) = make_uint4(0, 0, 0, 0);
+    // image DMA map: item q of this thread = LDS row q*64 + wave*8 + (lane>>3), slot lane&7 (rows >= 252 are not loaded)
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    auto img_off = [&](int q) -> uint32_t {
+        int r = q * 64 + wave * 8 + lrow;
+        r = r < IMG_ROWS ? r : IMG_ROWS - 1;
+        int b = b0 + r / 42;
+        b = b < n_boards ? b : n_boards - 1;
+        const int p = r % 42, y = p / 7, x = p - y * 7;
+        return (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8);
+    };
+    const uint32_t i_off0 = img_off(0), i_off1 = img_off(1), i_off2 = img_off(2), i_off3 = img_off(3);
+    const bool i_row3 = 192 + wave * 8 + lrow < IMG_ROWS;
+    const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
+    const uint32_t b_step = 64u * (uint32_t)d.K;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define AZ_IDMA_W(kk_, buf_)                                                                                 \
+    {                                                                                                        \
+        unsigned char* lb = smem + 65536 + (buf_) * 32768 + wave * 1024;                                     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + (kk_)), (lds_ptr)(lb), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + (kk_)), (lds_ptr)(lb + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 2 * b_step + (kk_)), (lds_ptr)(lb + 16384), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 3 * b_step + (kk_)), (lds_ptr)(lb + 24576), 16, 0, 0); \
+    }
+#define AZ_IDMA_IMG(cb_)                                                                                     \
+    {                                                                                                        \
+        unsigned char* la = smem + ((cb_) & 1) * 32768 + wave * 1024;                                        \
+        const uint32_t co_ = (uint32_t)((cb_) * 64);                                                         \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off0 + co_), (lds_ptr)(la), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off1 + co_), (lds_ptr)(la + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off2 + co_), (lds_ptr)(la + 16384), 16, 0, 0);    \
+        if (i_row3) __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off3 + co_), (lds_ptr)(la + 24576), 16, 0, 0); \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    // per-lane fragment rows: low 16 bits = output row inside the tile, bits 16..24 = tap validity ('same' padding)
+    uint32_t rowmask[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int ml = wr * 128 + mt * 16 + frow;
+        const int p = ml % 42, y = p / 7, x = p - y * 7;
+        uint32_t mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            if (ml < IMG_ROWS && iy >= 0 && iy < 6 && ix >= 0 && ix < 7) mask |= 1u << t;
+        }
+        rowmask[mt] = (uint32_t)ml | (mask << 16);
+    }
+    const int b_row0 = 65536 + (wc * 64 + frow) * 128;
+    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
+    // A fragment (mt, ks) of the current tap: LDS row = m + dt if the tap is inside the board, else the zero row
+#define AZ_ILDA(dst_, img_, mt0_, ks_)                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+        const uint32_t rm_ = rowmask[(mt0_) + i_];                                                           \
+        const int r_ = ((rm_ >> tapbit) & 1u) ? (int)(rm_ & 0xFFFFu) + dt : IMG_ZERO_ROW;                    \
+        dst_[i_] = *(const bf16x8*)((img_) + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));               \
+    }
+#define AZ_ILDB(dst_, wb_, coff_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        dst_[i_] = *(const bf16x8*)((wb_) + b_row0 + i_ * 2048 + (coff_));
+#define AZ_IMMA(mt0_, fb_, fa_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+    const int ncb = C / 64;
+    const int nk = ncb * 9;
+    AZ_IDMA_W(0, 0);
+    AZ_IDMA_IMG(0);
+    if (WBUF == 3) AZ_IDMA_W(1 * C, 1);             // K-step 1 = (cb 0, tap 1)
+    if (WBUF == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cb = 0, tap = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool new_img = tap == 0 && cb + 1 < ncb;
+        const bool w_issue = kt + (WBUF - 1) < nk;
+        if (w_issue) {
+            // weights of K-step kt + WBUF - 1
+            int ntap = tap + (WBUF - 1), ncbi = cb;
+            if (ntap >= 9) { ntap -= 9; ++ncbi; }
+            AZ_IDMA_W(ntap * C + ncbi * 64, (kt + WBUF - 1) % WBUF);
+        }
+        if (new_img) AZ_IDMA_IMG(cb + 1);       // issued after the weights: stays in flight over this step's wait
+        const unsigned char* sI = smem + (cb & 1) * 32768;
+        const unsigned char* sW = smem + (kt % WBUF) * 32768;   // b_row0 already carries the 64 KiB image offset
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int dt = (ky - 1) * 7 + (kx - 1);
+        const int tapbit = 16 + tap;
+        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+        AZ_ILDB(fbX, sW, coffB0);
+        AZ_ILDA(faX, sI, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_ILDA(faY, sI, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_IMMA(0, fbX, faX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_ILDB(fbY, sW, coffB1);
+        AZ_ILDA(faX, sI, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_IMMA(4, fbX, faY);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_ILDA(faY, sI, 4, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_IMMA(0, fbY, faX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_IMMA(4, fbY, faY);
+        // counted wait: the weights of K-step kt+1 must have landed; anything issued after them may stay in flight
+        // (WBUF == 3: the weights of kt+2, and the next image when it was issued this step or the step before)
+        {
+            const int younger = (WBUF == 3 && w_issue ? 4 : 0) + (new_img ? 4 : 0) +
+                                (WBUF == 3 && tap == 1 && cb + 1 < ncb ? 4 : 0);
+            if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                                    // raw: __syncthreads() would drain vmcnt to 0
+        __builtin_amdgcn_sched_barrier(0);
+        if (++tap == 9) { tap = 0; ++cb; }
+    }
+#undef AZ_IDMA_W
+#undef AZ_IDMA_IMG
+#undef AZ_ILDA
+#undef AZ_ILDB
+#undef AZ_IMMA
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ml = wr * 128 + mt * 16 + frow;
+            const int m = b0 * 42 + ml;
+            if (ml >= IMG_ROWS || m >= M) continue;
             float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
                   r3 = acc[mt][nt][3] + bv.w;
             if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
@@ -740,16 +918,26 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
     convnet_set_params(net, p.data(), L.total);
 }
 
-int g_gemm_variant = 2;   // 0: 128x128 everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3; 2: + phased fragment prefetch
+int g_gemm_variant = 5;   // 0: 128x128 tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3; 2: + phased fragment
+                          // prefetch; 3: 4-stage ring; 4: XCD column remap; 5 (default): conv2 image-resident + conv3 as 2;
+                          // 6: 5 with three weight buffers; 7: late DMA; 11/12: timing ablations (wrong results)
 
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
+    if ((g_gemm_variant == 5 || g_gemm_variant == 6) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
+        const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
+        const int t8 = (tiles + 7) / 8 * 8;
+        if (g_gemm_variant == 5) hipLaunchKernelGGL((k_conv_img<LAYER, 2>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else hipLaunchKernelGGL((k_conv_img<LAYER, 3>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        return;
+    }
     const bool big = g_gemm_variant >= 1 && (LAYER == 1 || LAYER == 2) && d.N % HBN_ == 0;
     if (big) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
         if (g_gemm_variant == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 2) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 7) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 4) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 11) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 12) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 2>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);

@@ -91,8 +91,9 @@ typedef struct az_stats {
 az_status az_create(const az_config* cfg, az_engine** out);
 void az_destroy(az_engine* e);
 const char* az_last_error(const az_engine* e);
-/* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" (0 = 128x128 tiles for every layer,
- * 1 = default: 256x256 LDS-DMA tiles for conv2/conv3). Unknown keys return AZ_ERR_BAD_ARGUMENT. */
+/* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
+ * net uses (0 = 128x128 register-staged tiles for every layer ... 5 = default; list in csrc/az_net.hip). All
+ * non-ablation variants are bit-identical. Unknown keys return AZ_ERR_BAD_ARGUMENT. */
 az_status az_set_option(az_engine* e, const char* key, int64_t value);
 az_status az_get_stats(az_engine* e, az_stats* out);
 az_status az_reset_stats(az_engine* e);
