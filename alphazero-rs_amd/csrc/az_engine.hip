@@ -184,12 +184,14 @@ void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int row
 
 // get_action_prob body shared by every entry point: S10/S1 prologue, then num_sims x
 // {select+expand, compact, predict, mask+store+backup}  (src/async_mcts.rs:81-82, :191-217).
+// rows_hint = host-side upper bound on the leaf batch (trees still searching): sizes the net's grids and picks tiles
 void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int num_sims, SearchParams sp,
-                const NetModel& net) {
+                const NetModel& net, int rows_hint) {
     hipStream_t s = e->stream;
+    if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
     launch_root_prepare(th.d, d_root_states, s);
     launch_compact(th.d, th.eb, s);
-    net_forward(e, net, th.eb, th.d.G);
+    net_forward(e, net, th.eb, rows_hint);
     launch_backup(th.d, th.eb, 1, s);
     for (int i = 0; i < num_sims; ++i) {
         hipEvent_t t0 = nullptr;
@@ -198,7 +200,7 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
         if (e->prof.on) e->prof.end(t0, RG_TREE, s);
         launch_compact(th.d, th.eb, s);
         if (e->prof.on) t0 = e->prof.begin(s);
-        net_forward(e, net, th.eb, th.d.G);
+        net_forward(e, net, th.eb, rows_hint);
         if (e->prof.on) { e->prof.end(t0, RG_NET, s); t0 = e->prof.begin(s); }
         launch_backup(th.d, th.eb, 0, s);
         if (e->prof.on) e->prof.end(t0, RG_TREE, s);
@@ -253,6 +255,12 @@ az_status find_net(az_engine* e, int model_id, NetModel** out) {
     *out = &it->second;
     return AZ_OK;
 }
+// the conv net's activation workspace is sized by az_config.max_batch: a tree batch may not exceed it
+az_status check_batch(az_engine* e, const NetModel& net, int trees) {
+    if (net.kind == AZ_NET_CONV && trees > e->cfg.max_batch)
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "concurrent trees exceed az_config.max_batch (conv net workspace)");
+    return AZ_OK;
+}
 
 struct ScopedTimer {
     az_engine* e;
@@ -305,6 +313,10 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (!e || !key) return AZ_ERR_BAD_ARGUMENT;
     if (std::strcmp(key, "gemm_variant") == 0 && value >= 0 && value <= 12) {
         convnet_set_variant((int)value);
+        return AZ_OK;
+    }
+    if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {
+        convnet_set_conv4_big((int)value);
         return AZ_OK;
     }
     return fail(e, AZ_ERR_BAD_ARGUMENT, std::string("unknown option or value: ") + key);
@@ -553,6 +565,8 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
     NetModel* net;
     az_status st = find_net(e, t->model_id, &net);
     if (st) return st;
+    st = check_batch(e, *net, t->th.d.G);
+    if (st) return st;
     ScopedTimer timer{e};
     try {
         HIPCHK(hipSetDevice(e->device));
@@ -561,7 +575,7 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
         HIPCHK(hipMemcpyAsync(t->d_root_states, states, (size_t)G * 16, hipMemcpyDefault, e->stream));
         HIPCHK(hipMemsetAsync(d.active, 1, G, e->stream));
         SearchParams sp{(uint32_t)t->max_depth, (float)t->cpuct};
-        run_search(e, t->th, t->d_root_states, t->num_sims, sp, *net);
+        run_search(e, t->th, t->d_root_states, t->num_sims, sp, *net, G);
         launch_root_policy(d, temp, seed, first_game_id, t->d_pi, t->d_counts, t->d_q, e->stream);
         HIPCHK(hipStreamSynchronize(e->stream));
         resolve_profile(e);
@@ -589,6 +603,8 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: negative capacity");
     NetModel* net;
     az_status st = find_net(e, p->model_id, &net);
+    if (st) return st;
+    st = check_batch(e, *net, C);
     if (st) return st;
     ScopedTimer timer{e};
     try {
@@ -641,15 +657,17 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         struct PinnedFree { uint32_t* p; ~PinnedFree() { (void)hipHostFree(p); } } pinned{h_ctr};
         uint64_t moves = 0;
         az_status result = AZ_OK;
+        int active = C;                               // slots still playing (read back after every move)
         for (int iter = 0;; ++iter) {
             launch_selfplay_sync_active(th.d, gd, s);
-            run_search(e, th, gd.state, p->num_sims, sp, *net);
+            run_search(e, th, gd.state, p->num_sims, sp, *net, active);
             launch_selfplay_move(th.d, gd, mp, s);
             if (mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
             HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             resolve_profile(e);
             ++moves;
+            active = (int)h_ctr[2];
             if (h_ctr[1] >= (uint32_t)n_games) break;
             if ((iter & 7) == 7 || h_ctr[2] == 0) {
                 result = check_tree_errors(e, th);
@@ -731,6 +749,10 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
     if (st) return st;
     st = find_net(e, p->old_model_id, &net_old);
     if (st) return st;
+    st = check_batch(e, *net_new, G);
+    if (st) return st;
+    st = check_batch(e, *net_old, G);
+    if (st) return st;
     ScopedTimer timer{e};
     try {
         HIPCHK(hipSetDevice(e->device));
@@ -762,8 +784,8 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         az_status result = AZ_OK;
         for (int ply = 0; ply <= AZ_MAX_PLIES; ++ply) {
             launch_arena_sync(tn.d, to.d, ad, s);
-            run_search(e, tn, ad.state, p->num_sims, sp, *net_new);
-            run_search(e, to, ad.state, p->num_sims, sp, *net_old);
+            run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0]);
+            run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0]);
             launch_arena_move(tn.d, ad, p->seed, s);
             launch_arena_move(to.d, ad, p->seed, s);
             HIPCHK(hipMemcpyAsync(ctr, ad.counters, sizeof ctr, hipMemcpyDeviceToHost, s));

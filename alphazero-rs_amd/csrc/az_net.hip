@@ -922,6 +922,8 @@ int g_gemm_variant = 5;   // 0: 128x128 tiles everywhere; 1: 256x256 LDS-DMA til
                           // prefetch; 3: 4-stage ring; 4: XCD column remap; 5 (default): conv2 image-resident + conv3 as 2;
                           // 6: 5 with three weight buffers; 7: late DMA; 11/12: timing ablations (wrong results)
 
+int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
+
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     if ((g_gemm_variant == 5 || g_gemm_variant == 6) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
@@ -931,7 +933,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
         else hipLaunchKernelGGL((k_conv_img<LAYER, 3>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
-    const bool big = g_gemm_variant >= 1 && (LAYER == 1 || LAYER == 2) && d.N % HBN_ == 0;
+    const bool big = g_gemm_variant >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_hint >= 4096)))) && d.N % HBN_ == 0;
     if (big) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
@@ -980,6 +982,7 @@ void convnet_resolve_profile(ConvNet* n, NetProfile* prof) {
 }
 
 void convnet_set_variant(int v) { g_gemm_variant = v; }
+void convnet_set_conv4_big(int v) { g_conv4_big = v; }
 
 void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t s, NetProfile* prof) {
     const int C = n->C;

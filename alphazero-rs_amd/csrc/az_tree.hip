@@ -259,37 +259,56 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
 
 // ---- inference batch assembly (src/async_mcts.rs:137-151 restated): deterministic compaction ----
 __global__ __launch_bounds__(1024) void k_compact(TreeDev t, EvalBatch eb) {
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
-    const int per = (t.G + 1023) / 1024;
-    const int g0 = tid * per;
-    uint32_t cnt = 0;
-    for (int i = 0; i < per; ++i) {
-        int g = g0 + i;
-        if (g < t.G && t.leaf_kind[g] == LEAF_EVAL) ++cnt;
-    }
-    part[tid] = cnt;
+    // Round r covers trees [r*1024, (r+1)*1024): coalesced flag loads, one ballot per wave, then a scan over the
+    // (round, wave) counts.  Rows come out in ascending tree order (deterministic batches).
+    __shared__ uint32_t cnt[1024];                          // [round*16 + wave], rounds <= 64 (G <= 65536)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rounds = (t.G + 1023) >> 10;
+    cnt[tid] = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele inclusive scan
-        uint32_t v = tid >= off ? part[tid - off] : 0u;
+    for (int r = 0; r < rounds; ++r) {
+        const int g = (r << 10) + tid;
+        const bool f = g < t.G && t.leaf_kind[g] == LEAF_EVAL;
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) cnt[r * 16 + wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    const uint32_t mine = cnt[tid];
+    for (int off = 1; off < 1024; off <<= 1) {              // inclusive Hillis-Steele scan over the 1024 entries
+        uint32_t v = tid >= off ? cnt[tid - off] : 0u;
         __syncthreads();
-        part[tid] += v;
+        cnt[tid] += v;
         __syncthreads();
     }
-    uint32_t slot = part[tid] - cnt;
-    for (int i = 0; i < per; ++i) {
-        int g = g0 + i;
-        if (g >= t.G) break;
-        if (t.leaf_kind[g] == LEAF_EVAL) {
-            t.slot_of[g] = (int32_t)slot;
-            eb.tree[slot] = (uint32_t)g;
-            eb.state[slot] = t.state[(size_t)g * t.R + t.leaf[g]];
-            ++slot;
-        } else {
-            t.slot_of[g] = -1;
+    const uint32_t excl = cnt[tid] - mine;
+    __syncthreads();
+    cnt[tid] = excl;                                        // exclusive prefix per (round, wave)
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const int g = (r << 10) + tid;
+        const bool f = g < t.G && t.leaf_kind[g] == LEAF_EVAL;
+        const unsigned long long m = __ballot(f);
+        if (g < t.G) {
+            if (f) {
+                const uint32_t slot = cnt[r * 16 + wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                t.slot_of[g] = (int32_t)slot;
+                eb.tree[slot] = (uint32_t)g;
+                eb.state[slot] = t.state[(size_t)g * t.R + t.leaf[g]];
+            } else {
+                t.slot_of[g] = -1;
+            }
         }
     }
-    if (tid == 1023) *eb.n = part[1023];
+    if (tid == 0) {
+        uint32_t total = 0;
+        const int last = rounds * 16 - 1;
+        // total = exclusive prefix of the last entry + its own count (recomputed: the last round's last wave)
+        const int g0 = ((rounds - 1) << 10) + 15 * 64;
+        uint32_t c = 0;
+        for (int i = 0; i < 64; ++i) { int g = g0 + i; if (g < t.G && t.leaf_kind[g] == LEAF_EVAL) ++c; }
+        total = cnt[last] + c;
+        *eb.n = total;
+    }
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
