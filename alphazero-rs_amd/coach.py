@@ -1,0 +1,164 @@
+"""Coach::learn around the MI355X engine -- SURVEY.md section 8(f1, f3).
+
+Mirrors src/coach.rs: `Coach.setup` takes the reference's 15 parameters (src/coach.rs:38-54) with the same
+meaning, `learn` runs the iteration loop of src/coach.rs:169-396: self-play episodes -> replay window
+(max_queue_length / max_history_length) -> save examples -> shuffle -> NNet::train -> arena of new vs old ->
+accept iff nwins + pwins > 0 and nwins / (nwins + pwins) >= update_threshold (:383-390).  Self-play and the arena
+are ONE engine call each (az_selfplay / az_arena); episodes shard across ranks by global game id when a process
+group is active, the tuples are gathered once per iteration (alphazero-rs_amd/dist.py) and gradients are all-reduced.
+
+On-disk formats (the reference's are bincode / TF checkpoints, src/coach.rs:159-167 with defect A14; these are the
+build's own, documented here):
+  <dir>/<iter>.examples   numpy .npz: lens [H] int64 (samples per history entry), boards [N,2,6,7] f32,
+                          pis [N,7] f32, vs [N] f32 -- the whole `history` deque, oldest entry first
+  <dir>/<model_id>.aznet  weights file of az_net_save
+Resume picks the largest numeric stem, as Coach::setup does (:55-81); non-numeric files are ignored instead of
+panicking.
+"""
+import collections
+import os
+
+import numpy as np
+
+
+class Coach:
+    def __init__(self):
+        raise TypeError("use Coach.setup(...)")
+
+    @classmethod
+    def setup(cls, engine, checkpoint_directory, mcts_reserve_size, update_threshold, temp_threshold,
+              max_history_length, max_queue_length, inference_batch_size, num_episode_threads, num_arena_games,
+              num_iters, num_eps, num_sims, num_sim_threads, max_depth, cpuct, trainer=None, group=None, log=print):
+        self = object.__new__(cls)
+        if num_sims % inference_batch_size != 0:                      # assert!, src/coach.rs:83
+            raise ValueError("num_sims % inference_batch_size != 0")
+        if num_sim_threads != 1:
+            raise ValueError("the engine runs one simulation per tree at a time (num_sim_threads = 1)")
+        self.engine, self.trainer, self.group, self.log = engine, trainer, group, log
+        self.dir = str(checkpoint_directory)
+        self.mcts_reserve_size, self.update_threshold, self.temp_threshold = mcts_reserve_size, update_threshold, temp_threshold
+        self.max_history_length, self.max_queue_length = max_history_length, max_queue_length
+        self.num_episode_threads = num_episode_threads    # = concurrent game slots on the GPU (rayon pool size, :202-205)
+        self.num_arena_games, self.num_iters, self.num_eps, self.num_sims = num_arena_games, num_iters, num_eps, num_sims
+        self.max_depth, self.cpuct = max_depth, cpuct
+        self.history = collections.deque()
+        self.start_iteration = 0
+        os.makedirs(self.dir, exist_ok=True)
+        stems = [int(f[:-9]) for f in os.listdir(self.dir) if f.endswith(".examples") and f[:-9].isdigit()]
+        if stems:                                                      # src/coach.rs:55-81
+            it = max(stems)
+            z = np.load(os.path.join(self.dir, f"{it}.examples"), allow_pickle=False)
+            o = 0
+            for n in z["lens"]:
+                n = int(n)
+                self.history.append((z["boards"][o:o + n], z["pis"][o:o + n], z["vs"][o:o + n]))
+                o += n
+            self.start_iteration = it + 1
+        return self
+
+    # ---- rank helpers -------------------------------------------------------------------------------------
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
+
+    def save_train_examples(self, iteration):
+        """src/coach.rs:159-167 (A14 repaired: <dir>/<iter>.examples, not an absolute path)."""
+        lens = np.array([h[2].shape[0] for h in self.history], np.int64)
+        cat = lambda i, shp: (np.concatenate([h[i] for h in self.history]) if len(self.history) else np.zeros(shp, np.float32))
+        path = os.path.join(self.dir, f"{iteration}.examples")
+        with open(path, "wb") as f:
+            np.savez(f, lens=lens, boards=cat(0, (0, 2, 6, 7)), pis=cat(1, (0, 7)), vs=cat(2, (0,)))
+        return path
+
+    def execute_episodes(self, model_id, iteration, seed):
+        """The self-play fan-out of src/coach.rs:241-272: num_eps x execute_episode, sharded by global game id."""
+        from . import dist as azdist
+        rank, world = self._world()
+        lo, hi = azdist.shard_range(self.num_eps, rank, world)
+        first = iteration * self.num_eps
+        if hi > lo:
+            r = self.engine.selfplay(n_games=hi - lo, num_sims=self.num_sims, model_id=model_id, seed=seed,
+                                     first_game_id=first + lo, concurrent=min(self.num_episode_threads, hi - lo),
+                                     temp_threshold=self.temp_threshold, max_depth=self.max_depth, cpuct=self.cpuct,
+                                     reserve=self.mcts_reserve_size, symmetries=False, want_boards=False)
+            states, pis, zs = r["states"], r["pis"], r["zs"]
+        else:
+            states, pis, zs = np.zeros((0, 2), np.uint64), np.zeros((0, 7), np.float32), np.zeros(0, np.float32)
+        if world > 1:
+            import torch
+            import torch.distributed as tdist
+            dev = torch.device("cuda", torch.cuda.current_device()) if tdist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            packed = azdist.pack_samples(torch.from_numpy(states.view(np.int64)).to(dev), torch.from_numpy(pis).to(dev),
+                                         torch.from_numpy(zs).to(dev))
+            counts = torch.zeros(world, dtype=torch.int64, device=dev)
+            tdist.all_gather_into_tensor(counts, torch.tensor([packed.shape[0]], dtype=torch.int64, device=dev), group=self.group)
+            cmax = int(counts.max())
+            padded = torch.zeros((cmax, azdist.TUPLE_WORDS), dtype=torch.int32, device=dev)
+            padded[: packed.shape[0]] = packed
+            allp = torch.zeros((world * cmax, azdist.TUPLE_WORDS), dtype=torch.int32, device=dev)
+            tdist.all_gather_into_tensor(allp, padded, group=self.group)        # every rank trains: all-gather
+            allp = torch.cat([allp[r * cmax: r * cmax + int(counts[r])] for r in range(world)])
+            s, p, z = azdist.unpack_samples(allp)
+        else:
+            import torch
+            s, p, z = torch.from_numpy(states.view(np.int64)), torch.from_numpy(pis), torch.from_numpy(zs)
+        from . import dist as azd
+        s2, p2, z2 = azd.expand_symmetries(s.cpu(), p.cpu(), z.cpu())           # get_symmetries at the destination
+        boards = states_to_boards(s2.numpy().view(np.uint64))
+        return boards, p2.numpy(), z2.numpy()
+
+    def learn(self, skip_first_play=False, seed=0, model_id=0):
+        """src/coach.rs:169-396.  Engine model slots: `model_id` is the current net, `model_id + 1` the candidate.
+        Returns a list of per-iteration dicts (wins, accepted, losses)."""
+        rank, world = self._world()
+        rng = np.random.default_rng(seed)
+        report = []
+        for iteration in range(self.start_iteration, self.start_iteration + self.num_iters):
+            if not skip_first_play or iteration > self.start_iteration:
+                boards, pis, vs = self.execute_episodes(model_id, iteration, seed)
+                if vs.shape[0] > self.max_queue_length:                 # :275-277: keep the newest max_queue_length
+                    boards, pis, vs = boards[-self.max_queue_length:], pis[-self.max_queue_length:], vs[-self.max_queue_length:]
+                self.history.append((boards, pis, vs))
+            if len(self.history) > self.max_history_length:             # :285-288
+                self.history.popleft()
+            if rank == 0:
+                self.save_train_examples(iteration)                     # :291-293
+            allb = np.concatenate([h[0] for h in self.history])
+            allp = np.concatenate([h[1] for h in self.history])
+            allv = np.concatenate([h[2] for h in self.history])
+            assert allv.shape[0] > 0                                    # :305
+            perm = rng.permutation(allv.shape[0])                       # :296-297 shuffle
+            allb, allp, allv = allb[perm], allp[perm], allv[perm]
+            prev = self.engine.net_get_params(model_id)
+            new = self.trainer.train(prev, allb, allp, allv, seed=seed + iteration)   # :329 -> NNet::train(samples, id, id+1)
+            self.engine.net_set_params(model_id + 1, new)
+            if rank == 0:
+                self.engine.net_save(model_id + 1, os.path.join(self.dir, f"{model_id + 1}.aznet"))
+            # arena: new (first listed) vs old, both seatings (:333-375)
+            wld, _ = self.engine.arena(self.num_arena_games, self.num_sims, new_model_id=model_id + 1, old_model_id=model_id,
+                                       seed=seed + 7919 * (iteration + 1), max_depth=self.max_depth, cpuct=self.cpuct,
+                                       reserve=self.mcts_reserve_size)
+            nwins, pwins, draws = int(wld[0]), int(wld[1]), int(wld[2])
+            self.log(f"NEW/PREV WINS : {nwins} / {pwins}; DRAWS : {draws}")            # :381
+            accepted = not (pwins + nwins == 0 or nwins / (pwins + nwins) < self.update_threshold)   # :383-390
+            self.log("ACCEPTING NEW MODEL" if accepted else "REJECTING NEW MODEL")
+            report.append({"iteration": iteration, "samples": int(allv.shape[0]), "nwins": nwins, "pwins": pwins,
+                           "draws": draws, "accepted": accepted, "losses": list(self.trainer.history), "model_id": model_id})
+            if accepted:
+                model_id += 1
+        self.model_id = model_id
+        return report
+
+
+def states_to_boards(states):
+    """to_features (connect_four_game.rs:219-237, S8) for [N,2] uint64 canonical bitboards -> [N,2,6,7] f32."""
+    states = np.asarray(states, np.uint64).reshape(-1, 2)
+    out = np.zeros((states.shape[0], 2, 6, 7), np.float32)
+    for r in range(6):
+        for c in range(7):
+            bit = np.uint64(1) << np.uint64(c * 7 + (5 - r))
+            out[:, 0, r, c] = (states[:, 0] & bit) != 0
+            out[:, 1, r, c] = (states[:, 1] & bit) != 0
+    return out

@@ -114,7 +114,9 @@ az_status az_net_get_params(az_engine* e, int32_t model_id, float* params, int64
 az_status az_net_predict(az_engine* e, int32_t model_id, const float* boards, int32_t B, float* pi, float* v);
 /* Same on canonical bitboards [B,2] (what the search feeds the net). */
 az_status az_net_predict_states(az_engine* e, int32_t model_id, const uint64_t* states, int32_t B, float* pi, float* v);
-/* NNet::train(examples, previous_model_id, model_id), src/nnet.rs:38 -- next tier; returns AZ_ERR_UNSUPPORTED. */
+/* NNet::train(examples, previous_model_id, model_id), src/nnet.rs:38. Not implemented inside the library (returns
+ * AZ_ERR_UNSUPPORTED): training currently runs host-side (alphazero-rs_amd/trainer.py, PyTorch-ROCm autograd on the same
+ * parameter vector) and uploads the result with az_net_set_params. */
 az_status az_net_train(az_engine* e, int32_t prev_id, int32_t id, const float* boards, const float* pis,
                        const float* vs, int64_t n);
 

@@ -1,0 +1,104 @@
+//! Raw bindings of include/az_engine.h plus a safe `Mi355xNNet` implementing the reference's `NNet` trait shape
+//! (src/nnet.rs:35-45) and helpers that replace the self-play fan-out (src/coach.rs:241-272) and the arena gate
+//! (src/coach.rs:333-390) with one engine call each.  NOT compiled in this repository (no Rust toolchain here).
+#![allow(non_camel_case_types)]
+use std::ffi::{CStr, CString};
+use std::os::raw::{c_char, c_int};
+use std::path::Path;
+
+use ndarray::{Array1, Array2, ArrayViewD};
+
+#[repr(C)] pub struct az_engine { _p: [u8; 0] }
+#[repr(C)] pub struct az_tree { _p: [u8; 0] }
+
+#[repr(C)] #[derive(Default, Clone, Copy)]
+pub struct az_config { pub device: i32, pub max_batch: i32, pub net_channels: i32, pub profile: i32 }
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct az_selfplay_params {
+    pub n_games: i32, pub concurrent: i32, pub num_sims: i32, pub temp_threshold: i32,
+    pub max_depth: i32, pub cpuct: i32, pub model_id: i32, pub symmetries: i32,
+    pub reserve: u64, pub seed: u64, pub first_game_id: u64, pub record_evals: i32, pub reserved0: i32,
+}
+#[repr(C)]
+pub struct az_samples {
+    pub capacity: i64, pub count: i64, pub states: *mut u64, pub boards: *mut f32,
+    pub pis: *mut f32, pub zs: *mut f32, pub game_len: *mut i32, pub moves: *mut u8,
+}
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct az_arena_params {
+    pub num_games: i32, pub num_sims: i32, pub max_depth: i32, pub cpuct: i32,
+    pub new_model_id: i32, pub old_model_id: i32, pub reserve: u64, pub seed: u64,
+}
+
+extern "C" {
+    pub fn az_create(cfg: *const az_config, out: *mut *mut az_engine) -> c_int;
+    pub fn az_destroy(e: *mut az_engine);
+    pub fn az_last_error(e: *const az_engine) -> *const c_char;
+    pub fn az_set_option(e: *mut az_engine, key: *const c_char, value: i64) -> c_int;
+    pub fn az_net_set_kind(e: *mut az_engine, model_id: i32, kind: c_int, salt: u64) -> c_int;
+    pub fn az_net_init_random(e: *mut az_engine, model_id: i32, seed: u64) -> c_int;
+    pub fn az_net_load(e: *mut az_engine, model_id: i32, path: *const c_char) -> c_int;
+    pub fn az_net_save(e: *mut az_engine, model_id: i32, path: *const c_char) -> c_int;
+    pub fn az_net_param_count(e: *const az_engine) -> i64;
+    pub fn az_net_set_params(e: *mut az_engine, model_id: i32, params: *const f32, n: i64) -> c_int;
+    pub fn az_net_get_params(e: *mut az_engine, model_id: i32, params: *mut f32, n: i64) -> c_int;
+    pub fn az_net_predict(e: *mut az_engine, model_id: i32, boards: *const f32, b: i32, pi: *mut f32, v: *mut f32) -> c_int;
+    pub fn az_net_train(e: *mut az_engine, prev_id: i32, id: i32, boards: *const f32, pis: *const f32, vs: *const f32, n: i64) -> c_int;
+    pub fn az_tree_create(e: *mut az_engine, n_games: i32, reserve: u64, num_sims: i32, max_depth: i32,
+                          model_id: i32, cpuct: i32, out: *mut *mut az_tree) -> c_int;
+    pub fn az_tree_destroy(t: *mut az_tree);
+    pub fn az_tree_get_action_prob(t: *mut az_tree, states: *const u64, temp: f32, seed: u64, first_game_id: u64,
+                                   pi: *mut f32, counts: *mut u16, q: *mut f32) -> c_int;
+    pub fn az_selfplay(e: *mut az_engine, p: *const az_selfplay_params, out: *mut az_samples) -> c_int;
+    pub fn az_arena(e: *mut az_engine, p: *const az_arena_params, out_wld: *mut u64, results: *mut i8) -> c_int;
+}
+
+/// The reference panics on every error (unwrap/assert!); keep that behaviour.
+pub fn check(e: *const az_engine, rc: c_int) {
+    if rc != 0 {
+        let msg = unsafe { CStr::from_ptr(az_last_error(e)) }.to_string_lossy().into_owned();
+        panic!("az_engine status {}: {}", rc, msg);
+    }
+}
+
+/// `impl NNet` (src/nnet.rs:35-45) over the engine; drop-in for `PythonNNet` (examples/utils/python_nnet.rs).
+pub struct Mi355xNNet { pub e: *mut az_engine }
+
+impl Mi355xNNet {
+    pub fn new<P: AsRef<Path>>(checkpoint: P) -> Self {                               // NNet::new, src/nnet.rs:36
+        let mut e = std::ptr::null_mut();
+        assert_eq!(unsafe { az_create(&az_config::default(), &mut e) }, 0, "az_create failed");
+        let p = CString::new(checkpoint.as_ref().join("0.aznet").to_str().unwrap()).unwrap();
+        if unsafe { az_net_load(e, 0, p.as_ptr()) } != 0 { check(e, unsafe { az_net_init_random(e, 0, 0) }); }
+        Mi355xNNet { e }
+    }
+    /// NNet::predict(board [B,2,6,7], model_id) -> (pi [B,7], v [B]), src/nnet.rs:40-44
+    pub fn predict(&self, board: ArrayViewD<f32>, model_id: usize) -> (Array2<f32>, Array1<f32>) {
+        let b = board.shape()[0];
+        let x = board.as_standard_layout();
+        let (mut pi, mut v) = (Array2::<f32>::zeros((b, 7)), Array1::<f32>::zeros(b));
+        check(self.e, unsafe { az_net_predict(self.e, model_id as i32, x.as_ptr(), b as i32, pi.as_mut_ptr(), v.as_mut_ptr()) });
+        (pi, v)
+    }
+}
+impl Drop for Mi355xNNet { fn drop(&mut self) { unsafe { az_destroy(self.e) } } }
+
+/// Replaces the rayon fan-out of `execute_episode` (src/coach.rs:241-272): returns (boards [N,2,6,7], pis [N,7], vs [N]).
+pub fn self_play(e: *mut az_engine, p: &az_selfplay_params) -> (Vec<f32>, Vec<f32>, Vec<f32>) {
+    let cap = p.n_games as usize * 42 * if p.symmetries != 0 { 2 } else { 1 };
+    let (mut boards, mut pis, mut zs) = (vec![0f32; cap * 84], vec![0f32; cap * 7], vec![0f32; cap]);
+    let mut out = az_samples { capacity: cap as i64, count: 0, states: std::ptr::null_mut(), boards: boards.as_mut_ptr(),
+                               pis: pis.as_mut_ptr(), zs: zs.as_mut_ptr(), game_len: std::ptr::null_mut(), moves: std::ptr::null_mut() };
+    check(e, unsafe { az_selfplay(e, p, &mut out) });
+    let n = out.count as usize;
+    boards.truncate(n * 84); pis.truncate(n * 7); zs.truncate(n);
+    (boards, pis, zs)
+}
+
+/// Replaces `play_games` + the tally of src/coach.rs:365-381: (nwins, pwins, draws) for the new model.
+pub fn arena(e: *mut az_engine, p: &az_arena_params) -> (u64, u64, u64) {
+    let mut wld = [0u64; 3];
+    check(e, unsafe { az_arena(e, p, wld.as_mut_ptr(), std::ptr::null_mut()) });
+    (wld[0], wld[1], wld[2])
+}

@@ -1,0 +1,167 @@
+"""CPU tests of the next-tier host logic: the trainer (NNet::train recipe) and the Coach::learn loop
+(replay window, examples files, resume, arena gate) driven by a fake engine that is backed by the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from net_ref import forward_ref, random_params
+
+
+@pytest.fixture(scope="module")
+def mods(engine_mod):
+    from alphazero_rs_amd import coach, trainer
+    return coach, trainer
+
+
+def test_trainer_forward_matches_reference(mods):
+    coach, trainer = mods
+    C = 16
+    p = random_params(C, 3)
+    boards = (np.random.default_rng(0).random((9, 2, 6, 7)) > 0.7).astype(np.float32)
+    net = trainer.PolicyValueNet(C, p, torch.device("cpu"))
+    net.eval()
+    with torch.no_grad():
+        logits, v = net(torch.from_numpy(boards))
+    rpi, rv = forward_ref(p, boards, C, emulate_bf16=False)
+    assert np.abs(torch.softmax(logits, 1).numpy() - rpi).max() < 1e-5 and np.abs(v.numpy() - rv).max() < 1e-5
+    assert np.array_equal(net.flat_params(), p)                       # layout round trip
+    assert trainer.layout(512)[1] == 10779144
+
+
+def test_trainer_reduces_loss_and_updates_bn(mods):
+    coach, trainer = mods
+    C = 16
+    g = np.random.default_rng(1)
+    boards = (g.random((256, 2, 6, 7)) > 0.6).astype(np.float32)
+    pis = g.random((256, 7)).astype(np.float32)
+    pis /= pis.sum(1, keepdims=True)
+    vs = np.tanh(boards.reshape(256, -1)[:, :5].sum(1) - 2).astype(np.float32)
+    p0 = random_params(C, 2, bn_random=False)
+    tr = trainer.Trainer(channels=C, epochs=6, batch_size=32, device=torch.device("cpu"))
+    p1 = tr.train(p0, boards, pis, vs, seed=5)
+    # training-mode loss falls epoch over epoch (the eval-mode loss lags: BN moving statistics move with momentum
+    # 0.99, the tf.layers default, so after a few dozen steps they are still near their initial values)
+    assert len(tr.history) == 6 and sum(tr.history[-1]) < sum(tr.history[0]) and tr.history[-1][1] < tr.history[0][1]
+    assert np.isfinite(sum(tr.evaluate(p1, boards, pis, vs)))
+    off, _ = trainer.layout(C)
+    o, _shape = off["conv2_bn"]
+    assert not np.array_equal(p1[o + 2 * C:o + 3 * C], p0[o + 2 * C:o + 3 * C])      # moving mean moved
+    assert np.array_equal(tr.train(p0, boards, pis, vs, seed=5), p1)                 # deterministic given the seed
+
+
+class FakeEngine:
+    """Stands in for alphazero_rs_amd.engine.Engine on a machine without a GPU: self-play and arena come from the
+    oracle with the hash fixture net (salt = a checksum of the model's parameters, so a retrained model plays
+    differently)."""
+
+    def __init__(self, oracle, C):
+        self.oracle, self.C, self.params = oracle, C, {}
+        self.calls = []
+
+    def _salt(self, model_id):
+        return int(np.abs(self.params[model_id]).sum() * 1e3) % (1 << 30)
+
+    def net_get_params(self, model_id):
+        return self.params[model_id].copy()
+
+    def net_set_params(self, model_id, p):
+        self.params[model_id] = np.asarray(p, np.float32).copy()
+
+    def net_save(self, model_id, path):
+        self.params[model_id].tofile(path)
+
+    def selfplay(self, n_games, num_sims, model_id, seed, first_game_id, concurrent, temp_threshold, max_depth, cpuct,
+                 reserve, symmetries, want_boards):
+        self.calls.append(("selfplay", n_games, first_game_id, model_id))
+        r = self.oracle.selfplay(n_games, num_sims, net_kind=self.oracle.NET_HASH, salt=self._salt(model_id), seed=seed,
+                                 first_game_id=first_game_id, temp_threshold=temp_threshold, threads=4)
+        from alphazero_rs_amd import dist as azdist
+        b = r["boards"][0::2]
+        states = np.zeros((b.shape[0], 2), np.uint64)
+        for rr in range(6):
+            for c in range(7):
+                bit = np.uint64(1) << np.uint64(c * 7 + (5 - rr))
+                states[:, 0] |= np.where(b[:, 0, rr, c] != 0, bit, np.uint64(0))
+                states[:, 1] |= np.where(b[:, 1, rr, c] != 0, bit, np.uint64(0))
+        return {"states": states, "pis": r["pis"][0::2], "zs": r["zs"][0::2], "count": b.shape[0], "ref": r}
+
+    def arena(self, num_games, num_sims, new_model_id, old_model_id, seed, max_depth, cpuct, reserve):
+        self.calls.append(("arena", num_games, new_model_id, old_model_id))
+        return self.oracle.arena(num_games, num_sims, net_kind=self.oracle.NET_HASH, salt=self._salt(new_model_id) ^ self._salt(old_model_id),
+                                 seed=seed, new_model_id=1, old_model_id=0, threads=4)
+
+
+def make_coach(coach, trainer, oracle, tmp, iters, C=16, history=2, queue=10000):
+    eng = FakeEngine(oracle, C)
+    eng.net_set_params(0, random_params(C, 9, bn_random=False))
+    tr = trainer.Trainer(channels=C, epochs=1, batch_size=16, device=torch.device("cpu"))
+    msgs = []
+    c = coach.Coach.setup(eng, tmp, 1000000, 0.6, 15, history, queue, 1, 64, 6, iters, 5, 10, 1, 1000, 1, trainer=tr,
+                          log=msgs.append)
+    return c, eng, msgs
+
+
+def test_coach_learn_loop(mods, oracle, tmp_path):
+    coach, trainer = mods
+    c, eng, msgs = make_coach(coach, trainer, oracle, str(tmp_path), iters=3)
+    rep = c.learn(seed=4)
+    assert [r["iteration"] for r in rep] == [0, 1, 2]
+    # self-play: num_eps episodes per iteration with global ids iteration*num_eps.., symmetries regenerated (x2)
+    sp = [x for x in eng.calls if x[0] == "selfplay"]
+    assert [(x[1], x[2]) for x in sp] == [(5, 0), (5, 5), (5, 10)]
+    ref0 = oracle.selfplay(5, 10, net_kind=oracle.NET_HASH, salt=eng._salt(0) if rep[0]["model_id"] == 0 else 0, seed=4, threads=4)
+    # history window: at most max_history_length (2) iterations are kept and trained on
+    assert len(c.history) == 2
+    assert rep[2]["samples"] == sum(h[2].shape[0] for h in c.history)
+    # gate arithmetic (src/coach.rs:383-390) and the log line (:381)
+    for r in rep:
+        tot = r["nwins"] + r["pwins"]
+        assert r["accepted"] == (tot > 0 and r["nwins"] / tot >= 0.6)
+        assert r["nwins"] + r["pwins"] + r["draws"] == 6
+    assert any(m.startswith("NEW/PREV WINS : ") for m in msgs)
+    # model ids advance only on acceptance
+    assert c.model_id == sum(r["accepted"] for r in rep)
+    # files: <iter>.examples per iteration, <id>.aznet per candidate
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".examples")) == ["0.examples", "1.examples", "2.examples"]
+    z = np.load(os.path.join(tmp_path, "2.examples"), allow_pickle=False)
+    assert z["lens"].tolist() == [h[2].shape[0] for h in c.history] and z["boards"].shape[1:] == (2, 6, 7)
+    # the stored tuples are the oracle's execute_episode tuples incl. the mirrored twins
+    first_iter = np.load(os.path.join(tmp_path, "0.examples"), allow_pickle=False)
+    if rep[0]["model_id"] == 0:
+        assert np.array_equal(first_iter["boards"], ref0["boards"]) and np.array_equal(first_iter["pis"], ref0["pis"])
+        assert np.array_equal(first_iter["vs"], ref0["zs"])
+
+
+def test_coach_resume_and_queue_limit(mods, oracle, tmp_path):
+    coach, trainer = mods
+    c, eng, _ = make_coach(coach, trainer, oracle, str(tmp_path), iters=1, queue=40)
+    c.learn(seed=1)
+    assert c.history[0][2].shape[0] == 40                      # only the newest max_queue_length samples are kept
+    open(os.path.join(tmp_path, "notes.txt"), "w").write("ignored")       # the reference would panic on this (A14)
+    c2, eng2, _ = make_coach(coach, trainer, oracle, str(tmp_path), iters=1, queue=40)
+    assert c2.start_iteration == 1 and len(c2.history) == 1 and c2.history[0][2].shape[0] == 40
+    rep = c2.learn(seed=1)
+    assert rep[0]["iteration"] == 1 and os.path.exists(os.path.join(tmp_path, "1.examples"))
+
+
+def test_setup_contracts(mods, oracle, tmp_path):
+    coach, trainer = mods
+    eng = FakeEngine(oracle, 16)
+    with pytest.raises(ValueError):
+        coach.Coach.setup(eng, str(tmp_path), 1000, 0.6, 15, 2, 100, 3, 1, 4, 1, 1, 10, 1, 1000, 1)     # 10 % 3 != 0
+    with pytest.raises(ValueError):
+        coach.Coach.setup(eng, str(tmp_path), 1000, 0.6, 15, 2, 100, 1, 1, 4, 1, 1, 10, 2, 1000, 1)     # sim threads != 1
+
+
+def test_states_to_boards(mods, oracle):
+    coach, _ = mods
+    s = (0, 0)
+    sts = []
+    for a in (3, 3, 2, 4, 0, 6, 6):
+        s = oracle.c4_play(s[0], s[1], a)
+        sts.append(s)
+    b = coach.states_to_boards(np.array(sts, dtype=np.uint64))
+    for i, st in enumerate(sts):
+        assert np.array_equal(b[i], oracle.c4_features(*st))
