@@ -311,8 +311,23 @@ const char* az_last_error(const az_engine* e) { return e ? e->err.c_str() : "nul
 
 az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (!e || !key) return AZ_ERR_BAD_ARGUMENT;
-    if (std::strcmp(key, "gemm_variant") == 0 && value >= 0 && value <= 12) {
+    if (std::strcmp(key, "gemm_variant") == 0 && value >= 0 && value <= 17) {
         convnet_set_variant((int)value);
+        return AZ_OK;
+    }
+    if (std::strcmp(key, "print_clock_stamps") == 0) {
+        // diagnostic (gemm_variant 13): median in-kernel clock of conv2's K loop for model `value`
+        auto it = e->nets.find((int)value);
+        std::vector<unsigned long long> st(2048);
+        if (it == e->nets.end() || !it->second.conv || !convnet_read_clock_stamps(it->second.conv, st.data()))
+            return fail(e, AZ_ERR_BAD_ARGUMENT, "no conv net under that model id");
+        std::vector<double> mhz;
+        for (int i = 0; i < 1024; ++i) if (st[2 * i + 1]) mhz.push_back(100.0 * (double)st[2 * i] / (double)st[2 * i + 1]);
+        std::sort(mhz.begin(), mhz.end());
+        if (mhz.empty()) return fail(e, AZ_ERR_BAD_ARGUMENT, "no stamps (run a forward with gemm_variant 13 first)");
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "clock MHz min %.0f median %.0f max %.0f over %zu blocks", mhz.front(), mhz[mhz.size() / 2], mhz.back(), mhz.size());
+        e->err = buf;       // returned through az_last_error
         return AZ_OK;
     }
     if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {
@@ -599,8 +614,7 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
     const int C = (p->concurrent <= 0 || p->concurrent > n_games) ? n_games : p->concurrent;
     if (C > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: at most 65536 concurrent games");
     const int nsym = p->symmetries ? 2 : 1;
-    if (out->capacity < (int64_t)n_games * AZ_MAX_PLIES * nsym && out->capacity < 0)
-        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: negative capacity");
+    if (out->capacity < 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: negative capacity");
     NetModel* net;
     az_status st = find_net(e, p->model_id, &net);
     if (st) return st;

@@ -32,6 +32,8 @@ void convnet_resolve_profile(ConvNet* n, NetProfile* prof);
 // If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
 // kernel-variant switch for A/B measurements (0 = 128x128 tiles everywhere, 1 = default)
 void convnet_set_variant(int v);
+// diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop
+bool convnet_read_clock_stamps(ConvNet* n, unsigned long long* out2048);
 void convnet_set_conv4_big(int v);
 void convnet_forward(ConvNet* n, const EvalBatch& eb, int n_rows_hint, hipStream_t s, NetProfile* prof);
 

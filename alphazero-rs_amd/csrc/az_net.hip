@@ -119,6 +119,7 @@ struct GemmDesc {
     int cin;                // channels per tap
     int K, N;
     int relu;
+    unsigned long long* dbg;   // diagnostic builds only (ABLATE == 3): per-block {shader cycles, 100 MHz ticks}
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -298,15 +299,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     AZ_DMA(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    unsigned long long st0 = 0, sr0 = 0;
+    if constexpr (ABLATE == 3) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     // LDS byte offsets of this lane's fragment rows (row-major 128-B rows, XOR-swizzled 16-B slots)
     const int a_row0 = (wr * 128 + frow) * 128, b_row0 = 32768 + (wc * 64 + frow) * 128;
     const int coff0 = ((0 + fq) ^ fsw) << 4, coff1 = ((4 + fq) ^ fsw) << 4;
 #define AZ_LDA(dst_, base_, mt0_, coff_)                                                     \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
-        dst_[i_] = *(const bf16x8*)((base_) + a_row0 + ((mt0_) + i_) * 2048 + (coff_));
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
+        if constexpr (ABLATE == 4 || ABLATE == 5) { asm volatile("" : "+v"(dst_[i_])); }      \
+        else dst_[i_] = *(const bf16x8*)((base_) + a_row0 + ((mt0_) + i_) * 2048 + (coff_)); \
+    }
 #define AZ_LDB(dst_, base_, coff_)                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
-        dst_[i_] = *(const bf16x8*)((base_) + b_row0 + i_ * 2048 + (coff_));
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
+        if constexpr (ABLATE == 4 || ABLATE == 5) { asm volatile("" : "+v"(dst_[i_])); }      \
+        else dst_[i_] = *(const bf16x8*)((base_) + b_row0 + i_ * 2048 + (coff_));            \
+    }
 #define AZ_MMA(mt0_, fb_, fa_)                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
@@ -314,7 +321,22 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
             else acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0); \
         }
     for (int kt = 0; kt < nk; ++kt) {
-        if (ABLATE != 1 && !LATE_DMA && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
+        if (ABLATE != 1 && ABLATE != 4 && ABLATE != 5 && ABLATE != 7 && !LATE_DMA && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
+        if constexpr (ABLATE == 7) {
+            if (kt + 1 < nk) {      // same addresses and widths, destination = registers (no LDS write)
+                const int cb_ = (kt + 1) / ntaps, tap = (kt + 1) - cb_ * ntaps;
+                const int c0 = cb_ * GBK, kk = tap * d.cin + c0;
+                const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;
+                const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);
+                uint4 r0 = *(const uint4*)(d.A + a_off0 + toff), r1 = *(const uint4*)(d.A + a_off1 + toff),
+                      r2 = *(const uint4*)(d.A + a_off2 + toff), r3 = *(const uint4*)(d.A + a_off3 + toff),
+                      r4 = *(const uint4*)(d.W + b_off0 + kk), r5 = *(const uint4*)(d.W + b_off0 + b_step + kk),
+                      r6 = *(const uint4*)(d.W + b_off0 + 2 * b_step + kk), r7 = *(const uint4*)(d.W + b_off0 + 3 * b_step + kk);
+                asm volatile("" :: "v"(r0.x ^ r0.y ^ r0.z ^ r0.w), "v"(r1.x ^ r1.y ^ r1.z ^ r1.w), "v"(r2.x ^ r2.y ^ r2.z ^ r2.w),
+                             "v"(r3.x ^ r3.y ^ r3.z ^ r3.w), "v"(r4.x ^ r4.y ^ r4.z ^ r4.w), "v"(r5.x ^ r5.y ^ r5.z ^ r5.w),
+                             "v"(r6.x ^ r6.y ^ r6.z ^ r6.w), "v"(r7.x ^ r7.y ^ r7.z ^ r7.w));
+            }
+        }
         const unsigned char* sA = smem + (kt & 1) * 65536;
         if constexpr (PIPE == 0) {
             const unsigned char* sB = sA + 32768;
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
         } else {
             // 4 phases of 16 MFMAs; the fragments of phase p+1 are requested before the MFMAs of phase p issue,
             // so an LDS round trip is exposed once per K-step (after the barrier) instead of eight times.
-            bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+            bf16x8 fbX[4] = {}, fbY[4] = {}, faX[4] = {}, faY[4] = {};
             AZ_LDB(fbX, sA, coff0);
             AZ_LDA(faX, sA, 0, coff0);
             __builtin_amdgcn_sched_barrier(0);
@@ -357,12 +379,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
             __builtin_amdgcn_sched_barrier(0);
             AZ_MMA(4, fbY, faY);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (ABLATE != 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (ABLATE == 6) __builtin_amdgcn_s_barrier();
+        else if constexpr (ABLATE != 5) __syncthreads();
     }
 #undef AZ_LDA
 #undef AZ_LDB
 #undef AZ_MMA
+    if constexpr (ABLATE == 3) {
+        // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6);
+        // the stamps go to a debug buffer nothing else reads
+        const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && d.dbg && blockIdx.x < 1024) { d.dbg[2 * blockIdx.x] = st1 - st0; d.dbg[2 * blockIdx.x + 1] = sr1 - sr0; }
+    }
 #undef AZ_DMA
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -523,8 +552,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm256r(const GemmDesc d) {
 // K-step.  Same K order (channel block outer, tap inner) and per-row accumulation order as the other variants.
 constexpr int IMG_NB = 6, IMG_ROWS = IMG_NB * 42, IMG_ZERO_ROW = 252;
 
-template <int LAYER, int WBUF>   // WBUF = weight buffers in LDS: 2 (prefetch 1 K-step ahead) or 3 (2 ahead, all 160 KiB)
-__global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
+template <int LAYER, int WBUF, int MIDBAR = 0, int SPREAD = 0>   // WBUF = weight buffers in LDS: 2 (prefetch 1 K-step ahead) or 3 (2 ahead)
+__global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {   // MIDBAR: barrier before the last MFMA cluster; SPREAD: one DMA
+                                                                            // instruction per MFMA cluster instead of a burst at the K-step's start
     __shared__ __attribute__((aligned(16))) unsigned char smem[(2 + WBUF) * 32768];   // img[2] | w[WBUF]
     const int n_boards = (int)(*d.n_dev);
     const int M = n_boards * 42;
@@ -563,6 +593,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
         __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + (kk_)), (lds_ptr)(lb + 8192), 16, 0, 0);     \
         __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 2 * b_step + (kk_)), (lds_ptr)(lb + 16384), 16, 0, 0); \
         __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 3 * b_step + (kk_)), (lds_ptr)(lb + 24576), 16, 0, 0); \
+    }
+#define AZ_IDMA_W1(kk_, buf_, i_)                                                                            \
+    __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + (i_) * b_step + (kk_)),                        \
+                                     (lds_ptr)(smem + 65536 + (buf_) * 32768 + wave * 1024 + (i_) * 8192), 16, 0, 0);
+#define AZ_IDMA_IMG1(cb_, i_)                                                                                \
+    {                                                                                                        \
+        const uint32_t io_ = (i_) == 0 ? i_off0 : (i_) == 1 ? i_off1 : (i_) == 2 ? i_off2 : i_off3;           \
+        if ((i_) < 3 || i_row3)                                                                              \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + io_ + (uint32_t)((cb_) * 64)),                  \
+                                             (lds_ptr)(smem + ((cb_) & 1) * 32768 + wave * 1024 + (i_) * 8192), 16, 0, 0); \
     }
 #define AZ_IDMA_IMG(cb_)                                                                                     \
     {                                                                                                        \
@@ -605,10 +645,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
 #define AZ_ILDB(dst_, wb_, coff_)                                                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
         dst_[i_] = *(const bf16x8*)((wb_) + b_row0 + i_ * 2048 + (coff_));
-#define AZ_IMMA(mt0_, fb_, fa_)                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+#define AZ_IMMA_H(mt0_, fb_, fa_, h_)                                                                        \
+    _Pragma("unroll") for (int i_ = 2 * (h_); i_ < 2 * (h_) + 2; ++i_)                                       \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
             acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+    // one MFMA cluster (16) with, in SPREAD mode, DMA instruction #q_ of the next tiles between its halves
+#define AZ_IMMA(mt0_, fb_, fa_, q_)                                                                          \
+    {                                                                                                        \
+        AZ_IMMA_H(mt0_, fb_, fa_, 0);                                                                        \
+        if constexpr (SPREAD == 1) {                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            if (w_issue) AZ_IDMA_W1(kk_w, buf_w, q_);                                                        \
+            if (new_img) AZ_IDMA_IMG1(cb + 1, q_);                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+        AZ_IMMA_H(mt0_, fb_, fa_, 1);                                                                        \
+    }
     const int ncb = C / 64;
     const int nk = ncb * 9;
     AZ_IDMA_W(0, 0);
@@ -618,54 +670,92 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cb = 0, tap = 0;
+    bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+    if constexpr (MIDBAR == 1) {
+        const int dt = -8, tapbit = 16;                    // K-step 0 = (cb 0, tap 0)
+        AZ_ILDB(fbX, smem, coffB0);
+        AZ_ILDA(faX, smem, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const bool new_img = tap == 0 && cb + 1 < ncb;
         const bool w_issue = kt + (WBUF - 1) < nk;
-        if (w_issue) {
-            // weights of K-step kt + WBUF - 1
-            int ntap = tap + (WBUF - 1), ncbi = cb;
-            if (ntap >= 9) { ntap -= 9; ++ncbi; }
-            AZ_IDMA_W(ntap * C + ncbi * 64, (kt + WBUF - 1) % WBUF);
+        // weights of K-step kt + WBUF - 1
+        int ntap_w = tap + (WBUF - 1), ncb_w = cb;
+        if (ntap_w >= 9) { ntap_w -= 9; ++ncb_w; }
+        const int kk_w = ntap_w * C + ncb_w * 64, buf_w = (kt + WBUF - 1) % WBUF;
+        if constexpr (SPREAD == 0) {
+            if (w_issue) AZ_IDMA_W(kk_w, buf_w);
+            if (new_img) AZ_IDMA_IMG(cb + 1);   // issued after the weights: stays in flight over this step's wait
         }
-        if (new_img) AZ_IDMA_IMG(cb + 1);       // issued after the weights: stays in flight over this step's wait
         const unsigned char* sI = smem + (cb & 1) * 32768;
         const unsigned char* sW = smem + (kt % WBUF) * 32768;   // b_row0 already carries the 64 KiB image offset
         const int ky = tap / 3, kx = tap - ky * 3;
         const int dt = (ky - 1) * 7 + (kx - 1);
         const int tapbit = 16 + tap;
-        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
-        AZ_ILDB(fbX, sW, coffB0);
-        AZ_ILDA(faX, sI, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        // DMA instructions that may stay in flight over this K-step's wait.  Burst mode: those issued after the weights
+        // of kt+1.  SPREAD mode (WBUF == 3): exactly the ones issued during this K-step (weights of kt+2, next image).
+        const int younger = SPREAD ? (w_issue ? 4 : 0) + (new_img ? 4 : 0)
+                                   : (WBUF == 3 && w_issue ? 4 : 0) + (new_img ? 4 : 0) + (WBUF == 3 && tap == 1 && cb + 1 < ncb ? 4 : 0);
+        if constexpr (MIDBAR == 0) {
+            AZ_ILDB(fbX, sW, coffB0);
+            AZ_ILDA(faX, sI, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (MIDBAR: fbX / faX were requested under the previous K-step's last MFMA cluster, or by the prologue)
         AZ_ILDA(faY, sI, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(0, fbX, faX);
+        AZ_IMMA(0, fbX, faX, 0);
         __builtin_amdgcn_sched_barrier(0);
         AZ_ILDB(fbY, sW, coffB1);
         AZ_ILDA(faX, sI, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(4, fbX, faY);
+        AZ_IMMA(4, fbX, faY, 1);
         __builtin_amdgcn_sched_barrier(0);
         AZ_ILDA(faY, sI, 4, 1);
         __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(0, fbY, faX);
+        AZ_IMMA(0, fbY, faX, 2);
         __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(4, fbY, faY);
-        // counted wait: the weights of K-step kt+1 must have landed; anything issued after them may stay in flight
-        // (WBUF == 3: the weights of kt+2, and the next image when it was issued this step or the step before)
-        {
-            const int younger = (WBUF == 3 && w_issue ? 4 : 0) + (new_img ? 4 : 0) +
-                                (WBUF == 3 && tap == 1 && cb + 1 < ncb ? 4 : 0);
+        if constexpr (MIDBAR == 1) {
+            // every LDS read of this K-step has returned and this wave's DMA pieces of the next weight tile have
+            // landed: after the barrier the next tile is complete and this tile's buffers may be refilled
+            if (younger == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (younger == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                const int ntap2 = tap == 8 ? 0 : tap + 1, ncb2 = tap == 8 ? cb + 1 : cb;
+                const unsigned char* sI2 = smem + (ncb2 & 1) * 32768;
+                const unsigned char* sW2 = smem + ((kt + 1) % WBUF) * 32768;
+                const int ky2 = ntap2 / 3, kx2 = ntap2 - ky2 * 3;
+                {
+                    const int dt = (ky2 - 1) * 7 + (kx2 - 1);
+                    const int tapbit = 16 + ntap2;
+                    AZ_ILDB(fbX, sW2, coffB0);
+                    AZ_ILDA(faX, sI2, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            AZ_IMMA(4, fbY, faY, 3);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            AZ_IMMA(4, fbY, faY, 3);
+            // counted wait: the weights of K-step kt+1 must have landed; anything issued after them may stay in flight
+            // (WBUF == 3: the weights of kt+2, and the next image when it was issued this step or the step before)
             if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                    // raw: __syncthreads() would drain vmcnt to 0
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_barrier();                                    // raw: __syncthreads() would drain vmcnt to 0
-        __builtin_amdgcn_sched_barrier(0);
         if (++tap == 9) { tap = 0; ++cb; }
     }
 #undef AZ_IDMA_W
 #undef AZ_IDMA_IMG
+#undef AZ_IDMA_W1
+#undef AZ_IDMA_IMG1
+#undef AZ_IMMA_H
 #undef AZ_ILDA
 #undef AZ_ILDB
 #undef AZ_IMMA
@@ -772,6 +862,7 @@ struct ConvNet {
     std::vector<hipEvent_t> ev_pool;
     uint32_t* pinned_n = nullptr;
     int pinned_cap = 0, pinned_next = 0;
+    unsigned long long* dbg = nullptr;     // [2048] clock stamps of the diagnostic variant
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr;
         if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
@@ -807,6 +898,8 @@ ConvNet* convnet_create(int channels, int max_batch, const char** err) {
     ok &= (n->fc1o = n->dalloc<uint16_t>(B * 1024)) != nullptr;
     ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
     if (ok) ok = hipMemset(n->act1, 0, B * 72 * C * sizeof(uint16_t)) == hipSuccess;   // the zero halo
+    ok &= (n->dbg = n->dalloc<unsigned long long>(2048)) != nullptr;
+    if (ok) ok = hipMemset(n->dbg, 0, 2048 * 8) == hipSuccess;
     if (ok) ok = hipHostMalloc((void**)&n->pinned_n, 4096 * sizeof(uint32_t)) == hipSuccess;
     n->pinned_cap = 4096;
     if (!ok) {
@@ -918,18 +1011,23 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
     convnet_set_params(net, p.data(), L.total);
 }
 
-int g_gemm_variant = 5;   // 0: 128x128 tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3; 2: + phased fragment
-                          // prefetch; 3: 4-stage ring; 4: XCD column remap; 5 (default): conv2 image-resident + conv3 as 2;
-                          // 6: 5 with three weight buffers; 7: late DMA; 11/12: timing ablations (wrong results)
+int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); every non-ablation variant is bit-identical:
+                          // 0: 128x128 register-staged tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3;
+                          // 2: + hand-phased fragment prefetch; 3: 4-stage ring of 32-deep stages; 4: XCD column remap;
+                          // 5 (default): conv2 image-resident (k_conv_img) + conv3 as 2; 6: 5 + third weight buffer;
+                          // 7: late DMA issue; 8: 5 + barrier before the last MFMA cluster; 9: 6 + DMA spread over the
+                          // clusters; 11-17: timing ablations / clock stamps (WRONG results, tools/ only)
 
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
 
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
-    if ((g_gemm_variant == 5 || g_gemm_variant == 6) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
+    if ((g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
         const int t8 = (tiles + 7) / 8 * 8;
         if (g_gemm_variant == 5) hipLaunchKernelGGL((k_conv_img<LAYER, 2>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 8) hipLaunchKernelGGL((k_conv_img<LAYER, 2, 1>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 9) hipLaunchKernelGGL((k_conv_img<LAYER, 3, 0, 1>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else hipLaunchKernelGGL((k_conv_img<LAYER, 3>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
@@ -938,9 +1036,14 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
         if (g_gemm_variant == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 7) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 4) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 16) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 6>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 17) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 7>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 14) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 4>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 15) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 5>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 13) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 3>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 11) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 12) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 2>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else hipLaunchKernelGGL((k_gemm256r<LAYER>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
@@ -982,6 +1085,9 @@ void convnet_resolve_profile(ConvNet* n, NetProfile* prof) {
 }
 
 void convnet_set_variant(int v) { g_gemm_variant = v; }
+bool convnet_read_clock_stamps(ConvNet* n, unsigned long long* out2048) {
+    return n && hipMemcpy(out2048, n->dbg, 2048 * 8, hipMemcpyDeviceToHost) == hipSuccess;
+}
 void convnet_set_conv4_big(int v) { g_conv4_big = v; }
 
 void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t s, NetProfile* prof) {
@@ -1003,6 +1109,7 @@ void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t
     GemmDesc d{};
     d.n_dev = eb.n;
     d.relu = 1;
+    d.dbg = n->dbg;
     // conv2: 3x3 same over the haloed [8][9][C] image -> [6][7][C]
     d.A = n->act1; d.W = n->wg[0]; d.bias = n->bg[0]; d.out = n->act2;
     d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;

@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--force-dist", action="store_true", help="init the process group and run the gather even at world size 1 (rehearsal)")
     args = ap.parse_args()
     episodes = args.episodes or 4 * args.games
 
@@ -125,8 +126,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from alphazero_rs_amd import engine as azeng
@@ -144,7 +149,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,9 +158,11 @@ def main():
         r = e.selfplay(n_games=episodes, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
                        first_game_id=first, symmetries=False, want_boards=False, out=out)
         n = r["count"]
-        if world > 1:
+        if use_dist:
             packed = azdist.pack_samples(out["states"][:n], out["pis"][:n], out["zs"][:n])
-            azdist.gather_samples(packed, dst=0)
+            gathered, counts = azdist.gather_samples(packed, dst=0)
+            if rank == 0 and int(counts.sum()) != gathered.shape[0]:
+                raise RuntimeError("gather_samples: count mismatch")
         return n, int(r["game_len"].sum())
 
     for i in range(args.warmup):
@@ -171,7 +178,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = e.stats()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -236,7 +243,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     e.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -89,6 +89,7 @@ typedef struct az_stats {
 
 /* ---- lifecycle ---------------------------------------------------------- */
 az_status az_create(const az_config* cfg, az_engine** out);
+/* Destroy every az_tree of the engine first: a tree borrows the engine's stream. */
 void az_destroy(az_engine* e);
 const char* az_last_error(const az_engine* e);
 /* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
