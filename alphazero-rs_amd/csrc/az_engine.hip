@@ -174,11 +174,11 @@ az_status fail_hip(az_engine* e, const HipFail& f) {
     return fail(e, AZ_ERR_HIP, buf);
 }
 
-void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int rows_hint) {
+void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int rows_hint, hipStream_t s) {
     if (net.kind == AZ_NET_CONV) {
-        convnet_forward(net.conv, eb, rows_hint, e->stream, e->prof.on ? &e->netprof : nullptr);
+        convnet_forward(net.conv, eb, rows_hint, s, e->prof.on ? &e->netprof : nullptr);
     } else {
-        launch_net_fixture(eb, net.kind, net.salt, e->stream);
+        launch_net_fixture(eb, net.kind, net.salt, s);
     }
 }
 
@@ -186,12 +186,12 @@ void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int row
 // {select+expand, compact, predict, mask+store+backup}  (src/async_mcts.rs:81-82, :191-217).
 // rows_hint = host-side upper bound on the leaf batch (trees still searching): sizes the net's grids and picks tiles
 void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int num_sims, SearchParams sp,
-                const NetModel& net, int rows_hint) {
-    hipStream_t s = e->stream;
+                const NetModel& net, int rows_hint, hipStream_t s = nullptr) {
+    if (!s) s = e->stream;
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
     launch_root_prepare(th.d, d_root_states, s);
     launch_compact(th.d, th.eb, s);
-    net_forward(e, net, th.eb, rows_hint);
+    net_forward(e, net, th.eb, rows_hint, s);
     launch_backup(th.d, th.eb, 1, s);
     for (int i = 0; i < num_sims; ++i) {
         hipEvent_t t0 = nullptr;
@@ -200,7 +200,7 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
         if (e->prof.on) e->prof.end(t0, RG_TREE, s);
         launch_compact(th.d, th.eb, s);
         if (e->prof.on) t0 = e->prof.begin(s);
-        net_forward(e, net, th.eb, rows_hint);
+        net_forward(e, net, th.eb, rows_hint, s);
         if (e->prof.on) { e->prof.end(t0, RG_NET, s); t0 = e->prof.begin(s); }
         launch_backup(th.d, th.eb, 0, s);
         if (e->prof.on) e->prof.end(t0, RG_TREE, s);
@@ -468,7 +468,7 @@ az_status az_net_predict_states(az_engine* e, int32_t model_id, const uint64_t* 
             uint32_t nb = (uint32_t)std::min(chunk, B - b0);
             HIPCHK(hipMemcpyAsync(eb.n, &nb, sizeof nb, hipMemcpyHostToDevice, e->stream));
             HIPCHK(hipMemcpyAsync(eb.state, states + 2 * (size_t)b0, (size_t)nb * 16, hipMemcpyDefault, e->stream));
-            net_forward(e, *m, eb, (int)nb);
+            net_forward(e, *m, eb, (int)nb, e->stream);
             HIPCHK(hipMemcpyAsync(hp.data(), eb.pi, (size_t)nb * 8 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             std::vector<float> packed((size_t)nb * 7);
@@ -534,6 +534,23 @@ void az_tree_destroy(az_tree* t) {
     (void)hipSetDevice(t->e->device);
     (void)hipStreamSynchronize(t->e->stream);
     delete t;
+}
+
+az_status az_tree_reset(az_tree* t, const uint64_t* root_states) {
+    if (!t) return AZ_ERR_BAD_ARGUMENT;
+    az_engine* e = t->e;
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        const ulonglong2* roots = nullptr;
+        if (root_states) {
+            HIPCHK(hipMemcpyAsync(t->d_root_states, root_states, (size_t)t->th.d.G * 16, hipMemcpyDefault, e->stream));
+            roots = t->d_root_states;
+        }
+        launch_reset_trees(t->th.d, nullptr, e->stream, roots);
+        HIPCHK(hipMemsetAsync(t->th.d.stat, 0, (size_t)t->th.d.G * ST_COUNT * sizeof(uint64_t), e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
 }
 
 az_status az_tree_record_evals(az_tree* t, int32_t cap) {
@@ -796,10 +813,31 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         launch_reset_trees(to.d, nullptr, s);
         SearchParams sp{(uint32_t)p->max_depth, (float)p->cpuct};
         az_status result = AZ_OK;
+        // The two searches of a ply touch disjoint trees and (for two different models) disjoint net workspaces:
+        // run the old model's on a second stream so its half batches overlap the new model's.
+        struct Side {
+            hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr;
+            ~Side() { if (s2) (void)hipStreamDestroy(s2); if (fork) (void)hipEventDestroy(fork); if (join) (void)hipEventDestroy(join); }
+        } side;
+        const bool overlap = net_new != net_old && !(net_new->conv && net_new->conv == net_old->conv);
+        if (overlap) {
+            HIPCHK(hipStreamCreate(&side.s2));
+            HIPCHK(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&side.join, hipEventDisableTiming));
+        }
         for (int ply = 0; ply <= AZ_MAX_PLIES; ++ply) {
             launch_arena_sync(tn.d, to.d, ad, s);
-            run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0]);
-            run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0]);
+            if (overlap) {
+                HIPCHK(hipEventRecord(side.fork, s));
+                HIPCHK(hipStreamWaitEvent(side.s2, side.fork, 0));
+                run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0], side.s2);
+                run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0], s);
+                HIPCHK(hipEventRecord(side.join, side.s2));
+                HIPCHK(hipStreamWaitEvent(s, side.join, 0));
+            } else {
+                run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0]);
+                run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0]);
+            }
             launch_arena_move(tn.d, ad, p->seed, s);
             launch_arena_move(to.d, ad, p->seed, s);
             HIPCHK(hipMemcpyAsync(ctr, ad.counters, sizeof ctr, hipMemcpyDeviceToHost, s));

@@ -12,6 +12,7 @@
 // bitboards directly (to_features fused, connect_four_game.rs:219-237) on the VALU.
 #include "az_net.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -63,43 +64,45 @@ AZ_D uint32_t pack_bf16x2(float lo, float hi) {
 __global__ __launch_bounds__(256) void k_conv1(const EvalBatch eb, const float* __restrict__ w /*[18][C]*/,
                                                const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out, int C) {
     const int cg = C / 8;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(*eb.n) * 42 * cg;
-    if (tid >= total) return;
-    const int c8 = (int)(tid % cg);
-    const int pos = (int)((tid / cg) % 42);
-    const size_t b = tid / ((size_t)cg * 42);
-    const int y = pos / 7, x = pos % 7;
-    const ulonglong2 s = eb.state[b];
-    float acc[8];
+    // grid-stride: a wave keeps its 8-channel group (c8) and walks positions, so its weight rows stay in registers'
+    // reach (L1) and the block count stays at a few per CU instead of one block per 4 positions
+    for (size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(tid % cg);
+        const int pos = (int)((tid / cg) % 42);
+        const size_t b = tid / ((size_t)cg * 42);
+        const int y = pos / 7, x = pos % 7;
+        const ulonglong2 s = eb.state[b];
+        float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int iy = y + ky - 1, ix = x + kx - 1;
-            if (iy < 0 || iy >= 6 || ix < 0 || ix >= 7) continue;
-            const uint64_t bit = 1ull << (ix * 7 + (5 - iy));
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = x + kx - 1;
+                if (iy < 0 || iy >= 6 || ix < 0 || ix >= 7) continue;
+                const uint64_t bit = 1ull << (ix * 7 + (5 - iy));
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-                if (!((ci == 0 ? s.x : s.y) & bit)) continue;
-                const float4* wp = (const float4*)(w + (size_t)((ky * 3 + kx) * 2 + ci) * C + c8 * 8);
-                float4 w0 = wp[0], w1 = wp[1];
-                acc[0] += w0.x; acc[1] += w0.y; acc[2] += w0.z; acc[3] += w0.w;
-                acc[4] += w1.x; acc[5] += w1.y; acc[6] += w1.z; acc[7] += w1.w;
+                for (int ci = 0; ci < 2; ++ci) {
+                    if (!((ci == 0 ? s.x : s.y) & bit)) continue;
+                    const float4* wp = (const float4*)(w + (size_t)((ky * 3 + kx) * 2 + ci) * C + c8 * 8);
+                    float4 w0 = wp[0], w1 = wp[1];
+                    acc[0] += w0.x; acc[1] += w0.y; acc[2] += w0.z; acc[3] += w0.w;
+                    acc[4] += w1.x; acc[5] += w1.y; acc[6] += w1.z; acc[7] += w1.w;
+                }
             }
-        }
-    const float4* bp = (const float4*)(bias + c8 * 8);
-    float4 b0 = bp[0], b1 = bp[1];
-    float r[8] = {acc[0] + b0.x, acc[1] + b0.y, acc[2] + b0.z, acc[3] + b0.w,
-                  acc[4] + b1.x, acc[5] + b1.y, acc[6] + b1.z, acc[7] + b1.w};
-    uint4 o;
-    o.x = pack_bf16x2(fmaxf(r[0], 0.0f), fmaxf(r[1], 0.0f));
-    o.y = pack_bf16x2(fmaxf(r[2], 0.0f), fmaxf(r[3], 0.0f));
-    o.z = pack_bf16x2(fmaxf(r[4], 0.0f), fmaxf(r[5], 0.0f));
-    o.w = pack_bf16x2(fmaxf(r[6], 0.0f), fmaxf(r[7], 0.0f));
-    *(uint4*)(out + (((b * 8 + (y + 1)) * 9 + (x + 1)) * (size_t)C + c8 * 8)) = o;
+        const float4* bp = (const float4*)(bias + c8 * 8);
+        float4 b0 = bp[0], b1 = bp[1];
+        float r[8] = {acc[0] + b0.x, acc[1] + b0.y, acc[2] + b0.z, acc[3] + b0.w,
+                      acc[4] + b1.x, acc[5] + b1.y, acc[6] + b1.z, acc[7] + b1.w};
+        uint4 o;
+        o.x = pack_bf16x2(fmaxf(r[0], 0.0f), fmaxf(r[1], 0.0f));
+        o.y = pack_bf16x2(fmaxf(r[2], 0.0f), fmaxf(r[3], 0.0f));
+        o.z = pack_bf16x2(fmaxf(r[4], 0.0f), fmaxf(r[5], 0.0f));
+        o.w = pack_bf16x2(fmaxf(r[6], 0.0f), fmaxf(r[7], 0.0f));
+        *(uint4*)(out + (((b * 8 + (y + 1)) * 9 + (x + 1)) * (size_t)C + c8 * 8)) = o;
+    }
 }
 
 // ---- implicit GEMM on MFMA: out[M,N] = relu(A_gather[M,K] * W[N,K]^T + bias) ---------------------------
@@ -410,6 +413,131 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
             *(uint2*)(d.out + (size_t)m * d.N + n) = o;
         }
     }
+}
+
+// ---- 256x256 tile with the 32x32x16 MFMA shape ("wide" variant) ---------------------------------------------
+// Same tile, waves and LDS-DMA staging as k_gemm256<PIPE=1>, but v_mfma_f32_32x32x16_bf16: half as many MFMA
+// instructions (32 per wave per K-step), each holding the SIMD's vector issue port for 8 of its 32 cycles instead
+// of 8 of 16, which leaves more issue slots for the DMA / LDS / address instructions of the two waves sharing a SIMD.
+// Fragment rows are 32 consecutive tile rows per instruction, so the swizzle is slot = chunk ^ ((row>>1)&7).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int LAYER>
+__global__ __launch_bounds__(512, 2) void k_gemm256w(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
+    const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int ntaps = d.K / d.cin;
+    const int NT = d.N / HBN_;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // DMA map: instruction q of wave w fills tile rows (q*8+w)*8 .. +7; lane -> row (lane>>3), slot (lane&7);
+    // LDS row R slot S holds chunk S ^ ((R>>1)&7), and (R>>1)&7 = ((w&1)*4 + (lrow>>1)) & 7
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ (((wave & 1) * 4 + (lrow >> 1)) & 7);
+    auto row_off = [&](int q) -> uint32_t {
+        int m = m0 + (q * 8 + wave) * 8 + lrow;
+        m = m < M ? m : M - 1;
+        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
+        const int y = r / d.out_w, x = r - y * d.out_w;
+        return (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
+    };
+    const uint32_t a_off0 = row_off(0), a_off1 = row_off(1), a_off2 = row_off(2), a_off3 = row_off(3);
+    const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
+    const uint32_t b_step = 64u * (uint32_t)d.K;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define AZ_WDMA(kt_, buf_)                                                                              \
+    {                                                                                                   \
+        const int cb_ = (kt_) / ntaps, tap = (kt_) - cb_ * ntaps;                                       \
+        const int c0 = cb_ * GBK, kk = tap * d.cin + c0;                                                \
+        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                          \
+        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                             \
+        unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
+        unsigned char* lb = la + 32768;                                                                 \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off0 + toff), (lds_ptr)(la), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off1 + toff), (lds_ptr)(la + 8192), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off2 + toff), (lds_ptr)(la + 16384), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off3 + toff), (lds_ptr)(la + 24576), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + kk), (lds_ptr)(lb), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + kk), (lds_ptr)(lb + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 2 * b_step + kk), (lds_ptr)(lb + 16384), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 3 * b_step + kk), (lds_ptr)(lb + 24576), 16, 0, 0); \
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+    const int nk = d.K / GBK;
+    const int frow = lane & 31, fh = lane >> 5, fsw = (lane >> 1) & 7;
+    const int a_row0 = (wr * 128 + frow) * 128, b_row0 = 32768 + (wc * 64 + frow) * 128;
+    // fragments of 16-deep k-step s_: chunk 2*s_ + fh
+#define AZ_WLD(fa_, fw_, base_, s_)                                                                     \
+    {                                                                                                   \
+        const int co_ = ((2 * (s_) + fh) ^ fsw) << 4;                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) fw_[i_] = *(const bf16x8*)((base_) + b_row0 + i_ * 4096 + co_); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) fa_[i_] = *(const bf16x8*)((base_) + a_row0 + i_ * 4096 + co_); \
+    }
+#define AZ_WMMA(fa_, fw_)                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw_[j_], fa_[i_], acc[i_][j_], 0, 0, 0);
+    AZ_WDMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) AZ_WDMA(kt + 1, (kt + 1) & 1);
+        const unsigned char* sA = smem + (kt & 1) * 65536;
+        bf16x8 faX[4], fwX[2], faY[4], fwY[2];
+        AZ_WLD(faX, fwX, sA, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_WLD(faY, fwY, sA, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_WMMA(faX, fwX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_WLD(faX, fwX, sA, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_WMMA(faY, fwY);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_WLD(faY, fwY, sA, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_WMMA(faX, fwX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_WMMA(faY, fwY);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef AZ_WDMA
+#undef AZ_WLD
+#undef AZ_WMMA
+    // D[n][m]: lane holds m = lane&31, n = 8*g + 4*(lane>>5) + (reg&3) for reg group g = reg>>2
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wc * 64 + nt * 32 + 8 * g + 4 * fh;
+            const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wr * 128 + mt * 32 + frow;
+                if (m >= M) continue;
+                float r0 = acc[mt][nt][4 * g + 0] + bv.x, r1 = acc[mt][nt][4 * g + 1] + bv.y,
+                      r2 = acc[mt][nt][4 * g + 2] + bv.z, r3 = acc[mt][nt][4 * g + 3] + bv.w;
+                if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+                uint2 o;
+                o.x = pack_bf16x2(r0, r1);
+                o.y = pack_bf16x2(r2, r3);
+                *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+            }
+        }
 }
 
 // ---- 256x256 tile, 4-stage LDS ring of 32-deep K stages ("ring" variant) ------------------------------------
@@ -1016,7 +1144,8 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); every no
                           // 2: + hand-phased fragment prefetch; 3: 4-stage ring of 32-deep stages; 4: XCD column remap;
                           // 5 (default): conv2 image-resident (k_conv_img) + conv3 as 2; 6: 5 + third weight buffer;
                           // 7: late DMA issue; 8: 5 + barrier before the last MFMA cluster; 9: 6 + DMA spread over the
-                          // clusters; 11-17: timing ablations / clock stamps (WRONG results, tools/ only)
+                          // clusters; 10: 2 with the 32x32x16 MFMA shape (1067 TFLOP/s: rejected);
+                          // 11-17: timing ablations / clock stamps (WRONG results, tools/ only)
 
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
 
@@ -1039,6 +1168,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
         else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 7) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 4) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 10) hipLaunchKernelGGL((k_gemm256w<LAYER>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 16) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 6>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 17) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 7>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 14) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 4>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
@@ -1104,7 +1234,8 @@ void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t
     }
     {
         const size_t threads = (size_t)rows_hint * 42 * (C / 8);
-        hipLaunchKernelGGL(k_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, eb, n->w1, n->b1, n->act1, C);
+        const size_t blocks = std::min<size_t>((threads + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(k_conv1, dim3((unsigned)blocks), dim3(256), 0, s, eb, n->w1, n->b1, n->act1, C);
     }
     GemmDesc d{};
     d.n_dev = eb.n;

@@ -97,7 +97,8 @@ struct ArenaDev {
 };
 
 // ---- launchers (all asynchronous on `s`) --------------------------------------
-void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s);
+void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s,
+                        const ulonglong2* roots = nullptr /*[G] root states, nullptr = initial board*/);
 void launch_root_prepare(const TreeDev& t, const ulonglong2* root_states, hipStream_t s);
 void launch_select(const TreeDev& t, SearchParams sp, hipStream_t s);
 void launch_compact(const TreeDev& t, const EvalBatch& eb, hipStream_t s);

@@ -96,7 +96,8 @@ AZ_D bool node_upgrade(const TreeDev& t, int g, size_t base, uint32_t slot, uint
 }
 
 // ---- NodeStore::new (src/node.rs:156-166): clear `seen`, push + upgrade the initial board ----
-__global__ __launch_bounds__(256) void k_reset_trees(TreeDev t, const uint8_t* flags, uint8_t* clear_flags) {
+__global__ __launch_bounds__(256) void k_reset_trees(TreeDev t, const uint8_t* flags, uint8_t* clear_flags,
+                                                     const ulonglong2* roots /*nullptr = initial board*/) {
     int g = blockIdx.x;
     if (flags && !flags[g]) return;
     uint32_t* tab = t.hash + (size_t)g * t.H;
@@ -106,8 +107,9 @@ __global__ __launch_bounds__(256) void k_reset_trees(TreeDev t, const uint8_t* f
         int sub = threadIdx.x;
         size_t base = (size_t)g * t.R;
         uint32_t ec;
-        uint32_t ins = c4_hash(0, 0) & (t.H - 1);
-        node_upgrade(t, g, base, 0u, 0ull, 0ull, 0u, 0u, ins, CTR_INIT, 1u, sub, &ec);
+        const ulonglong2 rs = roots ? roots[g] : make_ulonglong2(0ull, 0ull);     // NodeStore::from_root, src/node.rs:168-177
+        uint32_t ins = c4_hash(rs.x, rs.y) & (t.H - 1);
+        node_upgrade(t, g, base, 0u, rs.x, rs.y, 0u, 0u, ins, CTR_INIT, 1u, sub, &ec);
         if (sub == 0) {
             t.root[g] = 0;
             t.log_len[g] = 0;
@@ -585,8 +587,8 @@ __global__ void k_sync_active(TreeDev t, GamesDev gd) {
 // ---- launchers --------------------------------------------------------------------------------
 static inline int group_blocks(int G) { return (G * LANES + 63) / 64; }
 
-void launch_reset_trees(const TreeDev& t, const uint8_t* flags, hipStream_t s) {
-    hipLaunchKernelGGL(k_reset_trees, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags));
+void launch_reset_trees(const TreeDev& t, const uint8_t* flags, hipStream_t s, const ulonglong2* roots) {
+    hipLaunchKernelGGL(k_reset_trees, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags), roots);
 }
 void launch_root_prepare(const TreeDev& t, const ulonglong2* root_states, hipStream_t s) {
     hipLaunchKernelGGL(k_root_prepare, dim3(group_blocks(t.G)), dim3(64), 0, s, t, root_states);

@@ -68,7 +68,7 @@ EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_set_option", "az_get_stats", "az_reset_stats", "az_net_set_kind",
     "az_net_init_random", "az_net_load", "az_net_save", "az_net_param_count", "az_net_set_params",
     "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_tree_create",
-    "az_tree_destroy", "az_tree_get_action_prob", "az_tree_record_evals", "az_tree_get_evals",
+    "az_tree_destroy", "az_tree_reset", "az_tree_get_action_prob", "az_tree_record_evals", "az_tree_get_evals",
     "az_tree_node_counts", "az_selfplay", "az_selfplay_get_evals", "az_arena",
 ]
 
@@ -99,6 +99,7 @@ def load_library(path=LIB_PATH):
         "az_net_train": (i32, [vp, i32, i32, vp, vp, vp, i64]),
         "az_tree_create": (i32, [vp, i32, u64, i32, i32, i32, i32, C.POINTER(vp)]),
         "az_tree_destroy": (None, [vp]),
+        "az_tree_reset": (i32, [vp, vp]),
         "az_tree_get_action_prob": (i32, [vp, vp, f32, u64, u64, vp, vp, vp]),
         "az_tree_record_evals": (i32, [vp, i32]),
         "az_tree_get_evals": (i32, [vp, vp, vp, vp, vp]),
@@ -307,6 +308,11 @@ class TreeBatch:
         self.engine._check(_lib.az_tree_get_action_prob(self._h, _ptr(s), temp, seed, first_game_id, _ptr(pi),
                                                         _ptr(counts), _ptr(q)))
         return pi, counts, q
+
+    def reset(self, root_states=None):
+        """AsyncMcts::from_state: re-root every tree (None = the initial board)."""
+        s = None if root_states is None else np.ascontiguousarray(root_states, dtype=np.uint64).reshape(self.n_games, 2)
+        self.engine._check(_lib.az_tree_reset(self._h, _ptr(s)))
 
     def record_evals(self, cap):
         self.engine._check(_lib.az_tree_record_evals(self._h, cap))

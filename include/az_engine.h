@@ -128,6 +128,9 @@ az_status az_net_train(az_engine* e, int32_t prev_id, int32_t id, const float* b
 az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_t num_sims, int32_t max_depth,
                          int32_t model_id, int32_t cpuct, az_tree** out);
 void az_tree_destroy(az_tree* t);
+/* AsyncMcts::from_state(s, ..) (src/async_mcts.rs:50-72, NodeStore::from_root, src/node.rs:168-177): forget every
+ * tree of the batch and root tree g at root_states[g] (canonical bitboards [G,2]); NULL = the initial board. */
+az_status az_tree_reset(az_tree* t, const uint64_t* root_states);
 /* get_action_prob(&self, s, temp, episode_id, rng) for every tree at once (src/async_mcts.rs:74-115).
  * states [G,2]; outputs pi [G,7], counts [G,7] (child N), q [G,7] (child Q); counts/q may be NULL.
  * RNG (temp == 0 tie-break) = stream (seed, first_game_id + g, ply = stones on board). */

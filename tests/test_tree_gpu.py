@@ -278,3 +278,27 @@ def test_arena_full_size_properties(engine, engine_mod):
     # same games with the seats' owners renamed: game g of the swapped call is game (g + 2048) % 4096 of the first
     # only if the RNG stream were keyed on seats; it is keyed on the game index, so compare tallies statistically:
     assert int(wld2.sum()) == 4096
+
+
+def test_from_state_reset(engine, oracle):
+    """AsyncMcts::from_state (src/async_mcts.rs:50-72): trees rooted at an arbitrary position hold exactly the nodes the
+    oracle's from_root store holds, and search identically; reset(None) returns to the initial board."""
+    sims = 60
+    s = (0, 0)
+    for a in (3, 3, 2, 4, 1):
+        s = oracle.c4_play(s[0], s[1], a)
+    tb = engine.tree_create(3, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=1000, model_id=10, cpuct=1)
+    tb.get_action_prob(np.zeros((3, 2), np.uint64), 1.0)                 # dirty the trees first
+    tb.reset(np.array([s] * 3, dtype=np.uint64))
+    t = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), root=s)
+    assert int(tb.node_counts()[1]) == t.stats()["nodes"] == 1 + bin(oracle.c4_valid_mask(*s)).count("1")
+    pi, counts, q = tb.get_action_prob(np.array([s] * 3, dtype=np.uint64), 1.0, seed=2)
+    opi, ocnt, oq = t.get_action_prob(s[0], s[1], 1.0, seed=2)
+    assert np.array_equal(counts[2], ocnt) and np.array_equal(pi[0], opi) and np.array_equal(q[1], oq)
+    assert int(tb.node_counts()[0]) == t.stats()["nodes"]
+    tb.reset(None)
+    assert int(tb.node_counts()[0]) == 8
+    t0 = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10))
+    pi, counts, q = tb.get_action_prob(np.zeros((3, 2), np.uint64), 1.0, seed=2)
+    opi, ocnt, oq = t0.get_action_prob(0, 0, 1.0, seed=2)
+    assert np.array_equal(counts[0], ocnt) and np.array_equal(pi[2], opi)
