@@ -302,3 +302,40 @@ def test_from_state_reset(engine, oracle):
     pi, counts, q = tb.get_action_prob(np.zeros((3, 2), np.uint64), 1.0, seed=2)
     opi, ocnt, oq = t0.get_action_prob(0, 0, 1.0, seed=2)
     assert np.array_equal(counts[0], ocnt) and np.array_equal(pi[2], opi)
+
+
+@pytest.mark.parametrize("cpuct,max_depth", [(2, 1000), (5, 1000), (1, 2), (3, 0)])
+def test_cpuct_and_max_depth(engine, oracle, cpuct, max_depth):
+    """C6: cpuct is an i32 multiplied in f32 inside the PUCT term; B10: depth > max_depth returns eval_heuristic() = 0
+    un-negated (src/async_mcts.rs:241-244) -- with max_depth 0/2 most simulations take that exit."""
+    sims, G = 80, 6
+    tb = engine.tree_create(G, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=max_depth, model_id=10, cpuct=cpuct)
+    trees = [oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), cpuct=cpuct, max_depth=max_depth) for _ in range(G)]
+    states = [(0, 0)] * G
+    rng = np.random.default_rng(cpuct * 100 + max_depth)
+    for move in range(8):
+        pi, counts, q = tb.get_action_prob(np.array(states, dtype=np.uint64), 1.0, seed=6)
+        for g in range(G):
+            opi, ocnt, oq = trees[g].get_action_prob(states[g][0], states[g][1], 1.0, seed=6, game_id=g)
+            assert np.array_equal(counts[g], ocnt), (move, g)
+            assert np.array_equal(pi[g], opi) and np.array_equal(q[g], oq)
+        for g, s in enumerate(states):
+            nxt = oracle.c4_play(s[0], s[1], int(rng.choice([a for a in range(7) if pi[g][a] > 0])))
+            if oracle.c4_ended(*nxt) == 0.0:          # a finished game keeps searching its last position
+                states[g] = nxt
+    assert [int(x) for x in tb.node_counts()] == [t.stats()["nodes"] for t in trees]
+
+
+@pytest.mark.parametrize("temp", [0.5, 2.0, 0.25])
+def test_fractional_temperature(engine, oracle, temp):
+    """S6 (A7): pi = counts^(1/temp) / sum with f32 powf.  Visit counts are bit-exact; pi goes through powf on both
+    sides (libm vs the device library), so the bar is the north-star tolerance 1e-5 (the reference itself only ever
+    uses temp 0 and 1, src/coach.rs:122-126)."""
+    sims, G = 100, 4
+    tb = engine.tree_create(G, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=1000, model_id=10, cpuct=1)
+    pi, counts, q = tb.get_action_prob(np.zeros((G, 2), np.uint64), temp, seed=1)
+    t = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10))
+    opi, ocnt, oq = t.get_action_prob(0, 0, temp, seed=1)
+    for g in range(G):
+        assert np.array_equal(counts[g], ocnt) and np.array_equal(q[g], oq)
+        assert np.abs(pi[g] - opi).max() <= 1e-5 and abs(float(pi[g].sum()) - 1.0) < 1e-5
