@@ -165,3 +165,54 @@ def test_states_to_boards(mods, oracle):
     b = coach.states_to_boards(np.array(sts, dtype=np.uint64))
     for i, st in enumerate(sts):
         assert np.array_equal(b[i], oracle.c4_features(*st))
+
+
+# ---- Coach::learn on two ranks (gloo): episodes shard by global game id, tuples all-gathered, gradients all-reduced ----
+def _coach_rank(rank, world, port, tmp, q):
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from alphazero_rs_amd import coach, trainer
+    from oracle import oracle_py as orc
+    from test_coach_cpu import make_coach
+    c, eng, _ = make_coach(coach, trainer, orc, os.path.join(tmp, f"rank{rank}"), iters=1)
+    rep = c.learn(seed=4)
+    q.put((rank, rep[0]["samples"], c.history[0][0].copy(), c.history[0][1].copy(), c.history[0][2].copy(), eng.params[1].copy(),
+           [x for x in eng.calls if x[0] == "selfplay"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coach_two_ranks_match_single_process(mods, oracle, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    coach, trainer = mods
+    torch.set_num_threads(1)
+    c, eng, _ = make_coach(coach, trainer, oracle, os.path.join(tmp_path, "single"), iters=1)
+    rep = c.learn(seed=4)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_coach_rank, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, n, boards, pis, vs, params, calls in got:
+        # every rank ends with the full, identically ordered sample set (rank order == global game-id order)
+        assert n == rep[0]["samples"]
+        assert np.array_equal(boards, c.history[0][0]) and np.array_equal(pis, c.history[0][1]) and np.array_equal(vs, c.history[0][2])
+        # identical data + identical batches + averaged gradients -> the same weights as one process
+        assert np.allclose(params, eng.params[1], atol=1e-5)
+    # the 5 episodes were sharded 3 + 2 by global id
+    assert got[0][6] == [("selfplay", 3, 0, 0)] and got[1][6] == [("selfplay", 2, 3, 0)]
