@@ -96,6 +96,7 @@ struct TreeHost {
         d.leaf = mem.alloc<uint32_t>(G);
         d.leaf_kind = mem.alloc<uint32_t>(G);
         d.leaf_val = mem.alloc<float>(G);
+        d.leaf_state = mem.alloc<ulonglong2>(G);
         d.slot_of = mem.alloc<int32_t>(G);
         d.err = mem.alloc<uint32_t>(ERR_COUNT);
         d.stat = mem.alloc<uint64_t>((size_t)G * ST_COUNT);

@@ -63,19 +63,22 @@ AZ_D uint32_t pack_bf16x2(float lo, float hi) {
 // One thread = one board position x 8 output channels (one 16-byte store).
 __global__ __launch_bounds__(256) void k_conv1(const EvalBatch eb, const float* __restrict__ w /*[18][C]*/,
                                                const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out, int C) {
+    // The folded weights (18 x C f32 = 36 KiB at C = 512) are staged in LDS once per block; blocks are persistent
+    // (grid-stride over (leaf, position, 8-channel group) items), so the tap loop reads LDS instead of L2.
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];        // [18][C] + [C] bias
+    for (int i = threadIdx.x; i < 18 * C / 4; i += blockDim.x) ((float4*)w_lds)[i] = ((const float4*)w)[i];
+    for (int i = threadIdx.x; i < C / 4; i += blockDim.x) ((float4*)(w_lds + 18 * C))[i] = ((const float4*)bias)[i];
+    __syncthreads();
     const int cg = C / 8;
     const size_t total = (size_t)(*eb.n) * 42 * cg;
-    // grid-stride: a wave keeps its 8-channel group (c8) and walks positions, so its weight rows stay in registers'
-    // reach (L1) and the block count stays at a few per CU instead of one block per 4 positions
     for (size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (size_t)gridDim.x * blockDim.x) {
         const int c8 = (int)(tid % cg);
         const int pos = (int)((tid / cg) % 42);
         const size_t b = tid / ((size_t)cg * 42);
         const int y = pos / 7, x = pos % 7;
         const ulonglong2 s = eb.state[b];
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        const float4* bp = (const float4*)(w_lds + 18 * C + c8 * 8);
+        float4 a0 = bp[0], a1 = bp[1];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -86,21 +89,17 @@ __global__ __launch_bounds__(256) void k_conv1(const EvalBatch eb, const float* 
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci) {
                     if (!((ci == 0 ? s.x : s.y) & bit)) continue;
-                    const float4* wp = (const float4*)(w + (size_t)((ky * 3 + kx) * 2 + ci) * C + c8 * 8);
-                    float4 w0 = wp[0], w1 = wp[1];
-                    acc[0] += w0.x; acc[1] += w0.y; acc[2] += w0.z; acc[3] += w0.w;
-                    acc[4] += w1.x; acc[5] += w1.y; acc[6] += w1.z; acc[7] += w1.w;
+                    const float4* wp = (const float4*)(w_lds + ((ky * 3 + kx) * 2 + ci) * C + c8 * 8);
+                    const float4 w0 = wp[0], w1 = wp[1];
+                    a0.x += w0.x; a0.y += w0.y; a0.z += w0.z; a0.w += w0.w;
+                    a1.x += w1.x; a1.y += w1.y; a1.z += w1.z; a1.w += w1.w;
                 }
             }
-        const float4* bp = (const float4*)(bias + c8 * 8);
-        float4 b0 = bp[0], b1 = bp[1];
-        float r[8] = {acc[0] + b0.x, acc[1] + b0.y, acc[2] + b0.z, acc[3] + b0.w,
-                      acc[4] + b1.x, acc[5] + b1.y, acc[6] + b1.z, acc[7] + b1.w};
         uint4 o;
-        o.x = pack_bf16x2(fmaxf(r[0], 0.0f), fmaxf(r[1], 0.0f));
-        o.y = pack_bf16x2(fmaxf(r[2], 0.0f), fmaxf(r[3], 0.0f));
-        o.z = pack_bf16x2(fmaxf(r[4], 0.0f), fmaxf(r[5], 0.0f));
-        o.w = pack_bf16x2(fmaxf(r[6], 0.0f), fmaxf(r[7], 0.0f));
+        o.x = pack_bf16x2(fmaxf(a0.x, 0.0f), fmaxf(a0.y, 0.0f));
+        o.y = pack_bf16x2(fmaxf(a0.z, 0.0f), fmaxf(a0.w, 0.0f));
+        o.z = pack_bf16x2(fmaxf(a1.x, 0.0f), fmaxf(a1.y, 0.0f));
+        o.w = pack_bf16x2(fmaxf(a1.z, 0.0f), fmaxf(a1.w, 0.0f));
         *(uint4*)(out + (((b * 8 + (y + 1)) * 9 + (x + 1)) * (size_t)C + c8 * 8)) = o;
     }
 }
@@ -1234,8 +1233,9 @@ void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t
     }
     {
         const size_t threads = (size_t)rows_hint * 42 * (C / 8);
-        const size_t blocks = std::min<size_t>((threads + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(k_conv1, dim3((unsigned)blocks), dim3(256), 0, s, eb, n->w1, n->b1, n->act1, C);
+        const size_t blocks = std::min<size_t>((threads + 255) / 256, 256 * 4);      // 4 persistent blocks per CU (38 KiB LDS each)
+        hipLaunchKernelGGL(k_conv1, dim3((unsigned)blocks), dim3(256), (size_t)(19 * C) * sizeof(float), s, eb, n->w1, n->b1,
+                           n->act1, C);
     }
     GemmDesc d{};
     d.n_dev = eb.n;

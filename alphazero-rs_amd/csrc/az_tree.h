@@ -31,6 +31,7 @@ struct TreeDev {
     uint32_t* leaf;      // [G] node the simulation stopped on
     uint32_t* leaf_kind; // [G] LeafKind
     float* leaf_val;     // [G] value when LEAF_VALUE
+    ulonglong2* leaf_state; // [G] canonical state of the leaf when LEAF_EVAL (dense copy for the batch assembly)
     int32_t* slot_of;    // [G] row of this tree's leaf in the eval batch (LEAF_EVAL)
     // diagnostics
     uint32_t* err;       // [ERR_COUNT]

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, const ulonglong2
         t.root[g] = (root == NONE) ? 0u : root;
         t.leaf[g] = (root == NONE) ? 0u : root;
         t.leaf_kind[g] = kind;
+        t.leaf_state[g] = s;
         t.path_len[g] = 0;
         if (root == NONE || kind == LEAF_NONE) {
             // nothing to evaluate; a failed root also deactivates the tree for this search
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
     uint32_t depth = 0, plen = 0, kind = LEAF_NONE;
     float val = 0.0f;
     uint32_t n_exp = 0, n_link = 0, n_term = 0, n_depth = 0;
+    uint64_t leaf_m = 0, leaf_t = 0;
     for (;;) {
         uint4 pr = t.rec[base + cur];
         uint64_t pc = t.ctr[base + cur] + CTR_VISIT;            // visit(), src/node.rs:77-80; S5: before the checks
@@ -243,12 +245,15 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
         cur = cslot;
         if (ec2 != E_NONE) { val = ecode_value(ec2); kind = LEAF_VALUE; break; }   // S4 (A5)
         kind = LEAF_EVAL;                                       // :303-315: goes to the net
+        leaf_m = m2;
+        leaf_t = t2;
         break;
     }
     if (sub == 0) {
         t.leaf[g] = cur;
         t.leaf_kind[g] = kind;
         t.leaf_val[g] = val;
+        if (kind == LEAF_EVAL) t.leaf_state[g] = make_ulonglong2(leaf_m, leaf_t);
         t.path_len[g] = plen;
         uint64_t* st = t.stat + (size_t)g * ST_COUNT;
         st[ST_SIMS] += 1;
@@ -262,17 +267,26 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
 // ---- inference batch assembly (src/async_mcts.rs:137-151 restated): deterministic compaction ----
 __global__ __launch_bounds__(1024) void k_compact(TreeDev t, EvalBatch eb) {
     // Round r covers trees [r*1024, (r+1)*1024): coalesced flag loads, one ballot per wave, then a scan over the
-    // (round, wave) counts.  Rows come out in ascending tree order (deterministic batches).
+    // (round, wave) counts.  Rows come out in ascending tree order (deterministic batches).  Rounds are processed
+    // 8 at a time with all of a chunk's (coalesced) loads issued before the first use.
     __shared__ uint32_t cnt[1024];                          // [round*16 + wave], rounds <= 64 (G <= 65536)
+    __shared__ uint32_t total_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rounds = (t.G + 1023) >> 10;
     cnt[tid] = 0;
     __syncthreads();
-    for (int r = 0; r < rounds; ++r) {
-        const int g = (r << 10) + tid;
-        const bool f = g < t.G && t.leaf_kind[g] == LEAF_EVAL;
-        const unsigned long long m = __ballot(f);
-        if (lane == 0) cnt[r * 16 + wave] = (uint32_t)__popcll(m);
+    for (int r0 = 0; r0 < rounds; r0 += 8) {
+        uint32_t kind[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = ((r0 + i) << 10) + tid;
+            kind[i] = (r0 + i < rounds && g < t.G) ? t.leaf_kind[g] : (uint32_t)LEAF_NONE;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned long long m = __ballot(kind[i] == LEAF_EVAL);
+            if (lane == 0 && r0 + i < rounds) cnt[(r0 + i) * 16 + wave] = (uint32_t)__popcll(m);
+        }
     }
     __syncthreads();
     const uint32_t mine = cnt[tid];
@@ -282,35 +296,39 @@ __global__ __launch_bounds__(1024) void k_compact(TreeDev t, EvalBatch eb) {
         cnt[tid] += v;
         __syncthreads();
     }
+    if (tid == 1023) total_s = cnt[1023];
     const uint32_t excl = cnt[tid] - mine;
     __syncthreads();
     cnt[tid] = excl;                                        // exclusive prefix per (round, wave)
     __syncthreads();
-    for (int r = 0; r < rounds; ++r) {
-        const int g = (r << 10) + tid;
-        const bool f = g < t.G && t.leaf_kind[g] == LEAF_EVAL;
-        const unsigned long long m = __ballot(f);
-        if (g < t.G) {
-            if (f) {
-                const uint32_t slot = cnt[r * 16 + wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                t.slot_of[g] = (int32_t)slot;
-                eb.tree[slot] = (uint32_t)g;
-                eb.state[slot] = t.state[(size_t)g * t.R + t.leaf[g]];
-            } else {
-                t.slot_of[g] = -1;
+    for (int r0 = 0; r0 < rounds; r0 += 8) {
+        uint32_t kind[8];
+        ulonglong2 st[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = ((r0 + i) << 10) + tid;
+            const bool in = r0 + i < rounds && g < t.G;
+            kind[i] = in ? t.leaf_kind[g] : (uint32_t)LEAF_NONE;
+            if (in) st[i] = t.leaf_state[g];        // dense copy written by k_select / k_root_prepare (no tree gather here)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = ((r0 + i) << 10) + tid;
+            const bool f = kind[i] == LEAF_EVAL;
+            const unsigned long long m = __ballot(f);
+            if (r0 + i < rounds && g < t.G) {
+                if (f) {
+                    const uint32_t slot = cnt[(r0 + i) * 16 + wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    t.slot_of[g] = (int32_t)slot;
+                    eb.tree[slot] = (uint32_t)g;
+                    eb.state[slot] = st[i];
+                } else {
+                    t.slot_of[g] = -1;
+                }
             }
         }
     }
-    if (tid == 0) {
-        uint32_t total = 0;
-        const int last = rounds * 16 - 1;
-        // total = exclusive prefix of the last entry + its own count (recomputed: the last round's last wave)
-        const int g0 = ((rounds - 1) << 10) + 15 * 64;
-        uint32_t c = 0;
-        for (int i = 0; i < 64; ++i) { int g = g0 + i; if (g < t.G && t.leaf_kind[g] == LEAF_EVAL) ++c; }
-        total = cnt[last] + c;
-        *eb.n = total;
-    }
+    if (tid == 0) *eb.n = total_s;
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
