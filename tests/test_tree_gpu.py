@@ -339,3 +339,34 @@ def test_fractional_temperature(engine, oracle, temp):
     for g in range(G):
         assert np.array_equal(counts[g], ocnt) and np.array_equal(q[g], oq)
         assert np.abs(pi[g] - opi).max() <= 1e-5 and abs(float(pi[g].sum()) - 1.0) < 1e-5
+
+
+def test_ragged_sizes_and_limits(engine, oracle, engine_mod):
+    """Sizes that are not multiples of the 8-lane group / 64-lane wave, single slots, and the documented limits."""
+    for n, conc in ((3, 2), (13, 1), (67, 9)):
+        got = engine.selfplay(n_games=n, num_sims=25, model_id=10, seed=31, concurrent=conc, first_game_id=500)
+        ref = oracle.selfplay(n, 25, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=31, first_game_id=500, threads=4)
+        _compare_selfplay(got, ref)
+    with pytest.raises(engine_mod.AzError) as ei:
+        engine.tree_create(65537, reserve=100, num_sims=10, max_depth=10, model_id=0, cpuct=1)
+    assert ei.value.status == 1
+    with pytest.raises(engine_mod.AzError):
+        engine.selfplay(n_games=4, num_sims=0, model_id=0)
+    # reserve below the reachable bound -> AZ_ERR_CAPACITY out of az_selfplay too
+    with pytest.raises(engine_mod.AzError) as ei:
+        engine.selfplay(n_games=8, num_sims=50, model_id=0, reserve=64)
+    assert ei.value.status == 2
+
+
+def test_conv_net_batch_guard(engine_mod):
+    """A tree batch larger than az_config.max_batch cannot use the conv net (workspace bound) -> bad argument."""
+    e = engine_mod.Engine(device=0, max_batch=128, net_channels=128)
+    try:
+        e.net_init_random(0, 1)
+        with pytest.raises(engine_mod.AzError) as ei:
+            e.selfplay(n_games=256, num_sims=10, model_id=0)
+        assert ei.value.status == 1
+        r = e.selfplay(n_games=256, num_sims=10, model_id=0, concurrent=128, want_boards=False)
+        assert r["count"] == 2 * int(r["game_len"].sum())
+    finally:
+        e.close()
