@@ -787,6 +787,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {   // MI
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
         AZ_IMMA_H(mt0_, fb_, fa_, 1);                                                                        \
+        if constexpr (SPREAD == 2) {      /* DMA behind the whole cluster: the fragment reads issued before it have returned */ \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            if (w_issue) AZ_IDMA_W1(kk_w, buf_w, q_);                                                        \
+            if (new_img) AZ_IDMA_IMG1(cb + 1, q_);                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
     }
     const int ncb = C / 64;
     const int nk = ncb * 9;
@@ -1150,12 +1156,13 @@ int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 alw
 
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
-    if ((g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
+    if ((g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9 || g_gemm_variant == 18) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
         const int t8 = (tiles + 7) / 8 * 8;
         if (g_gemm_variant == 5) hipLaunchKernelGGL((k_conv_img<LAYER, 2>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 8) hipLaunchKernelGGL((k_conv_img<LAYER, 2, 1>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 9) hipLaunchKernelGGL((k_conv_img<LAYER, 3, 0, 1>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 18) hipLaunchKernelGGL((k_conv_img<LAYER, 3, 0, 2>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else hipLaunchKernelGGL((k_conv_img<LAYER, 3>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
@@ -1164,7 +1171,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
         if (g_gemm_variant == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9 || g_gemm_variant == 18) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 7) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 4) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 10) hipLaunchKernelGGL((k_gemm256w<LAYER>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);

@@ -199,9 +199,12 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
         uint4 cr = make_uint4(NONE, 0u, 0u, 0u);
         float u = 0.0f;
         if ((uint32_t)sub < nchild) {
+            // the child's record and (speculatively) its own counter are fetched together; only a link slot needs
+            // the second, dependent fetch of the canonical node's counter (resolve(), src/node.rs:179-193)
             cr = t.rec[base + cb + sub];
-            uint32_t r = cr.x != NONE ? cr.x : cb + (uint32_t)sub;     // resolve(), src/node.rs:179-193
-            u = puct(t.ctr[base + r], __uint_as_float(cr.y), sq, sp.cpuct_f);
+            uint64_t cc = t.ctr[base + cb + sub];
+            if (cr.x != NONE) cc = t.ctr[base + cr.x];
+            u = puct(cc, __uint_as_float(cr.y), sq, sp.cpuct_f);
         }
         uint32_t best = 0;
         float bu = gshflf(u, 0);

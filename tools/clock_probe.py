@@ -1,13 +1,12 @@
 """In-kernel clock of the conv2 K loop (diagnostic kernel variant 13): back-to-back launches for ~2 s, then read
 the s_memtime / s_memrealtime stamps."""
 import sys, os, time, numpy as np, ctypes
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tools'))
 from alphazero_rs_amd import engine as azeng
-from oracle import oracle_py as orc
-from test_net_gpu import random_states
+from _states import random_states
 e = azeng.Engine(device=0, max_batch=8192, profile=True)
 e.net_init_random(0, 1)
-uniq = random_states(orc, 512, 3)
+uniq = random_states(512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, 8192)]
 for variant in (13,):
     e.set_option("gemm_variant", variant)

@@ -1,13 +1,12 @@
 """Per-layer kernel times of the net forward for a few batch sizes and option settings (rocprof-free: uses
 az profile events for conv2/total, so only those two; per-layer needs rocprofv3 on this script)."""
 import sys, os, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tools'))
 from alphazero_rs_amd import engine as azeng
-from oracle import oracle_py as orc
-from test_net_gpu import random_states
+from _states import random_states
 e = azeng.Engine(device=0, max_batch=8192, profile=True)
 e.net_init_random(0, 1)
-uniq = random_states(orc, 512, 3)
+uniq = random_states(512, 3)
 for B in (8192, 5000, 2500):
     states = uniq[np.random.default_rng(0).integers(0, 512, B)]
     for opt in (0, 1):

@@ -1,15 +1,14 @@
 """A/B the net's GEMM variants on a full leaf batch: per-variant conv2 and whole-forward TFLOP/s, and bitwise /
 numeric agreement between variants.  Interleaved rounds in one process (variance-correlated)."""
 import sys, os, time, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tools'))
 from alphazero_rs_amd import engine as azeng
-from oracle import oracle_py as orc
-from test_net_gpu import random_states
+from _states import random_states
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 e = azeng.Engine(device=0, max_batch=B, profile=True)
 e.net_init_random(0, 1)
-uniq = random_states(orc, 512, 3)
+uniq = random_states(512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, B)]
 VARS = tuple(int(x) for x in os.environ.get('VARS', '0,2,3').split(','))
 outs = {}
