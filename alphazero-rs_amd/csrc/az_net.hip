@@ -272,24 +272,39 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     const uint32_t a_off0 = row_off(0), a_off1 = row_off(1), a_off2 = row_off(2), a_off3 = row_off(3);
     const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
     const uint32_t b_step = 64u * (uint32_t)d.K;
+    const uint32_t a_ob0 = a_off0 * 2u, a_ob1 = a_off1 * 2u, a_ob2 = a_off2 * 2u, a_ob3 = a_off3 * 2u;     // bytes
+    const uint32_t b_ob0 = b_off0 * 2u, b_ob1 = (b_off0 + b_step) * 2u, b_ob2 = (b_off0 + 2u * b_step) * 2u,
+                   b_ob3 = (b_off0 + 3u * b_step) * 2u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    // K-step walker (channel block outer, tap inner) kept in scalars and advanced with adds and compares only: the
+    // straightforward kt -> (cb, tap, ky, kx) needs two runtime integer divisions per K-step per wave, which showed
+    // up as 10x SQ_ACTIVE_INST_SCA (257 cycles per wave per K-step) in the PMC profile.
+    int ks_tap = 0, ks_kx = 0;
+    uint32_t ks_c0 = 0, ks_toff = 0, ks_kk = 0;
+#define AZ_KSTEP_ADVANCE()                                                                              \
+    {                                                                                                   \
+        ++ks_tap; ++ks_kx; ks_toff += (uint32_t)d.in_c; ks_kk += (uint32_t)d.cin;                       \
+        if (ks_kx == d.tap_w) { ks_kx = 0; ks_toff += (uint32_t)((d.in_w - d.tap_w) * d.in_c); }        \
+        if (ks_tap == ntaps) { ks_tap = 0; ks_kx = 0; ks_c0 += GBK; ks_toff = ks_c0; ks_kk = ks_c0; }   \
+    }
+    // DMA of the K-step the walker points at, into LDS buffer buf_; then advance the walker
 #define AZ_DMA(kt_, buf_)                                                                               \
     {                                                                                                   \
-        const int cb_ = (kt_) / ntaps, tap = (kt_) - cb_ * ntaps;                                       \
-        const int c0 = cb_ * GBK, kk = tap * d.cin + c0;                                                \
-        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                          \
-        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                             \
+        /* wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: the saddr form, no 64-bit VALU adds */ \
+        const char* abase = (const char*)(d.A + ks_toff);                                               \
+        const char* wbase = (const char*)(d.W + ks_kk);                                                 \
         unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
         unsigned char* lb = la + 32768;                                                                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off0 + toff), (lds_ptr)(la), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off1 + toff), (lds_ptr)(la + 8192), 16, 0, 0);  \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off2 + toff), (lds_ptr)(la + 16384), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off3 + toff), (lds_ptr)(la + 24576), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + kk), (lds_ptr)(lb), 16, 0, 0);                     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + kk), (lds_ptr)(lb + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 2 * b_step + kk), (lds_ptr)(lb + 16384), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 3 * b_step + kk), (lds_ptr)(lb + 24576), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob0), (lds_ptr)(la), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob1), (lds_ptr)(la + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob2), (lds_ptr)(la + 16384), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob3), (lds_ptr)(la + 24576), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, 0);    \
+        AZ_KSTEP_ADVANCE();                                                                             \
     }
     f32x4 acc[8][4];
 #pragma unroll
@@ -326,10 +341,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
         if (ABLATE != 1 && ABLATE != 4 && ABLATE != 5 && ABLATE != 7 && !LATE_DMA && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
         if constexpr (ABLATE == 7) {
             if (kt + 1 < nk) {      // same addresses and widths, destination = registers (no LDS write)
-                const int cb_ = (kt + 1) / ntaps, tap = (kt + 1) - cb_ * ntaps;
-                const int c0 = cb_ * GBK, kk = tap * d.cin + c0;
-                const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;
-                const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);
+                const uint32_t toff = ks_toff, kk = ks_kk;
+                AZ_KSTEP_ADVANCE();
                 uint4 r0 = *(const uint4*)(d.A + a_off0 + toff), r1 = *(const uint4*)(d.A + a_off1 + toff),
                       r2 = *(const uint4*)(d.A + a_off2 + toff), r3 = *(const uint4*)(d.A + a_off3 + toff),
                       r4 = *(const uint4*)(d.W + b_off0 + kk), r5 = *(const uint4*)(d.W + b_off0 + b_step + kk),
@@ -395,6 +408,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
         if (tid == 0 && d.dbg && blockIdx.x < 1024) { d.dbg[2 * blockIdx.x] = st1 - st0; d.dbg[2 * blockIdx.x + 1] = sr1 - sr0; }
     }
 #undef AZ_DMA
+#undef AZ_KSTEP_ADVANCE
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wc * 64 + nt * 16 + fq * 4;
@@ -711,34 +725,38 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {   // MI
     const bool i_row3 = 192 + wave * 8 + lrow < IMG_ROWS;
     const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
     const uint32_t b_step = 64u * (uint32_t)d.K;
+    const uint32_t i_ob0 = i_off0 * 2u, i_ob1 = i_off1 * 2u, i_ob2 = i_off2 * 2u, i_ob3 = i_off3 * 2u;     // bytes
+    const uint32_t b_ob0 = b_off0 * 2u, b_ob1 = (b_off0 + b_step) * 2u, b_ob2 = (b_off0 + 2u * b_step) * 2u,
+                   b_ob3 = (b_off0 + 3u * b_step) * 2u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
 #define AZ_IDMA_W(kk_, buf_)                                                                                 \
-    {                                                                                                        \
+    {   /* wave-uniform base + 32-bit per-lane byte offset (saddr form) */                                    \
         unsigned char* lb = smem + 65536 + (buf_) * 32768 + wave * 1024;                                     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + (kk_)), (lds_ptr)(lb), 16, 0, 0);                     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + (kk_)), (lds_ptr)(lb + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 2 * b_step + (kk_)), (lds_ptr)(lb + 16384), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 3 * b_step + (kk_)), (lds_ptr)(lb + 24576), 16, 0, 0); \
+        const char* wbase = (const char*)(d.W + (kk_));                                                      \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);                 \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, 0);         \
     }
 #define AZ_IDMA_W1(kk_, buf_, i_)                                                                            \
-    __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + (i_) * b_step + (kk_)),                        \
+    __builtin_amdgcn_global_load_lds((gbl_ptr)((const char*)(d.W + (kk_)) + ((i_) == 0 ? b_ob0 : (i_) == 1 ? b_ob1 : (i_) == 2 ? b_ob2 : b_ob3)), \
                                      (lds_ptr)(smem + 65536 + (buf_) * 32768 + wave * 1024 + (i_) * 8192), 16, 0, 0);
 #define AZ_IDMA_IMG1(cb_, i_)                                                                                \
     {                                                                                                        \
-        const uint32_t io_ = (i_) == 0 ? i_off0 : (i_) == 1 ? i_off1 : (i_) == 2 ? i_off2 : i_off3;           \
+        const uint32_t io_ = (i_) == 0 ? i_ob0 : (i_) == 1 ? i_ob1 : (i_) == 2 ? i_ob2 : i_ob3;               \
         if ((i_) < 3 || i_row3)                                                                              \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + io_ + (uint32_t)((cb_) * 64)),                  \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)((const char*)(d.A + (cb_) * 64) + io_),               \
                                              (lds_ptr)(smem + ((cb_) & 1) * 32768 + wave * 1024 + (i_) * 8192), 16, 0, 0); \
     }
 #define AZ_IDMA_IMG(cb_)                                                                                     \
     {                                                                                                        \
         unsigned char* la = smem + ((cb_) & 1) * 32768 + wave * 1024;                                        \
-        const uint32_t co_ = (uint32_t)((cb_) * 64);                                                         \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off0 + co_), (lds_ptr)(la), 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off1 + co_), (lds_ptr)(la + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off2 + co_), (lds_ptr)(la + 16384), 16, 0, 0);    \
-        if (i_row3) __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + i_off3 + co_), (lds_ptr)(la + 24576), 16, 0, 0); \
+        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob0), (lds_ptr)(la), 16, 0, 0);                 \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob1), (lds_ptr)(la + 8192), 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob2), (lds_ptr)(la + 16384), 16, 0, 0);         \
+        if (i_row3) __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob3), (lds_ptr)(la + 24576), 16, 0, 0); \
     }
     f32x4 acc[8][4];
 #pragma unroll
