@@ -136,10 +136,28 @@ class Coach:
             self.engine.net_set_params(model_id + 1, new)
             if rank == 0:
                 self.engine.net_save(model_id + 1, os.path.join(self.dir, f"{model_id + 1}.aznet"))
-            # arena: new (first listed) vs old, both seatings (:333-375)
-            wld, _ = self.engine.arena(self.num_arena_games, self.num_sims, new_model_id=model_id + 1, old_model_id=model_id,
-                                       seed=seed + 7919 * (iteration + 1), max_depth=self.max_depth, cpuct=self.cpuct,
-                                       reserve=self.mcts_reserve_size)
+            # arena: new (first listed) vs old, both seatings (:333-375); games sharded by global index across ranks,
+            # the W/L/D tally is one 3-counter all-reduce
+            total = 2 * (self.num_arena_games // 2)
+            a_seed = seed + 7919 * (iteration + 1)
+            if world > 1 and total > 0:
+                from . import dist as azdist
+                import torch
+                import torch.distributed as tdist
+                lo, hi = azdist.shard_range(total, rank, world)
+                wld = np.zeros(3, np.uint64)
+                if hi > lo:
+                    wld, _ = self.engine.arena(hi - lo, self.num_sims, new_model_id=model_id + 1, old_model_id=model_id,
+                                               seed=a_seed, max_depth=self.max_depth, cpuct=self.cpuct,
+                                               reserve=self.mcts_reserve_size, first_game=lo, total_games=total)
+                dev = torch.device("cuda", torch.cuda.current_device()) if tdist.get_backend(self.group) == "nccl" else torch.device("cpu")
+                t = torch.tensor([int(x) for x in wld], dtype=torch.int64, device=dev)
+                tdist.all_reduce(t, group=self.group)
+                wld = t.cpu().numpy()
+            else:
+                wld, _ = self.engine.arena(self.num_arena_games, self.num_sims, new_model_id=model_id + 1, old_model_id=model_id,
+                                           seed=a_seed, max_depth=self.max_depth, cpuct=self.cpuct,
+                                           reserve=self.mcts_reserve_size)
             nwins, pwins, draws = int(wld[0]), int(wld[1]), int(wld[2])
             self.log(f"NEW/PREV WINS : {nwins} / {pwins}; DRAWS : {draws}")            # :381
             accepted = not (pwins + nwins == 0 or nwins / (pwins + nwins) < self.update_threshold)   # :383-390

@@ -771,8 +771,15 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
     if (!e || !p || !out_wld) return AZ_ERR_BAD_ARGUMENT;
     if (p->num_games < 0 || p->num_sims <= 0 || p->max_depth < 0 || p->reserve < 8)
         return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: bad argument");
-    const int half = p->num_games / 2;               // num/2 games per seating, src/arena.rs:83
-    const int G = 2 * half;
+    // unsharded: num/2 games per seating (src/arena.rs:83, an odd game is dropped); sharded: this rank's range of an
+    // even global total, seated by global index
+    const bool sharded = p->total_games > 0;
+    if (sharded && (p->first_game < 0 || p->first_game + p->num_games > p->total_games))
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: shard outside [0, total_games)");
+    if (!sharded && p->first_game != 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: first_game without total_games");
+    const int half = sharded ? p->total_games / 2 : p->num_games / 2;
+    const int G = sharded ? p->num_games : 2 * half;
+    const int first = sharded ? p->first_game : 0;
     out_wld[0] = out_wld[1] = out_wld[2] = 0;
     if (G == 0) return AZ_OK;
     if (G > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: at most 65536 games");
@@ -798,7 +805,7 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         to.create(G, R, hash_entries(p->num_sims, calls), 0);
         DeviceMem mem;
         ArenaDev ad{};
-        ad.G = G; ad.half = half;
+        ad.G = G; ad.half = half; ad.first = first;
         ad.state = mem.alloc<ulonglong2>(G);
         ad.player = mem.alloc<int8_t>(G);
         ad.alive = mem.alloc<uint8_t>(G);
@@ -856,7 +863,7 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         std::vector<int8_t> res(G);
         HIPCHK(hipMemcpy(res.data(), ad.results, G, hipMemcpyDeviceToHost));
         for (int g = 0; g < G; ++g) {
-            const int win_cond = g < half ? 1 : -1, lose_cond = -win_cond;      // src/arena.rs:80-81
+            const int win_cond = first + g < half ? 1 : -1, lose_cond = -win_cond;   // src/arena.rs:80-81
             if (res[g] == win_cond) out_wld[0]++;
             else if (res[g] == lose_cond) out_wld[1]++;
             else out_wld[2]++;

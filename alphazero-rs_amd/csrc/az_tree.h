@@ -89,7 +89,8 @@ struct SelfplayMoveParams {
 
 // arena::play_games state (src/arena.rs:7-99): game g < half is seated (new, old), g >= half (old, new)
 struct ArenaDev {
-    int32_t G, half;
+    int32_t G, half;       // games in this shard; global index below which a game is seated (new, old)
+    int32_t first;         // global index of this shard's game 0
     ulonglong2* state;     // [G] canonical board of the position to move
     int8_t* player;        // [G] cur_player: +1 = first seat to move
     uint8_t* alive;        // [G]

@@ -561,7 +561,7 @@ __global__ void k_arena_sync(TreeDev tn, TreeDev to, ArenaDev ad) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ad.G) return;
     const bool alive = ad.alive[g] != 0;
-    const int first_model = g < ad.half ? 0 : 1;                       // 0 = new, 1 = old
+    const int first_model = ad.first + g < ad.half ? 0 : 1;            // 0 = new, 1 = old (global game index)
     const int mover = ad.player[g] == 1 ? first_model : 1 - first_model;
     tn.active[g] = alive && mover == 0;
     to.active[g] = alive && mover == 1;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64) void k_arena_move(TreeDev t, ArenaDev ad, uint6
     if (g >= t.G || !t.active[g]) return;
     const ulonglong2 s = ad.state[g];
     const int8_t player = ad.player[g];
-    RootPolicy rp = root_policy(t, g, sub, 0.0f, seed, (uint64_t)g, (uint64_t)__popcll(s.x | s.y));
+    RootPolicy rp = root_policy(t, g, sub, 0.0f, seed, (uint64_t)(ad.first + g), (uint64_t)__popcll(s.x | s.y));
     // argmax with max_by (last max) over the one-hot pi = the index of the 1
     const uint32_t hot = gballot(sub < ACTIONS && rp.pi == 1.0f) & 0x7Fu;
     const int action = hot ? (31 - __clz((int)hot)) : 0;

@@ -60,7 +60,8 @@ class az_samples(C.Structure):
 
 class az_arena_params(C.Structure):
     _fields_ = [("num_games", C.c_int32), ("num_sims", C.c_int32), ("max_depth", C.c_int32), ("cpuct", C.c_int32),
-                ("new_model_id", C.c_int32), ("old_model_id", C.c_int32), ("reserve", C.c_uint64), ("seed", C.c_uint64)]
+                ("new_model_id", C.c_int32), ("old_model_id", C.c_int32), ("reserve", C.c_uint64), ("seed", C.c_uint64),
+                ("first_game", C.c_int32), ("total_games", C.c_int32)]
 
 
 # every symbol include/az_engine.h declares (tests check the library exports all of them)
@@ -268,12 +269,15 @@ class Engine:
 
     # ---- arena::play_games ----
     def arena(self, num_games, num_sims, new_model_id, old_model_id, seed=0, max_depth=1000, cpuct=1,
-              reserve=1000000):
-        p = az_arena_params(num_games, num_sims, max_depth, cpuct, new_model_id, old_model_id, reserve, seed)
+              reserve=1000000, first_game=0, total_games=0):
+        """play_games: (W, L, D) for the new model + per-game results.  total_games > 0 plays the shard
+        [first_game, first_game + num_games) of a total_games arena (seating / RNG by global game index)."""
+        p = az_arena_params(num_games, num_sims, max_depth, cpuct, new_model_id, old_model_id, reserve, seed,
+                            first_game, total_games)
         wld = np.zeros(3, np.uint64)
         results = np.zeros(max(num_games, 1), np.int8)
         self._check(_lib.az_arena(self._h, C.byref(p), _ptr(wld), _ptr(results)))
-        return wld, results[: 2 * (num_games // 2)]
+        return wld, results[: (num_games if total_games > 0 else 2 * (num_games // 2))]
 
 
 class TreeBatch:

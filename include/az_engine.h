@@ -186,6 +186,12 @@ typedef struct az_arena_params {
     int32_t old_model_id;   /* second listed player ("old", pmcts, src/coach.rs:333-343) */
     uint64_t reserve;
     uint64_t seed;
+    /* Sharding (one process per GPU): this call plays games [first_game, first_game + num_games) of an arena of
+     * total_games (0 = num_games, first_game must then be 0).  Seating (game < total/2 -> (new, old)) and the RNG
+     * stream use the GLOBAL game index, so shards add up to exactly the unsharded arena (3-counter all-reduce).
+     * A sharded call plays all num_games of its range (the caller splits an even total). */
+    int32_t first_game;
+    int32_t total_games;
 } az_arena_params;
 /* out_wld[3] = {Win, Loss, Draw} for the new model (GameResult, src/arena.rs:54-59);
  * results [num_games] (may be NULL): +1 first seat won, -1 second seat won, 0 draw (play_game, src/arena.rs:51). */

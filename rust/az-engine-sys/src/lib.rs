@@ -29,6 +29,7 @@ pub struct az_samples {
 pub struct az_arena_params {
     pub num_games: i32, pub num_sims: i32, pub max_depth: i32, pub cpuct: i32,
     pub new_model_id: i32, pub old_model_id: i32, pub reserve: u64, pub seed: u64,
+    pub first_game: i32, pub total_games: i32,
 }
 
 extern "C" {

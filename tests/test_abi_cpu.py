@@ -26,7 +26,7 @@ def test_struct_layouts_match_header(engine_mod):
     assert ctypes.sizeof(engine_mod.az_config) == 16
     assert ctypes.sizeof(engine_mod.az_selfplay_params) == 64
     assert ctypes.sizeof(engine_mod.az_samples) == 64
-    assert ctypes.sizeof(engine_mod.az_arena_params) == 40
+    assert ctypes.sizeof(engine_mod.az_arena_params) == 48
     assert ctypes.sizeof(engine_mod.az_stats) == 17 * 8
 
 

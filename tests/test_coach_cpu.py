@@ -87,10 +87,19 @@ class FakeEngine:
                 states[:, 1] |= np.where(b[:, 1, rr, c] != 0, bit, np.uint64(0))
         return {"states": states, "pis": r["pis"][0::2], "zs": r["zs"][0::2], "count": b.shape[0], "ref": r}
 
-    def arena(self, num_games, num_sims, new_model_id, old_model_id, seed, max_depth, cpuct, reserve):
+    def arena(self, num_games, num_sims, new_model_id, old_model_id, seed, max_depth, cpuct, reserve, first_game=0, total_games=0):
         self.calls.append(("arena", num_games, new_model_id, old_model_id))
-        return self.oracle.arena(num_games, num_sims, net_kind=self.oracle.NET_HASH, salt=self._salt(new_model_id) ^ self._salt(old_model_id),
-                                 seed=seed, new_model_id=1, old_model_id=0, threads=4)
+        total = total_games or 2 * (num_games // 2)
+        wld, res = self.oracle.arena(total, num_sims, net_kind=self.oracle.NET_HASH, salt=self._salt(new_model_id) ^ self._salt(old_model_id),
+                                     seed=seed, new_model_id=1, old_model_id=0, threads=4)
+        if not total_games:
+            return wld, res
+        part = res[first_game:first_game + num_games]          # the shard's games of the full arena
+        w = l = d = 0
+        for g, r in zip(range(first_game, first_game + num_games), part):
+            win = 1 if g < total // 2 else -1
+            w, l, d = w + (r == win), l + (r == -win), d + (r == 0)
+        return np.array([w, l, d], np.uint64), part
 
 
 def make_coach(coach, trainer, oracle, tmp, iters, C=16, history=2, queue=10000):
@@ -184,7 +193,8 @@ def _coach_rank(rank, world, port, tmp, q):
     c, eng, _ = make_coach(coach, trainer, orc, os.path.join(tmp, f"rank{rank}"), iters=1)
     rep = c.learn(seed=4)
     q.put((rank, rep[0]["samples"], c.history[0][0].copy(), c.history[0][1].copy(), c.history[0][2].copy(), eng.params[1].copy(),
-           [x for x in eng.calls if x[0] == "selfplay"]))
+           [x for x in eng.calls if x[0] == "selfplay"], (rep[0]["nwins"], rep[0]["pwins"], rep[0]["draws"]),
+           [x for x in eng.calls if x[0] == "arena"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -208,7 +218,9 @@ def test_coach_two_ranks_match_single_process(mods, oracle, tmp_path):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, n, boards, pis, vs, params, calls in got:
+    for rank, n, boards, pis, vs, params, calls, wld, acalls in got:
+        # the arena was sharded 3 + 3 by global game index and the all-reduced tally equals the single-process one
+        assert wld == (rep[0]["nwins"], rep[0]["pwins"], rep[0]["draws"]) and acalls[0][1] == 3
         # every rank ends with the full, identically ordered sample set (rank order == global game-id order)
         assert n == rep[0]["samples"]
         assert np.array_equal(boards, c.history[0][0]) and np.array_equal(pis, c.history[0][1]) and np.array_equal(vs, c.history[0][2])

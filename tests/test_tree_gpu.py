@@ -370,3 +370,22 @@ def test_conv_net_batch_guard(engine_mod):
         assert r["count"] == 2 * int(r["game_len"].sum())
     finally:
         e.close()
+
+
+def test_arena_shards_add_up(engine, oracle, engine_mod):
+    """Arena games sharded by GLOBAL game index (one rank per GPU): three shards of a 20-game arena reproduce the
+    unsharded call game for game, and the W/L/D counters add up (the 3-counter all-reduce of SURVEY.md 8e)."""
+    engine.net_set_kind(51, engine_mod.NET_HASH, 4321 - 51 * MODEL_SALT)
+    engine.net_set_kind(50, engine_mod.NET_HASH, 4321 + MODEL_SALT - 50 * MODEL_SALT)
+    wld, res = engine.arena(20, 50, new_model_id=51, old_model_id=50, seed=9)
+    owld, ores = oracle.arena(20, 50, net_kind=oracle.NET_HASH, salt=4321, seed=9, new_model_id=0, old_model_id=1, threads=8)
+    assert np.array_equal(res, ores) and wld.tolist() == owld.tolist()
+    tot = np.zeros(3, np.uint64)
+    parts = []
+    for lo, hi in ((0, 7), (7, 13), (13, 20)):
+        w, r = engine.arena(hi - lo, 50, new_model_id=51, old_model_id=50, seed=9, first_game=lo, total_games=20)
+        tot += w
+        parts.append(r)
+    assert np.array_equal(np.concatenate(parts), res) and tot.tolist() == wld.tolist()
+    with pytest.raises(engine_mod.AzError):
+        engine.arena(5, 10, new_model_id=51, old_model_id=50, first_game=18, total_games=20)
