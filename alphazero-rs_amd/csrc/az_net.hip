@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
 // issued before this K-step's MFMAs and retired by vmcnt(0) + barrier at the end of the step.
 constexpr int HBM_ = 256, HBN_ = 256;
 
-template <int LAYER, int PIPE, int ABLATE = 0, int XCDMAP = 0, int LATE_DMA = 0>   // ABLATE (timing experiments only): 1 = no DMA in the loop, 2 = no MFMA
+template <int LAYER, int PIPE, int ABLATE = 0, int XCDMAP = 0, int LATE_DMA = 0, int AUXA = 0, int AUXW = 0>   // ABLATE (timing experiments only): 1 = no DMA in the loop, 2 = no MFMA
 __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
@@ -296,14 +296,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
         const char* wbase = (const char*)(d.W + ks_kk);                                                 \
         unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
         unsigned char* lb = la + 32768;                                                                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob0), (lds_ptr)(la), 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob1), (lds_ptr)(la + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob2), (lds_ptr)(la + 16384), 16, 0, 0);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob3), (lds_ptr)(la + 24576), 16, 0, 0);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, 0);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob0), (lds_ptr)(la), 16, 0, AUXA);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob1), (lds_ptr)(la + 8192), 16, 0, AUXA);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob2), (lds_ptr)(la + 16384), 16, 0, AUXA);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob3), (lds_ptr)(la + 24576), 16, 0, AUXA);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, AUXW);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, AUXW);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, AUXW);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, AUXW);    \
         AZ_KSTEP_ADVANCE();                                                                             \
     }
     f32x4 acc[8][4];
@@ -1168,6 +1168,7 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); every no
                           // 5 (default): conv2 image-resident (k_conv_img) + conv3 as 2; 6: 5 + third weight buffer;
                           // 7: late DMA issue; 8: 5 + barrier before the last MFMA cluster; 9: 6 + DMA spread over the
                           // clusters; 10: 2 with the 32x32x16 MFMA shape (1067 TFLOP/s: rejected);
+                          // 18: 6 + DMA behind each cluster; 19-21: LDS-DMA cache-policy bits (nt on A / A+W, sc0);
                           // 11-17: timing ablations / clock stamps (WRONG results, tools/ only)
 
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
@@ -1190,6 +1191,9 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
         const int mt8 = (mt + 7) / 8 * 8;
         if (g_gemm_variant == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9 || g_gemm_variant == 18) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 19) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 0, 2, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 20) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 0, 2, 2>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        else if (g_gemm_variant == 21) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 0, 1, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 7) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 4) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
         else if (g_gemm_variant == 10) hipLaunchKernelGGL((k_gemm256w<LAYER>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
