@@ -240,20 +240,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
 // issued before this K-step's MFMAs and retired by vmcnt(0) + barrier at the end of the step.
 constexpr int HBM_ = 256, HBN_ = 256;
 
-template <int LAYER, int PIPE, int ABLATE = 0, int XCDMAP = 0, int LATE_DMA = 0, int AUXA = 0, int AUXW = 0>   // ABLATE (timing experiments only): 1 = no DMA in the loop, 2 = no MFMA
+// ABLATE != 0 are timing experiments (WRONG results; tools/net_bench.py, profiles/README.md): 1 no DMA in the loop, 2 no MFMA,
+// 3 clock stamps, 4 no DMA + no fragment reads, 5 = 4 without the barrier, 6 DMA never waited for, 7 loads to registers
+template <int LAYER, int PIPE, int ABLATE = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
     const int ntaps = d.K / d.cin;
     const int NT = d.N / HBN_;
-    // XCD-aware order (blocks b and b+8 share an XCD): every XCD sweeps its row tiles for column tile 0, then for
-    // column tile 1, ...: the weight slice all of an XCD's CUs stream at a time is N/NT x K = 2.4 MB (fits the 4 MB L2);
-    // the activation tile is re-read once per column tile instead (from the Infinity Cache / HBM, 0.6 GB per pass).
+    // XCD-aware order (blocks b and b+8 share an XCD): the NT column tiles of a row tile run back to back on one XCD
     const int id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
-    const int per_xcd = (int)(gridDim.x >> 3) / NT;
-    const int ntile = XCDMAP ? j / per_xcd : j % NT;
-    const int mtile = (XCDMAP ? j % per_xcd : j / NT) * 8 + xcd;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
     const int m0 = mtile * HBM_, n0 = ntile * HBN_;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -296,14 +294,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
         const char* wbase = (const char*)(d.W + ks_kk);                                                 \
         unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
         unsigned char* lb = la + 32768;                                                                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob0), (lds_ptr)(la), 16, 0, AUXA);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob1), (lds_ptr)(la + 8192), 16, 0, AUXA);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob2), (lds_ptr)(la + 16384), 16, 0, AUXA);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob3), (lds_ptr)(la + 24576), 16, 0, AUXA);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, AUXW);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, AUXW);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, AUXW);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, AUXW);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob0), (lds_ptr)(la), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob1), (lds_ptr)(la + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob2), (lds_ptr)(la + 16384), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob3), (lds_ptr)(la + 24576), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, 0);    \
         AZ_KSTEP_ADVANCE();                                                                             \
     }
     f32x4 acc[8][4];
@@ -338,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
             else acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0); \
         }
     for (int kt = 0; kt < nk; ++kt) {
-        if (ABLATE != 1 && ABLATE != 4 && ABLATE != 5 && ABLATE != 7 && !LATE_DMA && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
+        if (ABLATE != 1 && ABLATE != 4 && ABLATE != 5 && ABLATE != 7 && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
         if constexpr (ABLATE == 7) {
             if (kt + 1 < nk) {      // same addresses and widths, destination = registers (no LDS write)
                 const uint32_t toff = ks_toff, kk = ks_kk;
@@ -379,9 +377,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
             AZ_LDA(faY, sA, 4, coff0);
             __builtin_amdgcn_sched_barrier(0);
             AZ_MMA(0, fbX, faX);
-            __builtin_amdgcn_sched_barrier(0);
-            // LATE_DMA: the next tile's DMA is issued behind the first MFMA cluster, off the K-step's start-up path
-            if (LATE_DMA && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             AZ_LDB(fbY, sA, coff1);
             AZ_LDA(faX, sA, 0, coff1);
@@ -428,275 +423,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
     }
 }
 
-// ---- 256x256 tile with the 32x32x16 MFMA shape ("wide" variant) ---------------------------------------------
-// Same tile, waves and LDS-DMA staging as k_gemm256<PIPE=1>, but v_mfma_f32_32x32x16_bf16: half as many MFMA
-// instructions (32 per wave per K-step), each holding the SIMD's vector issue port for 8 of its 32 cycles instead
-// of 8 of 16, which leaves more issue slots for the DMA / LDS / address instructions of the two waves sharing a SIMD.
-// Fragment rows are 32 consecutive tile rows per instruction, so the swizzle is slot = chunk ^ ((row>>1)&7).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <int LAYER>
-__global__ __launch_bounds__(512, 2) void k_gemm256w(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
-    const int M = (int)(*d.n_dev) * d.rows_per_sample;
-    const int ntaps = d.K / d.cin;
-    const int NT = d.N / HBN_;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
-    if (m0 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    // DMA map: instruction q of wave w fills tile rows (q*8+w)*8 .. +7; lane -> row (lane>>3), slot (lane&7);
-    // LDS row R slot S holds chunk S ^ ((R>>1)&7), and (R>>1)&7 = ((w&1)*4 + (lrow>>1)) & 7
-    const int lrow = lane >> 3;
-    const int chunk = (lane & 7) ^ (((wave & 1) * 4 + (lrow >> 1)) & 7);
-    auto row_off = [&](int q) -> uint32_t {
-        int m = m0 + (q * 8 + wave) * 8 + lrow;
-        m = m < M ? m : M - 1;
-        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
-        const int y = r / d.out_w, x = r - y * d.out_w;
-        return (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
-    };
-    const uint32_t a_off0 = row_off(0), a_off1 = row_off(1), a_off2 = row_off(2), a_off3 = row_off(3);
-    const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
-    const uint32_t b_step = 64u * (uint32_t)d.K;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-#define AZ_WDMA(kt_, buf_)                                                                              \
-    {                                                                                                   \
-        const int cb_ = (kt_) / ntaps, tap = (kt_) - cb_ * ntaps;                                       \
-        const int c0 = cb_ * GBK, kk = tap * d.cin + c0;                                                \
-        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                          \
-        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                             \
-        unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
-        unsigned char* lb = la + 32768;                                                                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off0 + toff), (lds_ptr)(la), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off1 + toff), (lds_ptr)(la + 8192), 16, 0, 0);  \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off2 + toff), (lds_ptr)(la + 16384), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off3 + toff), (lds_ptr)(la + 24576), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + kk), (lds_ptr)(lb), 16, 0, 0);                     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + kk), (lds_ptr)(lb + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 2 * b_step + kk), (lds_ptr)(lb + 16384), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + 3 * b_step + kk), (lds_ptr)(lb + 24576), 16, 0, 0); \
-    }
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
-    const int nk = d.K / GBK;
-    const int frow = lane & 31, fh = lane >> 5, fsw = (lane >> 1) & 7;
-    const int a_row0 = (wr * 128 + frow) * 128, b_row0 = 32768 + (wc * 64 + frow) * 128;
-    // fragments of 16-deep k-step s_: chunk 2*s_ + fh
-#define AZ_WLD(fa_, fw_, base_, s_)                                                                     \
-    {                                                                                                   \
-        const int co_ = ((2 * (s_) + fh) ^ fsw) << 4;                                                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) fw_[i_] = *(const bf16x8*)((base_) + b_row0 + i_ * 4096 + co_); \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) fa_[i_] = *(const bf16x8*)((base_) + a_row0 + i_ * 4096 + co_); \
-    }
-#define AZ_WMMA(fa_, fw_)                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                    \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw_[j_], fa_[i_], acc[i_][j_], 0, 0, 0);
-    AZ_WDMA(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) AZ_WDMA(kt + 1, (kt + 1) & 1);
-        const unsigned char* sA = smem + (kt & 1) * 65536;
-        bf16x8 faX[4], fwX[2], faY[4], fwY[2];
-        AZ_WLD(faX, fwX, sA, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_WLD(faY, fwY, sA, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_WMMA(faX, fwX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_WLD(faX, fwX, sA, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_WMMA(faY, fwY);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_WLD(faY, fwY, sA, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_WMMA(faX, fwX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_WMMA(faY, fwY);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#undef AZ_WDMA
-#undef AZ_WLD
-#undef AZ_WMMA
-    // D[n][m]: lane holds m = lane&31, n = 8*g + 4*(lane>>5) + (reg&3) for reg group g = reg>>2
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = n0 + wc * 64 + nt * 32 + 8 * g + 4 * fh;
-            const float4 bv = *(const float4*)(d.bias + n);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = m0 + wr * 128 + mt * 32 + frow;
-                if (m >= M) continue;
-                float r0 = acc[mt][nt][4 * g + 0] + bv.x, r1 = acc[mt][nt][4 * g + 1] + bv.y,
-                      r2 = acc[mt][nt][4 * g + 2] + bv.z, r3 = acc[mt][nt][4 * g + 3] + bv.w;
-                if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-                uint2 o;
-                o.x = pack_bf16x2(r0, r1);
-                o.y = pack_bf16x2(r2, r3);
-                *(uint2*)(d.out + (size_t)m * d.N + n) = o;
-            }
-        }
-}
-
-// ---- 256x256 tile, 4-stage LDS ring of 32-deep K stages ("ring" variant) ------------------------------------
-// Same tile and wave layout as k_gemm256, but the K loop advances in stages of 32 (one MFMA K-step) through a ring
-// of four 32 KiB LDS slots filled by LDS-DMA three stages ahead.  Per stage ONE raw s_barrier: the wave first
-// waits (counted vmcnt, never 0 in steady state) until ITS pieces of stage s+1 have landed, so after the barrier
-// stage s+1 is complete for everybody and the slot of stage s-1 is free; the fragments of stage s+1 are then
-// requested while the MFMAs of stage s issue, so no LDS round trip and no DMA wait sits between two MFMA
-// clusters.  Rows are 64 B (4 slots of 16 B); slot = chunk ^ 3*((row>>2)&1) keeps ds_read_b128 conflict-free.
-template <int LAYER>
-__global__ __launch_bounds__(512, 2) void k_gemm256r(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32768];
-    const int M = (int)(*d.n_dev) * d.rows_per_sample;
-    const int ntaps = d.K / d.cin;
-    const int NT = d.N / HBN_;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
-    if (m0 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    // DMA map: instruction q of wave w fills rows (q*8+w)*16 .. +15 of a stage; lane -> row (lane>>2), slot (lane&3)
-    const int lrow = lane >> 2;
-    const int chunk = (lane & 3) ^ (3 * ((lane >> 4) & 1));
-    auto row_off = [&](int q) -> uint32_t {
-        int m = m0 + (q * 8 + wave) * 16 + lrow;
-        m = m < M ? m : M - 1;
-        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
-        const int y = r / d.out_w, x = r - y * d.out_w;
-        return (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
-    };
-    const uint32_t a_off0 = row_off(0), a_off1 = row_off(1);
-    const uint32_t b_off0 = (uint32_t)((n0 + wave * 16 + lrow) * d.K + chunk * 8);
-    const uint32_t b_step = 128u * (uint32_t)d.K;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-    const int ns = d.K / 32;
-#define AZ_RDMA(s_)                                                                                        \
-    {                                                                                                      \
-        const int t2_ = (s_) >> 1, cb_ = t2_ / ntaps, tap = t2_ - cb_ * ntaps;                             \
-        const int c0 = cb_ * 64 + ((s_) & 1) * 32, kk = tap * d.cin + c0;                                  \
-        const int ky = tap / d.tap_w, kx = tap - ky * d.tap_w;                                             \
-        const uint32_t toff = (uint32_t)((ky * d.in_w + kx) * d.in_c + c0);                                \
-        unsigned char* la = smem + ((s_) & 3) * 32768 + wave * 1024;                                       \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off0 + toff), (lds_ptr)(la), 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.A + a_off1 + toff), (lds_ptr)(la + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + kk), (lds_ptr)(la + 16384), 16, 0, 0);      \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(d.W + b_off0 + b_step + kk), (lds_ptr)(la + 24576), 16, 0, 0); \
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fq = lane >> 4;
-    const int fslot = (fq ^ (3 * ((frow >> 2) & 1))) << 4;
-    const int a_row0 = (wr * 128 + frow) * 64 + fslot, b_row0 = 16384 + (wc * 64 + frow) * 64 + fslot;
-#define AZ_RLDA(dst_, s_, mt0_)                                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
-        dst_[i_] = *(const bf16x8*)(smem + ((s_) & 3) * 32768 + a_row0 + ((mt0_) + i_) * 1024);
-#define AZ_RLDB(dst_, s_)                                                                                  \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
-        dst_[i_] = *(const bf16x8*)(smem + ((s_) & 3) * 32768 + b_row0 + i_ * 1024);
-#define AZ_RMMA(mt0_, fb_, fa_)                                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                   \
-            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
-    // one stage: wait for stage s+1, barrier, refill the freed slot, MFMAs of stage s with stage s+1's fragments in flight
-#define AZ_RSTAGE(s_, fbC_, fbN_)                                                                          \
-    {                                                                                                      \
-        if ((s_) + 1 < ns) {                                                                               \
-            if ((s_) + 2 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-        }                                                                                                  \
-        __builtin_amdgcn_s_barrier();                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if ((s_) + 3 < ns) AZ_RDMA((s_) + 3);                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        AZ_RMMA(0, fbC_, faX);                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if ((s_) + 1 < ns) {                                                                               \
-            AZ_RLDB(fbN_, (s_) + 1);                                                                       \
-            AZ_RLDA(faX, (s_) + 1, 0);                                                                     \
-        }                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        AZ_RMMA(4, fbC_, faY);                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        /* the second half of stage s+1's A fragments: requested now, their latency rides out the wait + */ \
-        /* barrier at the top of the next stage (stage s+1 is already complete in LDS)                   */ \
-        if ((s_) + 1 < ns) AZ_RLDA(faY, (s_) + 1, 4);                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-    }
-    bf16x8 fb0[4], fb1[4], faX[4], faY[4];
-    AZ_RDMA(0);
-    AZ_RDMA(1);
-    AZ_RDMA(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    AZ_RLDB(fb0, 0);
-    AZ_RLDA(faX, 0, 0);
-    AZ_RLDA(faY, 0, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int s2 = 0; s2 < ns; s2 += 2) {     // ns is even (K is a multiple of 64)
-        AZ_RSTAGE(s2, fb0, fb1);
-        AZ_RSTAGE(s2 + 1, fb1, fb0);
-    }
-#undef AZ_RDMA
-#undef AZ_RLDA
-#undef AZ_RLDB
-#undef AZ_RMMA
-#undef AZ_RSTAGE
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = m0 + wr * 128 + mt * 16 + frow;
-            if (m >= M) continue;
-            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
-                  r3 = acc[mt][nt][3] + bv.w;
-            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-            uint2 o;
-            o.x = pack_bf16x2(r0, r1);
-            o.y = pack_bf16x2(r2, r3);
-            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
-        }
-    }
-}
-
-// ---- conv2 as an IMAGE-RESIDENT implicit GEMM ("img" variant) ------------------------------------------------
+// ---- conv2 as an IMAGE-RESIDENT implicit GEMM ----------------------------------------------------------------
 // The 9 filter taps of one 64-channel block read overlapping shifted windows of the same activations.  With an M tile
 // of 6 whole boards (252 output rows) the 64-channel slice of those boards is 6 x 42 x 128 B = 31.5 KiB: it is DMA'd
 // into LDS ONCE per channel block (double-buffered, landing during the previous block's taps) and the A fragments of
 // tap (ky,kx) are read from it at row m + (ky-1)*7 + (kx-1); out-of-board taps read a zero row ('same' padding).
 // Only the weight tile (32 KiB) still streams every K-step, so L2->LDS traffic falls from 64 KiB to 35.5 KiB per
-// K-step.  Same K order (channel block outer, tap inner) and per-row accumulation order as the other variants.
+// K-step.  Same K order (channel block outer, tap inner) and per-row accumulation order as the other kernels.
 constexpr int IMG_NB = 6, IMG_ROWS = IMG_NB * 42, IMG_ZERO_ROW = 252;
 
-template <int LAYER, int WBUF, int MIDBAR = 0, int SPREAD = 0>   // WBUF = weight buffers in LDS: 2 (prefetch 1 K-step ahead) or 3 (2 ahead)
-__global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {   // MIDBAR: barrier before the last MFMA cluster; SPREAD: one DMA
-                                                                            // instruction per MFMA cluster instead of a burst at the K-step's start
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 + WBUF) * 32768];   // img[2] | w[WBUF]
+template <int LAYER>
+__global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32768];   // img[2] | w[2]
     const int n_boards = (int)(*d.n_dev);
     const int M = n_boards * 42;
     const int C = d.cin;
@@ -713,41 +451,30 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {   // MI
     // image DMA map: item q of this thread = LDS row q*64 + wave*8 + (lane>>3), slot lane&7 (rows >= 252 are not loaded)
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ lrow;
-    auto img_off = [&](int q) -> uint32_t {
+    auto img_off = [&](int q) -> uint32_t {         // byte offset of this lane's 16 bytes of image row q*64 + wave*8 + lrow
         int r = q * 64 + wave * 8 + lrow;
         r = r < IMG_ROWS ? r : IMG_ROWS - 1;
         int b = b0 + r / 42;
         b = b < n_boards ? b : n_boards - 1;
         const int p = r % 42, y = p / 7, x = p - y * 7;
-        return (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8);
+        return (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8) * 2u;
     };
-    const uint32_t i_off0 = img_off(0), i_off1 = img_off(1), i_off2 = img_off(2), i_off3 = img_off(3);
+    const uint32_t i_ob0 = img_off(0), i_ob1 = img_off(1), i_ob2 = img_off(2), i_ob3 = img_off(3);
     const bool i_row3 = 192 + wave * 8 + lrow < IMG_ROWS;
-    const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
-    const uint32_t b_step = 64u * (uint32_t)d.K;
-    const uint32_t i_ob0 = i_off0 * 2u, i_ob1 = i_off1 * 2u, i_ob2 = i_off2 * 2u, i_ob3 = i_off3 * 2u;     // bytes
-    const uint32_t b_ob0 = b_off0 * 2u, b_ob1 = (b_off0 + b_step) * 2u, b_ob2 = (b_off0 + 2u * b_step) * 2u,
-                   b_ob3 = (b_off0 + 3u * b_step) * 2u;
+    const uint32_t b_ob0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
+    const uint32_t b_stepb = 128u * (uint32_t)d.K;                       // 64 weight rows, in bytes
+    const uint32_t b_ob1 = b_ob0 + b_stepb, b_ob2 = b_ob0 + 2u * b_stepb, b_ob3 = b_ob0 + 3u * b_stepb;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    // wave-uniform base + 32-bit per-lane byte offset (the saddr form of global_load_lds)
 #define AZ_IDMA_W(kk_, buf_)                                                                                 \
-    {   /* wave-uniform base + 32-bit per-lane byte offset (saddr form) */                                    \
+    {                                                                                                        \
         unsigned char* lb = smem + 65536 + (buf_) * 32768 + wave * 1024;                                     \
         const char* wbase = (const char*)(d.W + (kk_));                                                      \
         __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);                 \
         __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, 0);          \
         __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, 0);         \
         __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, 0);         \
-    }
-#define AZ_IDMA_W1(kk_, buf_, i_)                                                                            \
-    __builtin_amdgcn_global_load_lds((gbl_ptr)((const char*)(d.W + (kk_)) + ((i_) == 0 ? b_ob0 : (i_) == 1 ? b_ob1 : (i_) == 2 ? b_ob2 : b_ob3)), \
-                                     (lds_ptr)(smem + 65536 + (buf_) * 32768 + wave * 1024 + (i_) * 8192), 16, 0, 0);
-#define AZ_IDMA_IMG1(cb_, i_)                                                                                \
-    {                                                                                                        \
-        const uint32_t io_ = (i_) == 0 ? i_ob0 : (i_) == 1 ? i_ob1 : (i_) == 2 ? i_ob2 : i_ob3;               \
-        if ((i_) < 3 || i_row3)                                                                              \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)((const char*)(d.A + (cb_) * 64) + io_),               \
-                                             (lds_ptr)(smem + ((cb_) & 1) * 32768 + wave * 1024 + (i_) * 8192), 16, 0, 0); \
     }
 #define AZ_IDMA_IMG(cb_)                                                                                     \
     {                                                                                                        \
@@ -790,123 +517,57 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {   // MI
 #define AZ_ILDB(dst_, wb_, coff_)                                                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
         dst_[i_] = *(const bf16x8*)((wb_) + b_row0 + i_ * 2048 + (coff_));
-#define AZ_IMMA_H(mt0_, fb_, fa_, h_)                                                                        \
-    _Pragma("unroll") for (int i_ = 2 * (h_); i_ < 2 * (h_) + 2; ++i_)                                       \
+#define AZ_IMMA(mt0_, fb_, fa_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
             acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
-    // one MFMA cluster (16) with, in SPREAD mode, DMA instruction #q_ of the next tiles between its halves
-#define AZ_IMMA(mt0_, fb_, fa_, q_)                                                                          \
-    {                                                                                                        \
-        AZ_IMMA_H(mt0_, fb_, fa_, 0);                                                                        \
-        if constexpr (SPREAD == 1) {                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                               \
-            if (w_issue) AZ_IDMA_W1(kk_w, buf_w, q_);                                                        \
-            if (new_img) AZ_IDMA_IMG1(cb + 1, q_);                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                                               \
-        }                                                                                                    \
-        AZ_IMMA_H(mt0_, fb_, fa_, 1);                                                                        \
-        if constexpr (SPREAD == 2) {      /* DMA behind the whole cluster: the fragment reads issued before it have returned */ \
-            __builtin_amdgcn_sched_barrier(0);                                                               \
-            if (w_issue) AZ_IDMA_W1(kk_w, buf_w, q_);                                                        \
-            if (new_img) AZ_IDMA_IMG1(cb + 1, q_);                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                                               \
-        }                                                                                                    \
-    }
     const int ncb = C / 64;
     const int nk = ncb * 9;
     AZ_IDMA_W(0, 0);
     AZ_IDMA_IMG(0);
-    if (WBUF == 3) AZ_IDMA_W(1 * C, 1);             // K-step 1 = (cb 0, tap 1)
-    if (WBUF == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cb = 0, tap = 0;
-    bf16x8 fbX[4], fbY[4], faX[4], faY[4];
-    if constexpr (MIDBAR == 1) {
-        const int dt = -8, tapbit = 16;                    // K-step 0 = (cb 0, tap 0)
-        AZ_ILDB(fbX, smem, coffB0);
-        AZ_ILDA(faX, smem, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
     for (int kt = 0; kt < nk; ++kt) {
         const bool new_img = tap == 0 && cb + 1 < ncb;
-        const bool w_issue = kt + (WBUF - 1) < nk;
-        // weights of K-step kt + WBUF - 1
-        int ntap_w = tap + (WBUF - 1), ncb_w = cb;
-        if (ntap_w >= 9) { ntap_w -= 9; ++ncb_w; }
-        const int kk_w = ntap_w * C + ncb_w * 64, buf_w = (kt + WBUF - 1) % WBUF;
-        if constexpr (SPREAD == 0) {
-            if (w_issue) AZ_IDMA_W(kk_w, buf_w);
-            if (new_img) AZ_IDMA_IMG(cb + 1);   // issued after the weights: stays in flight over this step's wait
+        if (kt + 1 < nk) {
+            const int ntap = tap == 8 ? 0 : tap + 1, ncbi = tap == 8 ? cb + 1 : cb;
+            AZ_IDMA_W(ntap * C + ncbi * 64, (kt + 1) & 1);
         }
+        if (new_img) AZ_IDMA_IMG(cb + 1);       // issued after the weights: stays in flight over this step's wait
         const unsigned char* sI = smem + (cb & 1) * 32768;
-        const unsigned char* sW = smem + (kt % WBUF) * 32768;   // b_row0 already carries the 64 KiB image offset
+        const unsigned char* sW = smem + (kt & 1) * 32768;       // b_row0 already carries the 64 KiB image offset
         const int ky = tap / 3, kx = tap - ky * 3;
         const int dt = (ky - 1) * 7 + (kx - 1);
         const int tapbit = 16 + tap;
-        // DMA instructions that may stay in flight over this K-step's wait.  Burst mode: those issued after the weights
-        // of kt+1.  SPREAD mode (WBUF == 3): exactly the ones issued during this K-step (weights of kt+2, next image).
-        const int younger = SPREAD ? (w_issue ? 4 : 0) + (new_img ? 4 : 0)
-                                   : (WBUF == 3 && w_issue ? 4 : 0) + (new_img ? 4 : 0) + (WBUF == 3 && tap == 1 && cb + 1 < ncb ? 4 : 0);
-        if constexpr (MIDBAR == 0) {
-            AZ_ILDB(fbX, sW, coffB0);
-            AZ_ILDA(faX, sI, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // (MIDBAR: fbX / faX were requested under the previous K-step's last MFMA cluster, or by the prologue)
+        // 4 clusters of 16 MFMAs; the fragments of the next cluster are requested before the current one issues
+        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+        AZ_ILDB(fbX, sW, coffB0);
+        AZ_ILDA(faX, sI, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         AZ_ILDA(faY, sI, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(0, fbX, faX, 0);
+        AZ_IMMA(0, fbX, faX);
         __builtin_amdgcn_sched_barrier(0);
         AZ_ILDB(fbY, sW, coffB1);
         AZ_ILDA(faX, sI, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(4, fbX, faY, 1);
+        AZ_IMMA(4, fbX, faY);
         __builtin_amdgcn_sched_barrier(0);
         AZ_ILDA(faY, sI, 4, 1);
         __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(0, fbY, faX, 2);
+        AZ_IMMA(0, fbY, faX);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MIDBAR == 1) {
-            // every LDS read of this K-step has returned and this wave's DMA pieces of the next weight tile have
-            // landed: after the barrier the next tile is complete and this tile's buffers may be refilled
-            if (younger == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else if (younger == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) {
-                const int ntap2 = tap == 8 ? 0 : tap + 1, ncb2 = tap == 8 ? cb + 1 : cb;
-                const unsigned char* sI2 = smem + (ncb2 & 1) * 32768;
-                const unsigned char* sW2 = smem + ((kt + 1) % WBUF) * 32768;
-                const int ky2 = ntap2 / 3, kx2 = ntap2 - ky2 * 3;
-                {
-                    const int dt = (ky2 - 1) * 7 + (kx2 - 1);
-                    const int tapbit = 16 + ntap2;
-                    AZ_ILDB(fbX, sW2, coffB0);
-                    AZ_ILDA(faX, sI2, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_IMMA(4, fbY, faY, 3);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            AZ_IMMA(4, fbY, faY, 3);
-            // counted wait: the weights of K-step kt+1 must have landed; anything issued after them may stay in flight
-            // (WBUF == 3: the weights of kt+2, and the next image when it was issued this step or the step before)
-            if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                    // raw: __syncthreads() would drain vmcnt to 0
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        AZ_IMMA(4, fbY, faY);
+        // counted wait: the next weight tile must have landed; the next image (issued after it) may stay in flight
+        if (new_img) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // raw: __syncthreads() would drain vmcnt to 0
+        __builtin_amdgcn_sched_barrier(0);
         if (++tap == 9) { tap = 0; ++cb; }
     }
 #undef AZ_IDMA_W
 #undef AZ_IDMA_IMG
-#undef AZ_IDMA_W1
-#undef AZ_IDMA_IMG1
-#undef AZ_IMMA_H
 #undef AZ_ILDA
 #undef AZ_ILDB
 #undef AZ_IMMA
@@ -1162,49 +823,39 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
     convnet_set_params(net, p.data(), L.total);
 }
 
-int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); every non-ablation variant is bit-identical:
-                          // 0: 128x128 register-staged tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3;
-                          // 2: + hand-phased fragment prefetch; 3: 4-stage ring of 32-deep stages; 4: XCD column remap;
-                          // 5 (default): conv2 image-resident (k_conv_img) + conv3 as 2; 6: 5 + third weight buffer;
-                          // 7: late DMA issue; 8: 5 + barrier before the last MFMA cluster; 9: 6 + DMA spread over the
-                          // clusters; 10: 2 with the 32x32x16 MFMA shape (1067 TFLOP/s: rejected);
-                          // 18: 6 + DMA behind each cluster; 19-21: LDS-DMA cache-policy bits (nt on A / A+W, sc0);
-                          // 11-17: timing ablations / clock stamps (WRONG results, tools/ only)
-
+int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants 0, 1, 2, 5 are bit-identical:
+                          // 0: 128x128 register-staged tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3(/conv4);
+                          // 2: + hand-phased fragment prefetch; 5 (default): conv2 image-resident (k_conv_img), rest as 2;
+                          // 11-17: timing ablations / clock stamps of variant 2 (WRONG results, tools/ only).
+                          // Rejected and removed after measurement (numbers in profiles/README.md, code in git history):
+                          // 4-stage ring, XCD column remap, third weight buffer, late / spread DMA issue, mid barrier,
+                          // 32x32x16 MFMA shape, non-temporal cache policy.
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
 
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
-    if ((g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9 || g_gemm_variant == 18) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
+    const int v = g_gemm_variant;
+    if (v == 5 && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
         const int t8 = (tiles + 7) / 8 * 8;
-        if (g_gemm_variant == 5) hipLaunchKernelGGL((k_conv_img<LAYER, 2>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 8) hipLaunchKernelGGL((k_conv_img<LAYER, 2, 1>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 9) hipLaunchKernelGGL((k_conv_img<LAYER, 3, 0, 1>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 18) hipLaunchKernelGGL((k_conv_img<LAYER, 3, 0, 2>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else hipLaunchKernelGGL((k_conv_img<LAYER, 3>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
-    const bool big = g_gemm_variant >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_hint >= 4096)))) && d.N % HBN_ == 0;
+    const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_hint >= 4096)))) &&
+                     d.N % HBN_ == 0;
     if (big) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
-        if (g_gemm_variant == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 2 || g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 8 || g_gemm_variant == 9 || g_gemm_variant == 18) hipLaunchKernelGGL((k_gemm256<LAYER, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 19) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 0, 2, 0>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 20) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 0, 2, 2>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 21) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 0, 1, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 7) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 4) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 0, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 10) hipLaunchKernelGGL((k_gemm256w<LAYER>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 16) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 6>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 17) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 7>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 14) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 4>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 15) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 5>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 13) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 3>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 11) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 1>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else if (g_gemm_variant == 12) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 2>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        else hipLaunchKernelGGL((k_gemm256r<LAYER>), dim3(mt8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        const dim3 grid(mt8 * (d.N / HBN_)), block(512);
+        if (v == 1) hipLaunchKernelGGL((k_gemm256<LAYER, 0>), grid, block, 0, s, d);
+        else if (v == 11) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 1>), grid, block, 0, s, d);
+        else if (v == 12) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 2>), grid, block, 0, s, d);
+        else if (v == 13) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 3>), grid, block, 0, s, d);
+        else if (v == 14) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 4>), grid, block, 0, s, d);
+        else if (v == 15) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 5>), grid, block, 0, s, d);
+        else if (v == 16) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 6>), grid, block, 0, s, d);
+        else if (v == 17) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 7>), grid, block, 0, s, d);
+        else hipLaunchKernelGGL((k_gemm256<LAYER, 1>), grid, block, 0, s, d);
         return;
     }
     const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
