@@ -11,8 +11,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libaz_engine.so")
-SOURCES = ["az_tree.hip", "az_net.hip", "az_engine.hip"]
-HEADERS = ["az_common.h", "az_tree.h", "az_net.h", os.path.join("..", "..", "include", "az_engine.h")]
+SOURCES = ["az_tree.hip", "az_net.hip", "az_train.hip", "az_engine.hip"]
+HEADERS = ["az_common.h", "az_tree.h", "az_net.h", "az_train.h", os.path.join("..", "..", "include", "az_engine.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-result"]
 

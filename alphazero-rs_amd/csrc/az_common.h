@@ -77,6 +77,13 @@ AZ_HD uint64_t rng_draw(uint64_t seed, uint64_t game_id, uint64_t ply, uint64_t 
     return mix64(mix64(mix64(mix64(seed) ^ game_id) ^ ply) ^ purpose);
 }
 AZ_HD uint32_t rng_choose(uint64_t r, uint32_t k) { return (uint32_t)(((r >> 32) * (uint64_t)k) >> 32); }
+// trainer streams: batch row j of step t = rng_choose(rng_draw(seed, t, j, RNG_BATCH), n_samples);
+// dropout: element idx of layer `layer` is KEPT iff the top 24 bits of its draw are below keep_prob * 2^24
+constexpr uint64_t RNG_BATCH = 4;
+AZ_HD bool dropout_keep(uint64_t mask_seed, uint32_t layer, uint64_t idx, uint32_t keep_thresh24) {
+    const uint64_t r = mix64(mix64(mask_seed ^ ((uint64_t)(layer + 1) * 0xD1B54A32D192ED03ull)) ^ idx);
+    return (uint32_t)(r >> 40) < keep_thresh24;
+}
 
 // ---- Connect Four on canonical bitboards (connect_four_game.rs:81-238) --------
 // bit(col,row) = col*7 + row, row 0 = bottom; `mine` = side to move.

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "az_net.h"
+#include "az_train.h"
 #include "az_tree.h"
 
 using namespace az;
@@ -150,6 +151,13 @@ struct az_engine {
     std::vector<uint64_t> sp_log_states;
     std::vector<float> sp_log_pi, sp_log_v;
     int sp_log_cap = 0;
+    // NNet::train
+    Trainer* trainer = nullptr;
+    bool train_open = false;
+    TrainHyper hyper;
+    int train_epochs = 10, train_batch = 64;       // connect_four_net.py:13-14
+    uint64_t train_seed = 0;
+    std::vector<float> train_history;              // (loss_pi, loss_v) mean per epoch of the last az_net_train
 };
 
 struct az_tree {
@@ -303,6 +311,7 @@ void az_destroy(az_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->nets) if (kv.second.conv) convnet_destroy(kv.second.conv);
+    trainer_destroy(e->trainer);
     { double ms[RG_COUNT] = {0, 0}; e->prof.resolve(ms); }
     (void)hipStreamDestroy(e->stream);
     delete e;
@@ -336,6 +345,12 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         convnet_set_conv4_big((int)value);
         return AZ_OK;
     }
+    // NNet::train hyper-parameters (defaults = connect_four_net.py:13-15, :21)
+    if (std::strcmp(key, "train_epochs") == 0 && value >= 1 && value <= 100000) { e->train_epochs = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "train_batch") == 0 && value >= 2 && value <= TRAIN_MAX_BATCH) { e->train_batch = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "train_seed") == 0) { e->train_seed = (uint64_t)value; return AZ_OK; }
+    if (std::strcmp(key, "train_lr_e9") == 0 && value > 0) { e->hyper.lr = (float)((double)value * 1e-9); return AZ_OK; }
+    if (std::strcmp(key, "train_dropout_e6") == 0 && value >= 0 && value < 1000000) { e->hyper.dropout = (float)((double)value * 1e-6); return AZ_OK; }
     return fail(e, AZ_ERR_BAD_ARGUMENT, std::string("unknown option or value: ") + key);
 }
 
@@ -502,8 +517,114 @@ az_status az_net_predict(az_engine* e, int32_t model_id, const float* boards, in
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
 
-az_status az_net_train(az_engine* e, int32_t, int32_t, const float*, const float*, const float*, int64_t) {
-    return fail(e, AZ_ERR_UNSUPPORTED, "NNet::train is the next tier (SURVEY.md 8f-2)");
+// ---- NNet::train, src/nnet.rs:38 ----------------------------------------------------------------
+az_status az_net_train_begin(az_engine* e, int32_t previous_model_id) {
+    if (!e) return AZ_ERR_BAD_ARGUMENT;
+    NetModel* m;
+    az_status st = find_net(e, previous_model_id, &m);
+    if (st) return st;
+    if (m->kind != AZ_NET_CONV) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_net_train: the previous model has no parameters");
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        if (!e->trainer) {
+            const char* err = nullptr;
+            e->trainer = trainer_create(e->cfg.net_channels, &err);
+            if (!e->trainer) return fail(e, AZ_ERR_HIP, err ? err : "trainer_create failed");
+        }
+        const int64_t n = az_net_param_count(e);
+        std::vector<float> p((size_t)n);
+        if (!convnet_get_params(m->conv, p.data(), n)) return fail(e, AZ_ERR_BAD_ARGUMENT, "parameter count mismatch");
+        if (!trainer_set_params(e->trainer, p.data(), n)) return fail(e, AZ_ERR_HIP, "trainer_set_params failed");
+        e->train_open = true;
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_net_train_step(az_engine* e, const float* boards, const float* pis, const float* vs, int32_t b, uint64_t mask_seed,
+                            int32_t apply, float* loss_out, float* grads_out) {
+    if (!e || !boards || !pis || !vs) return AZ_ERR_BAD_ARGUMENT;
+    if (!e->train_open) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_net_train_step: call az_net_train_begin first");
+    if (b < 2 || b > TRAIN_MAX_BATCH) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_net_train_step: batch must be in [2, 256]");
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        Trainer* t = e->trainer;
+        HIPCHK(hipMemcpyAsync(trainer_batch_boards(t), boards, (size_t)b * 84 * sizeof(float), hipMemcpyDefault, e->stream));
+        HIPCHK(hipMemcpyAsync(trainer_batch_pis(t), pis, (size_t)b * 7 * sizeof(float), hipMemcpyDefault, e->stream));
+        HIPCHK(hipMemcpyAsync(trainer_batch_vs(t), vs, (size_t)b * sizeof(float), hipMemcpyDefault, e->stream));
+        if (!trainer_step(t, e->hyper, trainer_batch_boards(t), trainer_batch_pis(t), trainer_batch_vs(t), b, mask_seed, apply != 0,
+                          e->stream))
+            return fail(e, AZ_ERR_HIP, "trainer_step failed");
+        double l[2];
+        if (!trainer_read_losses(t, l, true, e->stream)) return fail(e, AZ_ERR_HIP, "trainer_read_losses failed");
+        if (loss_out) { loss_out[0] = (float)l[0]; loss_out[1] = (float)l[1]; }
+        if (grads_out && !trainer_get_grads(t, grads_out, az_net_param_count(e), e->stream))
+            return fail(e, AZ_ERR_HIP, "trainer_get_grads failed");
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_net_train_end(az_engine* e, int32_t model_id) {
+    if (!e) return AZ_ERR_BAD_ARGUMENT;
+    if (!e->train_open) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_net_train_end: no open training session");
+    const int64_t n = az_net_param_count(e);
+    std::vector<float> p((size_t)n);
+    if (!trainer_get_params(e->trainer, p.data(), n, e->stream)) return fail(e, AZ_ERR_HIP, "trainer_get_params failed");
+    e->train_open = false;
+    return az_net_set_params(e, model_id, p.data(), n);
+}
+
+az_status az_net_train(az_engine* e, int32_t previous_model_id, int32_t model_id, const float* boards, const float* pis,
+                       const float* vs, int64_t n) {
+    if (!e || !boards || !pis || !vs || n <= 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_net_train: bad argument");
+    az_status st = az_net_train_begin(e, previous_model_id);
+    if (st) return st;
+    ScopedTimer timer{e};
+    try {
+        DeviceMem mem;
+        float* d_boards = mem.alloc<float>((size_t)n * 84);
+        float* d_pis = mem.alloc<float>((size_t)n * 7);
+        float* d_vs = mem.alloc<float>((size_t)n);
+        HIPCHK(hipMemcpy(d_boards, boards, (size_t)n * 84 * sizeof(float), hipMemcpyDefault));
+        HIPCHK(hipMemcpy(d_pis, pis, (size_t)n * 7 * sizeof(float), hipMemcpyDefault));
+        HIPCHK(hipMemcpy(d_vs, vs, (size_t)n * sizeof(float), hipMemcpyDefault));
+        const int b = e->train_batch;
+        const int64_t steps = std::max<int64_t>(1, n / b);          // connect_four_net.py:127-130: len(examples) / batch_size
+        int64_t* d_idx = mem.alloc<int64_t>((size_t)steps * b);
+        std::vector<int64_t> idx((size_t)steps * b);
+        Trainer* t = e->trainer;
+        e->train_history.clear();
+        uint64_t gstep = 0;
+        for (int epoch = 0; epoch < e->train_epochs; ++epoch) {
+            // batches are drawn with replacement (np.random.randint, :130), from the build's counter RNG
+            for (int64_t sidx = 0; sidx < steps; ++sidx)
+                for (int j = 0; j < b; ++j) {
+                    const uint64_t r = rng_draw(e->train_seed, gstep + (uint64_t)sidx, (uint64_t)j, RNG_BATCH);
+                    idx[(size_t)sidx * b + j] = (int64_t)(((unsigned __int128)r * (unsigned __int128)n) >> 64);
+                }
+            HIPCHK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+            for (int64_t sidx = 0; sidx < steps; ++sidx, ++gstep) {
+                trainer_gather(t, d_boards, d_pis, d_vs, d_idx + sidx * b, b, e->stream);
+                const uint64_t mask_seed = mix64(mix64(e->train_seed ^ 0xD6E8FEB86659FD93ull) ^ gstep);
+                if (!trainer_step(t, e->hyper, trainer_batch_boards(t), trainer_batch_pis(t), trainer_batch_vs(t), b, mask_seed, true,
+                                  e->stream))
+                    return fail(e, AZ_ERR_HIP, "trainer_step failed");
+            }
+            double l[2];
+            if (!trainer_read_losses(t, l, true, e->stream)) return fail(e, AZ_ERR_HIP, "trainer_read_losses failed");
+            e->train_history.push_back((float)(l[0] / (double)steps));
+            e->train_history.push_back((float)(l[1] / (double)steps));
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+    } catch (const HipFail& f) { e->train_open = false; return fail_hip(e, f); }
+    return az_net_train_end(e, model_id);
+}
+
+int32_t az_net_train_history(const az_engine* e, float* out, int32_t cap_epochs) {
+    if (!e) return 0;
+    const int32_t epochs = (int32_t)(e->train_history.size() / 2);
+    if (out)
+        for (int32_t i = 0; i < std::min(epochs, cap_epochs); ++i) { out[2 * i] = e->train_history[2 * i]; out[2 * i + 1] = e->train_history[2 * i + 1]; }
+    return epochs;
 }
 
 // ---- AsyncMcts -------------------------------------------------------------------------------

@@ -10,6 +10,31 @@ namespace az {
 
 struct ConvNet;   // weights + activation workspace, az_net.hip
 
+// offsets of the flat f32 parameter vector (the weights file)
+struct Layout {
+    int C;
+    int64_t conv_w[4], conv_b[4], conv_bn[4], fc_w[2], fc_b[2], fc_bn[2], pi_w, pi_b, v_w, v_b, total;
+    explicit Layout(int c) : C(c) {
+        int64_t o = 0;
+        for (int l = 0; l < 4; ++l) {
+            int cin = l == 0 ? 2 : C;
+            conv_w[l] = o; o += 9ll * cin * C;
+            conv_b[l] = o; o += C;
+            conv_bn[l] = o; o += 4ll * C;
+        }
+        const int fin[2] = {6 * C, 1024}, fout[2] = {1024, 512};
+        for (int l = 0; l < 2; ++l) {
+            fc_w[l] = o; o += (int64_t)fin[l] * fout[l];
+            fc_b[l] = o; o += fout[l];
+            fc_bn[l] = o; o += 4ll * fout[l];
+        }
+        pi_w = o; o += 512 * 7; pi_b = o; o += 7;
+        v_w = o; o += 512; v_b = o; o += 1;
+        total = o;
+    }
+};
+
+
 struct NetProfile {          // filled when profiling is on
     double conv2_ms = 0, conv2_flops = 0, total_ms = 0, total_flops = 0;
     uint64_t launches = 0;

@@ -636,29 +636,6 @@ __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_
 //   conv1 W[3][3][2][C] b[C] bn[4][C] | conv2..4 W[3][3][C][C] b[C] bn[4][C] |
 //   fc1 W[6C][1024] b[1024] bn[4][1024] (input index = (y*3+x)*C + c of conv4's [2][3][C] output) |
 //   fc2 W[1024][512] b[512] bn[4][512] | pi W[512][7] b[7] | v W[512][1] b[1]
-struct Layout {
-    int C;
-    int64_t conv_w[4], conv_b[4], conv_bn[4], fc_w[2], fc_b[2], fc_bn[2], pi_w, pi_b, v_w, v_b, total;
-    explicit Layout(int c) : C(c) {
-        int64_t o = 0;
-        for (int l = 0; l < 4; ++l) {
-            int cin = l == 0 ? 2 : C;
-            conv_w[l] = o; o += 9ll * cin * C;
-            conv_b[l] = o; o += C;
-            conv_bn[l] = o; o += 4ll * C;
-        }
-        const int fin[2] = {6 * C, 1024}, fout[2] = {1024, 512};
-        for (int l = 0; l < 2; ++l) {
-            fc_w[l] = o; o += (int64_t)fin[l] * fout[l];
-            fc_b[l] = o; o += fout[l];
-            fc_bn[l] = o; o += 4ll * fout[l];
-        }
-        pi_w = o; o += 512 * 7; pi_b = o; o += 7;
-        v_w = o; o += 512; v_b = o; o += 1;
-        total = o;
-    }
-};
-
 struct ConvNet {
     int C = 512, max_batch = 0;
     std::vector<float> params;        // raw f32 parameters as set

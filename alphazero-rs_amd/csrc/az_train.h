@@ -1,0 +1,49 @@
+// az_train.h -- NNet::train on the device (src/nnet.rs:38; recipe of connect_four_net.py:13-21, :102-151).
+//
+// f32 training of the policy+value net on the engine's flat parameter layout (az_net.hip `Layout`, the weights
+// file): forward in BatchNorm training mode, softmax cross-entropy + mean squared error, backward, Adam.
+// Every GEMM (conv layers as im2col x weights, dgrad, wgrad, the FCs) runs on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32); the column reductions are two-stage and summed in a fixed order, so a step is
+// deterministic run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace az {
+
+struct Trainer;
+
+struct TrainHyper {
+    float lr = 1e-3f;            // connect_four_net.py:21
+    float beta1 = 0.9f, beta2 = 0.999f, adam_eps = 1e-8f;
+    float bn_momentum = 0.99f;   // tf.layers.batch_normalization default
+    float bn_eps = 1e-3f;
+    float dropout = 0.3f;        // connect_four_net.py:15
+};
+
+constexpr int TRAIN_MAX_BATCH = 256;
+
+Trainer* trainer_create(int channels, const char** err);
+void trainer_destroy(Trainer* t);
+// host f32 parameters in weights-file order; resets the Adam moments and the step counter
+bool trainer_set_params(Trainer* t, const float* host_params, int64_t count);
+bool trainer_get_params(Trainer* t, float* host_params, int64_t count, hipStream_t s);
+// One optimisation step on a device-resident batch: boards [b][2][6][7], pis [b][7], vs [b] (f32).
+// mask_seed keys the dropout masks of this step (hash of (mask_seed, layer, element): az_common.h dropout_keep).
+// apply = false computes the loss and the gradients only.  The per-step losses are accumulated on the device
+// (trainer_read_losses).  Returns false on a HIP error.
+bool trainer_step(Trainer* t, const TrainHyper& h, const float* d_boards, const float* d_pis, const float* d_vs, int b,
+                  uint64_t mask_seed, bool apply, hipStream_t s);
+// sums of (loss_pi, loss_v) over the steps since the last call with reset = true; synchronises the stream
+bool trainer_read_losses(Trainer* t, double out[2], bool reset, hipStream_t s);
+// gradients of the last step, weights-file order (running-stat slots are 0)
+bool trainer_get_grads(Trainer* t, float* host_grads, int64_t count, hipStream_t s);
+// device scratch for the caller's batch: [TRAIN_MAX_BATCH] x (84 + 7 + 1) floats
+float* trainer_batch_boards(Trainer* t);
+float* trainer_batch_pis(Trainer* t);
+float* trainer_batch_vs(Trainer* t);
+// gather rows idx[0..b) of the device-resident sample arrays into the trainer's batch scratch
+void trainer_gather(Trainer* t, const float* all_boards, const float* all_pis, const float* all_vs, const int64_t* d_idx, int b,
+                    hipStream_t s);
+
+}  // namespace az

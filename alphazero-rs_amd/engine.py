@@ -68,7 +68,8 @@ class az_arena_params(C.Structure):
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_set_option", "az_get_stats", "az_reset_stats", "az_net_set_kind",
     "az_net_init_random", "az_net_load", "az_net_save", "az_net_param_count", "az_net_set_params",
-    "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_tree_create",
+    "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_net_train_history",
+    "az_net_train_begin", "az_net_train_step", "az_net_train_end", "az_tree_create",
     "az_tree_destroy", "az_tree_reset", "az_tree_get_action_prob", "az_tree_record_evals", "az_tree_get_evals",
     "az_tree_node_counts", "az_selfplay", "az_selfplay_get_evals", "az_arena",
 ]
@@ -98,6 +99,10 @@ def load_library(path=LIB_PATH):
         "az_net_predict": (i32, [vp, i32, vp, i32, vp, vp]),
         "az_net_predict_states": (i32, [vp, i32, vp, i32, vp, vp]),
         "az_net_train": (i32, [vp, i32, i32, vp, vp, vp, i64]),
+        "az_net_train_history": (i32, [vp, vp, i32]),
+        "az_net_train_begin": (i32, [vp, i32]),
+        "az_net_train_step": (i32, [vp, vp, vp, vp, i32, u64, i32, vp, vp]),
+        "az_net_train_end": (i32, [vp, i32]),
         "az_tree_create": (i32, [vp, i32, u64, i32, i32, i32, i32, C.POINTER(vp)]),
         "az_tree_destroy": (None, [vp]),
         "az_tree_reset": (i32, [vp, vp]),
@@ -209,6 +214,31 @@ class Engine:
         p = np.ascontiguousarray(pis, dtype=np.float32)
         v = np.ascontiguousarray(vs, dtype=np.float32)
         self._check(_lib.az_net_train(self._h, prev_id, model_id, _ptr(b), _ptr(p), _ptr(v), v.size))
+        return self.train_history()
+
+    def train_history(self):
+        """[(loss_pi, loss_v)] per epoch of the last train()."""
+        n = _lib.az_net_train_history(self._h, None, 0)
+        out = np.zeros((n, 2), np.float32)
+        _lib.az_net_train_history(self._h, _ptr(out), n)
+        return [tuple(float(x) for x in r) for r in out]
+
+    def train_begin(self, prev_id):
+        self._check(_lib.az_net_train_begin(self._h, prev_id))
+
+    def train_step(self, boards, pis, vs, mask_seed=0, apply=True, want_grads=False):
+        """One optimisation step on an explicit batch -> ((loss_pi, loss_v), grads or None)."""
+        b = np.ascontiguousarray(boards, dtype=np.float32)
+        p = np.ascontiguousarray(pis, dtype=np.float32)
+        v = np.ascontiguousarray(vs, dtype=np.float32)
+        loss = np.zeros(2, np.float32)
+        grads = np.zeros(self.net_param_count(), np.float32) if want_grads else None
+        self._check(_lib.az_net_train_step(self._h, _ptr(b), _ptr(p), _ptr(v), v.size, int(mask_seed), int(bool(apply)),
+                                           _ptr(loss), _ptr(grads) if want_grads else None))
+        return (float(loss[0]), float(loss[1])), grads
+
+    def train_end(self, model_id):
+        self._check(_lib.az_net_train_end(self._h, model_id))
 
     def set_option(self, key, value):
         self._check(_lib.az_set_option(self._h, key.encode(), int(value)))

@@ -116,11 +116,27 @@ az_status az_net_get_params(az_engine* e, int32_t model_id, float* params, int64
 az_status az_net_predict(az_engine* e, int32_t model_id, const float* boards, int32_t B, float* pi, float* v);
 /* Same on canonical bitboards [B,2] (what the search feeds the net). */
 az_status az_net_predict_states(az_engine* e, int32_t model_id, const uint64_t* states, int32_t B, float* pi, float* v);
-/* NNet::train(examples, previous_model_id, model_id), src/nnet.rs:38. Not implemented inside the library (returns
- * AZ_ERR_UNSUPPORTED): training currently runs host-side (alphazero-rs_amd/trainer.py, PyTorch-ROCm autograd on the same
- * parameter vector) and uploads the result with az_net_set_params. */
+/* NNet::train(examples, previous_model_id, model_id), src/nnet.rs:38: start from the weights of prev_id, run the
+ * reference's recipe on the device (connect_four_net.py:13-21, :102-151: loss = softmax cross-entropy(pi) + mean
+ * squared error(v), Adam, BatchNorm in training mode, dropout on the two FC layers; epochs x (n / batch) steps on
+ * batches drawn with replacement), store the result under id. boards [n,2,6,7], pis [n,7], vs [n] f32, host or
+ * device. f32 throughout, GEMMs on the f32 matrix cores (csrc/az_train.hip). Hyper-parameters through
+ * az_set_option: "train_epochs" (10), "train_batch" (64, <= 256), "train_seed" (0), "train_lr_e9" (1000000 = 1e-3),
+ * "train_dropout_e6" (300000 = 0.3). Batches and dropout masks come from the build's counter RNG (B7). */
 az_status az_net_train(az_engine* e, int32_t prev_id, int32_t id, const float* boards, const float* pis,
                        const float* vs, int64_t n);
+/* (loss_pi, loss_v) averaged over each epoch of the last az_net_train: writes min(epochs, cap_epochs) pairs to out
+ * (may be NULL) and returns the number of epochs. */
+int32_t az_net_train_history(const az_engine* e, float* out, int32_t cap_epochs);
+/* Fine-grained parity entries (what az_net_train is made of). begin: load prev_id's weights, zero the Adam moments.
+ * step: ONE optimisation step on an explicit batch (2 <= b <= 256); mask_seed keys this step's dropout masks;
+ * apply = 0 leaves the weights alone (loss and gradients only, BatchNorm moving averages still advance);
+ * loss_out[2] = (loss_pi, loss_v), grads_out[az_net_param_count] = d loss / d parameter in weights-file order
+ * (both may be NULL). end: store the weights under model_id. */
+az_status az_net_train_begin(az_engine* e, int32_t prev_id);
+az_status az_net_train_step(az_engine* e, const float* boards, const float* pis, const float* vs, int32_t b,
+                            uint64_t mask_seed, int32_t apply, float* loss_out, float* grads_out);
+az_status az_net_train_end(az_engine* e, int32_t model_id);
 
 /* ---- AsyncMcts, src/async_mcts.rs:14-115 -------------------------------- */
 /* n_games independent AsyncMcts::default(reserve, num_sims, 1, max_depth, model_id, cpuct, ..)

@@ -1,0 +1,24 @@
+"""Time az_net_train (NNet::train on the device): C=512, batch 64, `steps` optimisation steps in one epoch."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from alphazero_rs_amd import engine as E
+
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+n = steps * batch
+rng = np.random.default_rng(0)
+boards = (rng.random((n, 2, 6, 7)) < 0.2).astype(np.float32)
+pis = rng.dirichlet(np.ones(7), n).astype(np.float32)
+vs = rng.choice([-1.0, 1.0], n).astype(np.float32)
+e = E.Engine(device=0, max_batch=1024, net_channels=C)
+e.net_init_random(0, seed=1)
+e.set_option("train_epochs", 1); e.set_option("train_batch", batch)
+e.train(0, 1, boards[: 4 * batch], pis[: 4 * batch], vs[: 4 * batch])     # warm-up (allocations, code load)
+t0 = time.time()
+hist = e.train(0, 1, boards, pis, vs)
+dt = time.time() - t0
+flop = 3 * 2 * 164_493_312 * (C / 512) ** 2 * batch    # ~3x the forward MACs (forward + dgrad + wgrad), C^2 scaling approx.
+print(f"C={C} batch={batch} steps={steps}: {dt / steps * 1e3:.3f} ms/step, {n / dt:.0f} samples/s, ~{flop / (dt / steps) / 1e12:.1f} TFLOP/s f32, loss {hist}")
