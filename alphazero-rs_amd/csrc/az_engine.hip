@@ -157,6 +157,7 @@ struct az_engine {
     TrainHyper hyper;
     int train_epochs = 10, train_batch = 64;       // connect_four_net.py:13-14
     uint64_t train_seed = 0;
+    int train_graph = 1;
     std::vector<float> train_history;              // (loss_pi, loss_v) mean per epoch of the last az_net_train
 };
 
@@ -349,6 +350,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "train_epochs") == 0 && value >= 1 && value <= 100000) { e->train_epochs = (int)value; return AZ_OK; }
     if (std::strcmp(key, "train_batch") == 0 && value >= 2 && value <= TRAIN_MAX_BATCH) { e->train_batch = (int)value; return AZ_OK; }
     if (std::strcmp(key, "train_seed") == 0) { e->train_seed = (uint64_t)value; return AZ_OK; }
+    if (std::strcmp(key, "train_graph") == 0 && (value == 0 || value == 1)) { e->train_graph = (int)value; if (e->trainer) trainer_set_graph(e->trainer, value != 0); return AZ_OK; }
     if (std::strcmp(key, "train_lr_e9") == 0 && value > 0) { e->hyper.lr = (float)((double)value * 1e-9); return AZ_OK; }
     if (std::strcmp(key, "train_dropout_e6") == 0 && value >= 0 && value < 1000000) { e->hyper.dropout = (float)((double)value * 1e-6); return AZ_OK; }
     return fail(e, AZ_ERR_BAD_ARGUMENT, std::string("unknown option or value: ") + key);
@@ -530,6 +532,7 @@ az_status az_net_train_begin(az_engine* e, int32_t previous_model_id) {
             const char* err = nullptr;
             e->trainer = trainer_create(e->cfg.net_channels, &err);
             if (!e->trainer) return fail(e, AZ_ERR_HIP, err ? err : "trainer_create failed");
+            trainer_set_graph(e->trainer, e->train_graph != 0);
         }
         const int64_t n = az_net_param_count(e);
         std::vector<float> p((size_t)n);
@@ -602,13 +605,10 @@ az_status az_net_train(az_engine* e, int32_t previous_model_id, int32_t model_id
                     idx[(size_t)sidx * b + j] = (int64_t)(((unsigned __int128)r * (unsigned __int128)n) >> 64);
                 }
             HIPCHK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
-            for (int64_t sidx = 0; sidx < steps; ++sidx, ++gstep) {
-                trainer_gather(t, d_boards, d_pis, d_vs, d_idx + sidx * b, b, e->stream);
-                const uint64_t mask_seed = mix64(mix64(e->train_seed ^ 0xD6E8FEB86659FD93ull) ^ gstep);
-                if (!trainer_step(t, e->hyper, trainer_batch_boards(t), trainer_batch_pis(t), trainer_batch_vs(t), b, mask_seed, true,
-                                  e->stream))
-                    return fail(e, AZ_ERR_HIP, "trainer_step failed");
-            }
+            if (!trainer_run_epoch(t, e->hyper, d_boards, d_pis, d_vs, d_idx, steps, b, mix64(e->train_seed ^ 0xD6E8FEB86659FD93ull), gstep,
+                                   e->stream))
+                return fail(e, AZ_ERR_HIP, "trainer_run_epoch failed");
+            gstep += (uint64_t)steps;
             double l[2];
             if (!trainer_read_losses(t, l, true, e->stream)) return fail(e, AZ_ERR_HIP, "trainer_read_losses failed");
             e->train_history.push_back((float)(l[0] / (double)steps));

@@ -42,8 +42,11 @@ bool trainer_get_grads(Trainer* t, float* host_grads, int64_t count, hipStream_t
 float* trainer_batch_boards(Trainer* t);
 float* trainer_batch_pis(Trainer* t);
 float* trainer_batch_vs(Trainer* t);
-// gather rows idx[0..b) of the device-resident sample arrays into the trainer's batch scratch
-void trainer_gather(Trainer* t, const float* all_boards, const float* all_pis, const float* all_vs, const int64_t* d_idx, int b,
-                    hipStream_t s);
+// One epoch of `steps` optimisation steps on device-resident samples: step i trains on rows d_idx[i*b .. i*b+b) of
+// (all_boards [n][84], all_pis [n][7], all_vs [n]); its dropout masks are keyed by mix64(seed_key ^ (gstep0 + i)).
+// The launch sequence of a step is captured in a hipGraph and replayed.  Synchronises the stream.
+bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards, const float* all_pis, const float* all_vs,
+                       const int64_t* d_idx, int64_t steps, int b, uint64_t seed_key, uint64_t gstep0, hipStream_t s);
+void trainer_set_graph(Trainer* t, bool on);      // A/B switch: replay a captured graph (default) or launch directly
 
 }  // namespace az

@@ -35,23 +35,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct GemmF32 {
     const float* A; int64_t sAm, sAk;
     const float* B; int64_t sBk, sBn;
-    float* C; int64_t ldc;
-    const float* bias;      // nullptr = none
+    float* C; int64_t ldc;  // splits == 1: the output; else partial sums [splits][M][N] (ldc = N)
+    const float* bias;      // nullptr = none (splits == 1 only)
     int M, N, K;
+    int k_per_split;        // multiple of TBK; blockIdx.z covers K range [z*k_per_split, +k_per_split)
+    int splits;
 };
 
-constexpr int TBM = 64, TBN = 64, TBK = 16, TLD = 80;
+constexpr int TBM = 64, TBN = 64, TBK = 16, TLD = 84;
 
-AZ_D float4 ld4_guard(const float* p, int64_t stride, int valid) {   // up to 4 elements p[0], p[stride], ...
+AZ_D float4 ld4_guard(const float* p, int valid) {   // up to 4 consecutive elements, zero-filled
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid >= 4 && stride == 1 && (((uintptr_t)p) & 15) == 0) return *(const float4*)p;
+    if (valid >= 4 && (((uintptr_t)p) & 15) == 0) return *(const float4*)p;
     if (valid > 0) v.x = p[0];
-    if (valid > 1) v.y = p[stride];
-    if (valid > 2) v.z = p[2 * stride];
-    if (valid > 3) v.w = p[3 * stride];
+    if (valid > 1) v.y = p[1];
+    if (valid > 2) v.z = p[2];
+    if (valid > 3) v.w = p[3];
     return v;
 }
 
+// Split-K: a GEMM whose output has few 64x64 tiles (the FCs at batch 64, conv4) is cut along K into blockIdx.z
+// slices so that every CU holds several blocks (that, not a deep software pipeline, is what hides the global-load
+// latency of the short K loop); the slices are summed in a fixed order by k_splitk_reduce, so the result does not
+// depend on scheduling.  The next tile's global loads are issued before the current tile's MFMAs.
 template <int A_K1, int B_N1>
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
     __shared__ __attribute__((aligned(16))) float As[TBK][TLD];
@@ -59,36 +65,41 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+    const int kbeg = blockIdx.z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = lane >> 4;
-    for (int k0 = 0; k0 < g.K; k0 += TBK) {
-        if (A_K1) {        // 64 rows x 16 k: thread -> row tid>>2, k quad (tid&3)*4; stored transposed
-            const int m = tid >> 2, kq = (tid & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + m < g.M) v = ld4_guard(g.A + (int64_t)(m0 + m) * g.sAm + (k0 + kq), 1, g.K - (k0 + kq));
-            As[kq + 0][m] = v.x; As[kq + 1][m] = v.y; As[kq + 2][m] = v.z; As[kq + 3][m] = v.w;
-        } else {           // 16 k x 64 rows: thread -> k tid>>4, row quad (tid&15)*4
-            const int k = tid >> 4, mq = (tid & 15) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + k < g.K) v = ld4_guard(g.A + (int64_t)(k0 + k) * g.sAk + (m0 + mq), 1, g.M - (m0 + mq));
-            *(float4*)&As[k][mq] = v;
-        }
-        if (B_N1) {
-            const int k = tid >> 4, nq = (tid & 15) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + k < g.K) v = ld4_guard(g.B + (int64_t)(k0 + k) * g.sBk + (n0 + nq), 1, g.N - (n0 + nq));
-            *(float4*)&Bs[k][nq] = v;
-        } else {
-            const int n = tid >> 2, kq = (tid & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + n < g.N) v = ld4_guard(g.B + (int64_t)(n0 + n) * g.sBn + (k0 + kq), 1, g.K - (k0 + kq));
-            Bs[kq + 0][n] = v.x; Bs[kq + 1][n] = v.y; Bs[kq + 2][n] = v.z; Bs[kq + 3][n] = v.w;
-        }
-        __syncthreads();
+    // this thread's slice of the A and B tiles: 4 consecutive elements along the contiguous direction
+    const int a_r = A_K1 ? tid >> 2 : tid >> 4, a_q = A_K1 ? (tid & 3) * 4 : (tid & 15) * 4;
+    const int b_r = B_N1 ? tid >> 4 : tid >> 2, b_q = B_N1 ? (tid & 15) * 4 : (tid & 3) * 4;
+    float4 va, vb;
+#define AZ_TLOAD(k0_)                                                                                          \
+    {                                                                                                          \
+        va = make_float4(0.f, 0.f, 0.f, 0.f);                                                                  \
+        vb = make_float4(0.f, 0.f, 0.f, 0.f);                                                                  \
+        if (A_K1) { if (m0 + a_r < g.M) va = ld4_guard(g.A + (int64_t)(m0 + a_r) * g.sAm + ((k0_) + a_q), kend - ((k0_) + a_q)); } \
+        else { if ((k0_) + a_r < kend) va = ld4_guard(g.A + (int64_t)((k0_) + a_r) * g.sAk + (m0 + a_q), g.M - (m0 + a_q)); }      \
+        if (B_N1) { if ((k0_) + b_r < kend) vb = ld4_guard(g.B + (int64_t)((k0_) + b_r) * g.sBk + (n0 + b_q), g.N - (n0 + b_q)); } \
+        else { if (n0 + b_r < g.N) vb = ld4_guard(g.B + (int64_t)(n0 + b_r) * g.sBn + ((k0_) + b_q), kend - ((k0_) + b_q)); }      \
+    }
+#define AZ_TSTORE()                                                                                            \
+    {                                                                                                          \
+        if (A_K1) { As[a_q + 0][a_r] = va.x; As[a_q + 1][a_r] = va.y; As[a_q + 2][a_r] = va.z; As[a_q + 3][a_r] = va.w; } \
+        else *(float4*)&As[a_r][a_q] = va;                                                                     \
+        if (B_N1) *(float4*)&Bs[b_r][b_q] = vb;                                                                \
+        else { Bs[b_q + 0][b_r] = vb.x; Bs[b_q + 1][b_r] = vb.y; Bs[b_q + 2][b_r] = vb.z; Bs[b_q + 3][b_r] = vb.w; } \
+    }
+    if (kbeg < kend) {
+        AZ_TLOAD(kbeg);
+        AZ_TSTORE();
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += TBK) {
+        const bool more = k0 + TBK < kend;
+        if (more) AZ_TLOAD(k0 + TBK);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int k = kk * 4 + fk;
@@ -101,7 +112,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
             acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, a1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
+        if (more) AZ_TSTORE();
+        __syncthreads();
     }
+#undef AZ_TLOAD
+#undef AZ_TSTORE
+    float* cbase = g.splits > 1 ? g.C + (int64_t)blockIdx.z * g.M * g.N : g.C;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 32 + i * 16 + fr;
@@ -109,12 +125,58 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 32 + j * 16 + fk * 4;
-            float* c = g.C + (int64_t)m * g.ldc + n;
+            float* c = cbase + (int64_t)m * g.ldc + n;
+            if (n + 3 < g.N && ((((uintptr_t)c) & 15) == 0)) {
+                float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                if (g.bias) { const float4 bv = *(const float4*)(g.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+                *(float4*)c = o;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (n + q < g.N) c[q] = acc[i][j][q] + (g.bias ? g.bias[n + q] : 0.0f);
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < g.N) c[q] = acc[i][j][q] + (g.bias ? g.bias[n + q] : 0.0f);
+            }
         }
     }
+}
+
+// C[m][n] = sum over slices (in slice order) of partial[z][m][n] (+ bias[n])
+__global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int64_t ldc,
+                                const float* __restrict__ bias) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const int64_t m = i / N;
+        float s = partial[i];
+        for (int z = 1; z < splits; ++z) s += partial[(int64_t)z * total + i];
+        C[m * ldc + n] = s + (bias ? bias[n] : 0.0f);
+    }
+}
+
+// what changes from step to step lives in device memory, so the launch sequence of a step is the same every time
+struct StepState {
+    uint64_t mask_seed;     // keys the dropout masks of this step
+    float bc1, sqrt_bc2;    // Adam bias corrections 1 - beta1^t, sqrt(1 - beta2^t)
+    int64_t idx_offset;     // first row of this step's batch in the epoch's index array
+};
+
+// epoch driver state: k_step_advance derives each step's StepState on the device
+struct EpochCounters {
+    uint64_t seed_key;      // mix64(train_seed ^ constant)
+    uint64_t gstep;         // global step index (keys the dropout masks)
+    int64_t epoch_step;     // step index inside the current epoch
+    double beta1, beta2;
+    double pow1, pow2;      // beta1^t, beta2^t as running products (the host keeps the same products: Trainer::pow1/2)
+};
+__global__ void k_step_advance(StepState* st, EpochCounters* c, int b) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->mask_seed = mix64(c->seed_key ^ c->gstep);
+    c->pow1 *= c->beta1;
+    c->pow2 *= c->beta2;
+    st->bc1 = (float)(1.0 - c->pow1);
+    st->sqrt_bc2 = sqrtf((float)(1.0 - c->pow2));
+    st->idx_offset = c->epoch_step * b;
+    c->gstep += 1;
+    c->epoch_step += 1;
 }
 
 // ---- data movement -------------------------------------------------------------------------------------------
@@ -170,11 +232,12 @@ __global__ void k_col2im(const float* __restrict__ dcol, float* __restrict__ din
 
 __global__ void k_gather_batch(const float* __restrict__ all_boards, const float* __restrict__ all_pis,
                                const float* __restrict__ all_vs, const int64_t* __restrict__ idx, int b,
-                               float* __restrict__ boards, float* __restrict__ pis, float* __restrict__ vs) {
+                               float* __restrict__ boards, float* __restrict__ pis, float* __restrict__ vs,
+                               const StepState* __restrict__ st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b * 92) return;
     const int j = i / 92, f = i % 92;
-    const int64_t src = idx[j];
+    const int64_t src = idx[st->idx_offset + j];
     if (f < 84) boards[(size_t)j * 84 + f] = all_boards[(size_t)src * 84 + f];
     else if (f < 91) pis[(size_t)j * 7 + (f - 84)] = all_pis[(size_t)src * 7 + (f - 84)];
     else vs[j] = all_vs[src];
@@ -193,33 +256,34 @@ struct BnLayer {
     uint32_t drop_layer;    // dropout stream id; keep_thresh = 0 -> no dropout
     uint32_t keep_thresh;
     float drop_scale;
-    uint64_t mask_seed;
 };
 
-AZ_D float bn_grad_in(const BnLayer& L, int r, int c, float mean, float invstd, float gamma, float beta, float& xh) {
+
+AZ_D float bn_grad_in(const BnLayer& L, uint64_t mask_seed, int r, int c, float mean, float invstd, float gamma, float beta, float& xh) {
     const size_t i = (size_t)r * L.N + c;
     xh = (L.z[i] - mean) * invstd;
     const float y = gamma * xh + beta;
     float g = y > 0.0f ? L.grad_out[i] : 0.0f;
-    if (L.keep_thresh) g = dropout_keep(L.mask_seed, L.drop_layer, i, L.keep_thresh) ? g * L.drop_scale : 0.0f;
+    if (L.keep_thresh) g = dropout_keep(mask_seed, L.drop_layer, i, L.keep_thresh) ? g * L.drop_scale : 0.0f;
     return g;
 }
 
 // stage 1 of a column reduction: block (64 columns x 4 row lanes) reduces rows [blockIdx.y*rpb, +rpb) and writes
-// partial[blockIdx.y][column][2] (f64); KIND 0: (sum z, sum z^2); 1: BN backward (sum g, sum g*xhat); 2: (sum x, -)
+// partial[blockIdx.y][column][2] (f64); KIND 0: (sum z, sum z^2); 1: BN backward (sum g, sum g*xhat)
 template <int KIND>
-__global__ __launch_bounds__(256) void k_colreduce(const BnLayer L, const float* __restrict__ x, int rpb, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_colreduce(const BnLayer L, int rpb, double* __restrict__ partial,
+                                                   const StepState* __restrict__ st) {
     __shared__ double red[4][64][2];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
     double s0 = 0.0, s1 = 0.0;
     if (c < L.N) {
         float mean = 0.f, invstd = 0.f, gamma = 0.f, beta = 0.f;
-        if (KIND == 1) { mean = L.mean[c]; invstd = L.invstd[c]; gamma = L.gamma[c]; beta = L.beta[c]; }
+        uint64_t mask_seed = 0;
+        if (KIND == 1) { mean = L.mean[c]; invstd = L.invstd[c]; gamma = L.gamma[c]; beta = L.beta[c]; if (L.keep_thresh) mask_seed = st->mask_seed; }
         for (int r = r0 + ty; r < r1; r += 4) {
-            if (KIND == 0) { const float v = x[(size_t)r * L.N + c]; s0 += v; s1 += (double)v * v; }
-            else if (KIND == 1) { float xh; const float g = bn_grad_in(L, r, c, mean, invstd, gamma, beta, xh); s0 += g; s1 += (double)g * xh; }
-            else s0 += x[(size_t)r * L.N + c];
+            if (KIND == 0) { const float v = L.z[(size_t)r * L.N + c]; s0 += v; s1 += (double)v * v; }
+            else { float xh; const float g = bn_grad_in(L, mask_seed, r, c, mean, invstd, gamma, beta, xh); s0 += g; s1 += (double)g * xh; }
         }
     }
     red[ty][threadIdx.x & 63][0] = s0;
@@ -234,66 +298,68 @@ __global__ __launch_bounds__(256) void k_colreduce(const BnLayer L, const float*
     }
 }
 
-// stage 2, forward statistics: batch mean / biased variance -> mean, invstd; moving averages updated in place
-// (moving = momentum*moving + (1-momentum)*batch, the variance with Bessel's correction, as F.batch_norm does)
-__global__ void k_bn_stats_finish(const double* __restrict__ partial, int nparts, int M, int N, float eps, float momentum,
-                                  float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                  float* __restrict__ run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int p = 0; p < nparts; ++p) { s0 += partial[((size_t)p * N + c) * 2]; s1 += partial[((size_t)p * N + c) * 2 + 1]; }
-    const double mu = s0 / M;
-    double var = s1 / M - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    const double unbiased = M > 1 ? var * M / (M - 1) : var;
-    run_mean[c] = momentum * run_mean[c] + (1.0f - momentum) * (float)mu;
-    run_var[c] = momentum * run_var[c] + (1.0f - momentum) * (float)unbiased;
-}
+// Stage 2 is folded into the consumers: every block of the apply kernels first sums the partials of its 64 columns
+// in slice order (<= 32 slices: cheap, and the same result in every block), so there is no separate finish launch.
 
-// stage 2, backward: dgamma = sum g*xhat, dbeta = sum g (also kept in sums[N][2] for k_bn_bwd_apply)
-__global__ void k_bn_bwd_finish(const double* __restrict__ partial, int nparts, int N, float* __restrict__ sums,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int p = 0; p < nparts; ++p) { s0 += partial[((size_t)p * N + c) * 2]; s1 += partial[((size_t)p * N + c) * 2 + 1]; }
-    sums[2 * c] = (float)s0; sums[2 * c + 1] = (float)s1;
-    dbeta[c] = (float)s0; dgamma[c] = (float)s1;
-}
-
-__global__ void k_colsum_finish(const double* __restrict__ partial, int nparts, int N, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    double s0 = 0.0;
-    for (int p = 0; p < nparts; ++p) s0 += partial[((size_t)p * N + c) * 2];
-    out[c] = (float)s0;
-}
-
-// a = dropout(relu(gamma * xhat + beta))
-__global__ void k_bn_apply(const BnLayer L) {
-    const int64_t total = (int64_t)L.M * L.N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % L.N);
-        const float xh = (L.z[i] - L.mean[c]) * L.invstd[c];
-        float y = fmaxf(L.gamma[c] * xh + L.beta[c], 0.0f);
-        if (L.keep_thresh) y = dropout_keep(L.mask_seed, L.drop_layer, (uint64_t)i, L.keep_thresh) ? y * L.drop_scale : 0.0f;
+// a = dropout(relu(gamma * xhat + beta)).  grid (N/64, row blocks of `rpb` rows); block = 64 columns x 4 row lanes.
+// Batch mean / biased variance -> mean, invstd (kept for the backward pass); the blockIdx.y == 0 blocks also update
+// the moving averages in place (moving = momentum*moving + (1-momentum)*batch, the variance with Bessel's
+// correction, as F.batch_norm does).
+__global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double* __restrict__ partial, int nparts, int rpb, float eps,
+                                                  float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                  const StepState* __restrict__ st) {
+    __shared__ float s_mean[64], s_inv[64];
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, ty = threadIdx.x >> 6;
+    if (ty == 0 && c < L.N) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int p = 0; p < nparts; ++p) { s0 += partial[((size_t)p * L.N + c) * 2]; s1 += partial[((size_t)p * L.N + c) * 2 + 1]; }
+        const double mu = s0 / L.M;
+        double var = s1 / L.M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)mu, inv = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[cl] = mean; s_inv[cl] = inv;
+        if (blockIdx.y == 0) {
+            L.mean[c] = mean; L.invstd[c] = inv;
+            const double unbiased = L.M > 1 ? var * L.M / (L.M - 1) : var;
+            run_mean[c] = momentum * run_mean[c] + (1.0f - momentum) * (float)mu;
+            run_var[c] = momentum * run_var[c] + (1.0f - momentum) * (float)unbiased;
+        }
+    }
+    __syncthreads();
+    if (c >= L.N) return;
+    const float mean = s_mean[cl], inv = s_inv[cl], gamma = L.gamma[c], beta = L.beta[c];
+    const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
+    const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
+    for (int r = r0 + ty; r < r1; r += 4) {
+        const size_t i = (size_t)r * L.N + c;
+        float y = fmaxf(gamma * ((L.z[i] - mean) * inv) + beta, 0.0f);
+        if (L.keep_thresh) y = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i, L.keep_thresh) ? y * L.drop_scale : 0.0f;
         L.out[i] = y;
     }
 }
 
-// dz = gamma * invstd * (g - (dbeta + xhat * dgamma) / M)
-__global__ void k_bn_bwd_apply(const BnLayer L, const float* __restrict__ sums) {
-    const int64_t total = (int64_t)L.M * L.N;
+// dz = gamma * invstd * (g - (dbeta + xhat * dgamma) / M), dgamma = sum g*xhat, dbeta = sum g (same grid as k_bn_apply)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnLayer L, const double* __restrict__ partial, int nparts, int rpb,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      const StepState* __restrict__ st) {
+    __shared__ float s_db[64], s_dg[64];
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, ty = threadIdx.x >> 6;
+    if (ty == 0 && c < L.N) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int p = 0; p < nparts; ++p) { s0 += partial[((size_t)p * L.N + c) * 2]; s1 += partial[((size_t)p * L.N + c) * 2 + 1]; }
+        s_db[cl] = (float)s0; s_dg[cl] = (float)s1;
+        if (blockIdx.y == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+    }
+    __syncthreads();
+    if (c >= L.N) return;
+    const float mean = L.mean[c], invstd = L.invstd[c], gamma = L.gamma[c], beta = L.beta[c], db = s_db[cl], dg = s_dg[cl];
     const float inv_m = 1.0f / (float)L.M;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % L.N), r = (int)(i / L.N);
-        const float mean = L.mean[c], invstd = L.invstd[c], gamma = L.gamma[c];
+    const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
+    const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
+    for (int r = r0 + ty; r < r1; r += 4) {
         float xh;
-        const float g = bn_grad_in(L, r, c, mean, invstd, gamma, L.beta[c], xh);
-        L.out[i] = gamma * invstd * (g - (sums[2 * c] + xh * sums[2 * c + 1]) * inv_m);
+        const float g = bn_grad_in(L, mask_seed, r, c, mean, invstd, gamma, beta, xh);
+        L.out[(size_t)r * L.N + c] = gamma * invstd * (g - (db + xh * dg) * inv_m);
     }
 }
 
@@ -375,7 +441,8 @@ __global__ void k_heads_bwd(const float* __restrict__ a, const float* __restrict
 
 // ---- Adam (torch.optim.Adam form: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)) ------------------------------------
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                       int64_t n, float lr, float b1, float b2, float eps, float bc1, float sqrt_bc2) {
+                       int64_t n, float lr, float b1, float b2, float eps, const StepState* __restrict__ st) {
+    const float bc1 = st->bc1, sqrt_bc2 = st->sqrt_bc2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -400,7 +467,13 @@ struct Trainer {
     float *dz = nullptr, *dact = nullptr, *dcol = nullptr;     // backward scratch (largest layer)
     float *sums = nullptr, *dhead = nullptr, *sample_loss = nullptr, *logits = nullptr;
     double *partial = nullptr, *loss_totals = nullptr;
+    float* splitk = nullptr;           // partial sums of the split-K GEMMs
+    StepState* step_state = nullptr;
+    EpochCounters* counters = nullptr;
+    bool use_graph = true;
+    size_t splitk_floats = 0;
     int64_t step = 0;
+    double pow1 = 1.0, pow2 = 1.0;     // beta1^step, beta2^step
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr;
         if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
@@ -444,6 +517,10 @@ Trainer* trainer_create(int channels, const char** err) {
     ok &= (t->sample_loss = t->dalloc<float>(B * 2)) != nullptr;
     ok &= (t->partial = t->dalloc<double>((size_t)RED_PARTS * std::max<size_t>(C, 1024) * 2)) != nullptr;
     ok &= (t->loss_totals = t->dalloc<double>(2)) != nullptr;
+    ok &= (t->step_state = t->dalloc<StepState>(1)) != nullptr;
+    ok &= (t->counters = t->dalloc<EpochCounters>(1)) != nullptr;
+    t->splitk_floats = (size_t)32 << 20;      // 128 MiB
+    ok &= (t->splitk = t->dalloc<float>(t->splitk_floats)) != nullptr;
     if (!ok) { if (err) *err = "hipMalloc failed for the trainer workspace"; trainer_destroy(t); return nullptr; }
     (void)hipMemset(t->loss_totals, 0, 2 * sizeof(double));
     return t;
@@ -463,6 +540,7 @@ bool trainer_set_params(Trainer* t, const float* host_params, int64_t count) {
         hipMemset(t->grads, 0, bytes) != hipSuccess || hipMemset(t->loss_totals, 0, 2 * sizeof(double)) != hipSuccess)
         return false;
     t->step = 0;
+    t->pow1 = t->pow2 = 1.0;
     return true;
 }
 
@@ -490,46 +568,64 @@ float* trainer_batch_boards(Trainer* t) { return t->bboards; }
 float* trainer_batch_pis(Trainer* t) { return t->bpis; }
 float* trainer_batch_vs(Trainer* t) { return t->bvs; }
 
-void trainer_gather(Trainer* t, const float* all_boards, const float* all_pis, const float* all_vs, const int64_t* d_idx, int b,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_batch, dim3((b * 92 + 255) / 256), dim3(256), 0, s, all_boards, all_pis, all_vs, d_idx, b,
-                       t->bboards, t->bpis, t->bvs);
-}
-
 namespace {
 
 inline dim3 grid1(int64_t n, int block = 256, int cap = 4096) { return dim3((unsigned)std::min<int64_t>((n + block - 1) / block, cap)); }
 
+// split-K plan + launch (ws = workspace of ws_floats floats for the partial sums)
+template <int A_K1, int B_N1>
+void launch_gemm_f32(GemmF32 g, float* ws, size_t ws_floats, hipStream_t s) {
+    const int tiles = ((g.M + TBM - 1) / TBM) * ((g.N + TBN - 1) / TBN);
+    const int ksteps = (g.K + TBK - 1) / TBK;
+    int splits = std::max(1, std::min(1536 / std::max(tiles, 1), ksteps / 8));
+    while (splits > 1 && (size_t)splits * g.M * g.N > ws_floats) --splits;
+    int k_per = ((ksteps + splits - 1) / splits) * TBK;
+    splits = (g.K + k_per - 1) / k_per;
+    g.k_per_split = k_per;
+    g.splits = splits;
+    float* out = g.C;
+    const int64_t ldc = g.ldc;
+    const float* bias = g.bias;
+    if (splits > 1) { g.C = ws; g.ldc = g.N; g.bias = nullptr; }
+    hipLaunchKernelGGL((k_gemm_f32<A_K1, B_N1>), dim3((g.N + TBN - 1) / TBN, (g.M + TBM - 1) / TBM, splits), dim3(256), 0, s, g);
+    if (splits > 1)
+        hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)g.M * g.N), dim3(256), 0, s, ws, splits, g.M, g.N, out, ldc, bias);
+}
+
 // C[M][N] = A[M][K] W[K][N] + bias
-void gemm_nn(const float* A, int64_t lda, const float* W, float* Cm, const float* bias, int M, int N, int K, hipStream_t s) {
-    GemmF32 g{A, lda, 1, W, N, 1, Cm, N, bias, M, N, K};
-    hipLaunchKernelGGL((k_gemm_f32<1, 1>), dim3((N + TBN - 1) / TBN, (M + TBM - 1) / TBM), dim3(256), 0, s, g);
+void gemm_nn(const float* A, int64_t lda, const float* W, float* Cm, const float* bias, int M, int N, int K, float* ws, size_t wsn,
+             hipStream_t s) {
+    GemmF32 g{A, lda, 1, W, N, 1, Cm, N, bias, M, N, K, 0, 1};
+    launch_gemm_f32<1, 1>(g, ws, wsn, s);
 }
 // dA[M][K] = dZ[M][N] W[K][N]^T   (contraction over n; "B"(n, k) = W[k*N + n])
-void gemm_nt(const float* dZ, const float* W, float* dA, int64_t ldda, int M, int N, int K, hipStream_t s) {
-    GemmF32 g{dZ, N, 1, W, 1, N, dA, ldda, nullptr, M, K, N};
-    hipLaunchKernelGGL((k_gemm_f32<1, 0>), dim3((K + TBN - 1) / TBN, (M + TBM - 1) / TBM), dim3(256), 0, s, g);
+void gemm_nt(const float* dZ, const float* W, float* dA, int64_t ldda, int M, int N, int K, float* ws, size_t wsn, hipStream_t s) {
+    GemmF32 g{dZ, N, 1, W, 1, N, dA, ldda, nullptr, M, K, N, 0, 1};
+    launch_gemm_f32<1, 0>(g, ws, wsn, s);
 }
 // dW[K][N] = A[M][K]^T dZ[M][N]   (contraction over rows; "A"(k, r) = A[r*lda + k])
-void gemm_tn(const float* A, int64_t lda, const float* dZ, float* dW, int M, int N, int K, hipStream_t s) {
-    GemmF32 g{A, 1, lda, dZ, N, 1, dW, N, nullptr, K, N, M};
-    hipLaunchKernelGGL((k_gemm_f32<0, 1>), dim3((N + TBN - 1) / TBN, (K + TBM - 1) / TBM), dim3(256), 0, s, g);
+void gemm_tn(const float* A, int64_t lda, const float* dZ, float* dW, int M, int N, int K, float* ws, size_t wsn, hipStream_t s) {
+    GemmF32 g{A, 1, lda, dZ, N, 1, dW, N, nullptr, K, N, M, 0, 1};
+    launch_gemm_f32<0, 1>(g, ws, wsn, s);
 }
 
 int red_parts(int M) { return std::max(1, std::min(RED_PARTS, (M + 63) / 64)); }
 
 }  // namespace
 
-bool trainer_step(Trainer* t, const TrainHyper& h, const float* d_boards, const float* d_pis, const float* d_vs, int b,
-                  uint64_t mask_seed, bool apply, hipStream_t s) {
-    if (!t || b <= 1 || b > TRAIN_MAX_BATCH) return false;
+namespace {
+
+// every kernel of one optimisation step, in order, on stream s (no host synchronisation: capturable in a hipGraph)
+void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const float* d_pis, const float* d_vs, int b, bool apply,
+                  hipStream_t s) {
     const int C = t->C;
     const Layout& L = t->L;
     float* P = t->params;
     float* G = t->grads;
+    const StepState* st = t->step_state;
     struct LayerDef { const float* A; int64_t lda; int M, K, N; int64_t w, bias, bn; bool drop; };
     const int rows[6] = {b * 42, b * 42, b * 20, b * 6, b, b};
-    LayerDef ld[6] = {
+    const LayerDef ld[6] = {
         {t->col[0], 20, rows[0], 18, C, L.conv_w[0], L.conv_b[0], L.conv_bn[0], false},
         {t->col[1], 9ll * C, rows[1], 9 * C, C, L.conv_w[1], L.conv_b[1], L.conv_bn[1], false},
         {t->col[2], 9ll * C, rows[2], 9 * C, C, L.conv_w[2], L.conv_b[2], L.conv_bn[2], false},
@@ -549,20 +645,19 @@ bool trainer_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         d.drop_layer = (uint32_t)l;
         d.keep_thresh = ld[l].drop ? keep_thresh : 0u;
         d.drop_scale = drop_scale;
-        d.mask_seed = mask_seed;
         return d;
     };
+    constexpr int APPLY_ROWS = 64;      // rows per block of the apply kernels
     // ---- forward ----
     hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
-        gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, s);
+        gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
         BnLayer bn = bn_desc(l, t->a[l], nullptr);
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
-        hipLaunchKernelGGL((k_colreduce<0>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, bn, t->z[l], rpb, t->partial);
-        hipLaunchKernelGGL(k_bn_stats_finish, dim3((d.N + 255) / 256), dim3(256), 0, s, t->partial, parts, d.M, d.N, h.bn_eps,
-                           h.bn_momentum, t->mean[l], t->invstd[l], P + d.bn + 2 * d.N, P + d.bn + 3 * d.N);
-        hipLaunchKernelGGL(k_bn_apply, grid1((int64_t)d.M * d.N), dim3(256), 0, s, bn);
+        hipLaunchKernelGGL((k_colreduce<0>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
+        hipLaunchKernelGGL(k_bn_apply, dim3((d.N + 63) / 64, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
+                           APPLY_ROWS, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
         if (l == 0) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 42 * 9 * C / 4), dim3(256), 0, s, t->a[0], t->col[1], b, 6, 7, C, 1);
         if (l == 1) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 20 * 9 * C / 4), dim3(256), 0, s, t->a[1], t->col[2], b, 6, 7, C, 0);
         if (l == 2) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 6 * 9 * C / 4), dim3(256), 0, s, t->a[2], t->col[3], b, 4, 5, C, 0);
@@ -578,31 +673,78 @@ bool trainer_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         // t->dact holds d loss / d a[l]  ->  dz (through dropout, ReLU and BatchNorm)
         BnLayer bn = bn_desc(l, t->dz, t->dact);
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
-        hipLaunchKernelGGL((k_colreduce<1>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, bn, (const float*)nullptr, rpb, t->partial);
-        hipLaunchKernelGGL(k_bn_bwd_finish, dim3((d.N + 255) / 256), dim3(256), 0, s, t->partial, parts, d.N, t->sums, G + d.bn,
-                           G + d.bn + d.N);
-        hipLaunchKernelGGL(k_bn_bwd_apply, grid1((int64_t)d.M * d.N), dim3(256), 0, s, bn, t->sums);
-        // bias gradient = column sums of dz (zero up to rounding under BatchNorm; kept, as autograd keeps it)
-        BnLayer cs{}; cs.M = d.M; cs.N = d.N;
-        hipLaunchKernelGGL((k_colreduce<2>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, cs, t->dz, rpb, t->partial);
-        hipLaunchKernelGGL(k_colsum_finish, dim3((d.N + 255) / 256), dim3(256), 0, s, t->partial, parts, d.N, G + d.bias);
-        gemm_tn(d.A, d.lda, t->dz, G + d.w, d.M, d.N, d.K, s);
+        hipLaunchKernelGGL((k_colreduce<1>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
+        hipLaunchKernelGGL(k_bn_bwd_apply, dim3((d.N + 63) / 64, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial,
+                           parts, APPLY_ROWS, G + d.bn, G + d.bn + d.N, st);
+        // The gradient of a bias in front of a BatchNorm is identically zero (the batch mean absorbs it); the kernels
+        // leave those slots at 0 instead of the rounding residue a column sum of dz would give, which Adam would
+        // turn into a random walk of size lr.
+        gemm_tn(d.A, d.lda, t->dz, G + d.w, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
         if (l == 0) break;
         if (l >= 4) {
-            gemm_nt(t->dz, P + d.w, t->dact, d.K, d.M, d.N, d.K, s);      // FC: d a[l-1] directly ([b][K])
+            gemm_nt(t->dz, P + d.w, t->dact, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);      // FC: d a[l-1] directly
         } else {
-            gemm_nt(t->dz, P + d.w, t->dcol, d.K, d.M, d.N, d.K, s);
+            gemm_nt(t->dz, P + d.w, t->dcol, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
             const int H = l == 3 ? 4 : 6, W = l == 3 ? 5 : 7, pad = l == 1 ? 1 : 0;
             hipLaunchKernelGGL(k_col2im, grid1((int64_t)b * H * W * C / 4), dim3(256), 0, s, t->dcol, t->dact, b, H, W, C, pad);
         }
     }
-    if (apply) {
-        t->step += 1;
-        const float bc1 = 1.0f - std::pow(h.beta1, (float)t->step), bc2 = 1.0f - std::pow(h.beta2, (float)t->step);
-        hipLaunchKernelGGL(k_adam, grid1(L.total), dim3(256), 0, s, P, G, t->m, t->v, L.total, h.lr, h.beta1, h.beta2, h.adam_eps, bc1,
-                           std::sqrt(bc2));
-    }
+    if (apply)
+        hipLaunchKernelGGL(k_adam, grid1(L.total), dim3(256), 0, s, P, G, t->m, t->v, L.total, h.lr, h.beta1, h.beta2, h.adam_eps, st);
+}
+
+}  // namespace
+
+bool trainer_step(Trainer* t, const TrainHyper& h, const float* d_boards, const float* d_pis, const float* d_vs, int b,
+                  uint64_t mask_seed, bool apply, hipStream_t s) {
+    if (!t || b <= 1 || b > TRAIN_MAX_BATCH) return false;
+    StepState st{};
+    st.mask_seed = mask_seed;
+    const double p1 = t->pow1 * (double)h.beta1, p2 = t->pow2 * (double)h.beta2;
+    st.bc1 = (float)(1.0 - p1);
+    st.sqrt_bc2 = sqrtf((float)(1.0 - p2));
+    st.idx_offset = 0;
+    if (hipMemcpyAsync(t->step_state, &st, sizeof st, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+    enqueue_step(t, h, d_boards, d_pis, d_vs, b, apply, s);
+    if (apply) { t->step += 1; t->pow1 = p1; t->pow2 = p2; }
     return hipGetLastError() == hipSuccess;
 }
+
+bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards, const float* all_pis, const float* all_vs,
+                       const int64_t* d_idx, int64_t steps, int b, uint64_t seed_key, uint64_t gstep0, hipStream_t s) {
+    if (!t || b <= 1 || b > TRAIN_MAX_BATCH || steps <= 0) return false;
+    EpochCounters c{seed_key, gstep0, 0, (double)h.beta1, (double)h.beta2, t->pow1, t->pow2};
+    if (hipMemcpyAsync(t->counters, &c, sizeof c, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+    if (hipStreamSynchronize(s) != hipSuccess) return false;      // `c` is a stack object
+    auto one_step = [&]() {
+        hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, t->step_state, t->counters, b);
+        hipLaunchKernelGGL(k_gather_batch, dim3((b * 92 + 255) / 256), dim3(256), 0, s, all_boards, all_pis, all_vs, d_idx, b, t->bboards,
+                           t->bpis, t->bvs, (const StepState*)t->step_state);
+        enqueue_step(t, h, t->bboards, t->bpis, t->bvs, b, true, s);
+    };
+    // the step's ~60 launches are captured once and replayed: the epoch is launch-bound otherwise
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool graphed = false;
+    if (t->use_graph && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        one_step();
+        if (hipStreamEndCapture(s, &graph) == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess)
+            graphed = true;
+    }
+    (void)hipGetLastError();
+    bool ok = true;
+    for (int64_t i = 0; i < steps && ok; ++i) {
+        if (graphed) ok = hipGraphLaunch(exec, s) == hipSuccess;
+        else one_step();
+    }
+    ok = ok && hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess;
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    t->step += steps;
+    for (int64_t i = 0; i < steps; ++i) { t->pow1 *= (double)h.beta1; t->pow2 *= (double)h.beta2; }
+    return ok;
+}
+
+void trainer_set_graph(Trainer* t, bool on) { if (t) t->use_graph = on; }
 
 }  // namespace az
