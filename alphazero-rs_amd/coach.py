@@ -7,10 +7,15 @@ accept iff nwins + pwins > 0 and nwins / (nwins + pwins) >= update_threshold (:3
 are ONE engine call each (az_selfplay / az_arena); episodes shard across ranks by global game id when a process
 group is active, the tuples are gathered once per iteration (alphazero-rs_amd/dist.py) and gradients are all-reduced.
 
+NNet::train is the engine's own (az_net_train, csrc/az_train.hip) unless a `trainer` object is passed (the PyTorch
+autograd trainer of alphazero-rs_amd/trainer.py, which all-reduces gradients across ranks; with the engine's trainer
+every rank trains on the same gathered samples and, the kernels being deterministic, ends with the same weights).
+The C++ host (include/az_host.hpp `Coach`) runs the same sequence with the same seeds and writes the same files.
+
 On-disk formats (the reference's are bincode / TF checkpoints, src/coach.rs:159-167 with defect A14; these are the
 build's own, documented here):
-  <dir>/<iter>.examples   numpy .npz: lens [H] int64 (samples per history entry), boards [N,2,6,7] f32,
-                          pis [N,7] f32, vs [N] f32 -- the whole `history` deque, oldest entry first
+  <dir>/<iter>.examples   "AZEX0001": char magic[8]; int64 H; int64 lens[H] (samples per history entry);
+                          f32 boards[N][2][6][7]; f32 pis[N][7]; f32 vs[N] -- the whole `history` deque, oldest first
   <dir>/<model_id>.aznet  weights file of az_net_save
 Resume picks the largest numeric stem, as Coach::setup does (:55-81); non-numeric files are ignored instead of
 panicking.
@@ -47,12 +52,7 @@ class Coach:
         stems = [int(f[:-9]) for f in os.listdir(self.dir) if f.endswith(".examples") and f[:-9].isdigit()]
         if stems:                                                      # src/coach.rs:55-81
             it = max(stems)
-            z = np.load(os.path.join(self.dir, f"{it}.examples"), allow_pickle=False)
-            o = 0
-            for n in z["lens"]:
-                n = int(n)
-                self.history.append((z["boards"][o:o + n], z["pis"][o:o + n], z["vs"][o:o + n]))
-                o += n
+            self.history.extend(load_examples(os.path.join(self.dir, f"{it}.examples")))
             self.start_iteration = it + 1
         return self
 
@@ -65,11 +65,8 @@ class Coach:
 
     def save_train_examples(self, iteration):
         """src/coach.rs:159-167 (A14 repaired: <dir>/<iter>.examples, not an absolute path)."""
-        lens = np.array([h[2].shape[0] for h in self.history], np.int64)
-        cat = lambda i, shp: (np.concatenate([h[i] for h in self.history]) if len(self.history) else np.zeros(shp, np.float32))
         path = os.path.join(self.dir, f"{iteration}.examples")
-        with open(path, "wb") as f:
-            np.savez(f, lens=lens, boards=cat(0, (0, 2, 6, 7)), pis=cat(1, (0, 7)), vs=cat(2, (0,)))
+        save_examples(path, self.history)
         return path
 
     def execute_episodes(self, model_id, iteration, seed):
@@ -113,7 +110,6 @@ class Coach:
         """src/coach.rs:169-396.  Engine model slots: `model_id` is the current net, `model_id + 1` the candidate.
         Returns a list of per-iteration dicts (wins, accepted, losses)."""
         rank, world = self._world()
-        rng = np.random.default_rng(seed)
         report = []
         for iteration in range(self.start_iteration, self.start_iteration + self.num_iters):
             if not skip_first_play or iteration > self.start_iteration:
@@ -129,11 +125,16 @@ class Coach:
             allp = np.concatenate([h[1] for h in self.history])
             allv = np.concatenate([h[2] for h in self.history])
             assert allv.shape[0] > 0                                    # :305
-            perm = rng.permutation(allv.shape[0])                       # :296-297 shuffle
+            perm = shuffle_permutation(allv.shape[0], seed, iteration)  # :296-297 shuffle
             allb, allp, allv = allb[perm], allp[perm], allv[perm]
-            prev = self.engine.net_get_params(model_id)
-            new = self.trainer.train(prev, allb, allp, allv, seed=seed + iteration)   # :329 -> NNet::train(samples, id, id+1)
-            self.engine.net_set_params(model_id + 1, new)
+            if self.trainer is None:                                    # :329 -> NNet::train(samples, id, id + 1)
+                self.engine.set_option("train_seed", seed + iteration)
+                losses = self.engine.train(model_id, model_id + 1, allb, allp, allv)
+            else:
+                prev = self.engine.net_get_params(model_id)
+                new = self.trainer.train(prev, allb, allp, allv, seed=seed + iteration)
+                self.engine.net_set_params(model_id + 1, new)
+                losses = list(self.trainer.history)
             if rank == 0:
                 self.engine.net_save(model_id + 1, os.path.join(self.dir, f"{model_id + 1}.aznet"))
             # arena: new (first listed) vs old, both seatings (:333-375); games sharded by global index across ranks,
@@ -163,7 +164,7 @@ class Coach:
             accepted = not (pwins + nwins == 0 or nwins / (pwins + nwins) < self.update_threshold)   # :383-390
             self.log("ACCEPTING NEW MODEL" if accepted else "REJECTING NEW MODEL")
             report.append({"iteration": iteration, "samples": int(allv.shape[0]), "nwins": nwins, "pwins": pwins,
-                           "draws": draws, "accepted": accepted, "losses": list(self.trainer.history), "model_id": model_id})
+                           "draws": draws, "accepted": accepted, "losses": losses, "model_id": model_id})
             if accepted:
                 model_id += 1
         self.model_id = model_id
@@ -180,3 +181,51 @@ def states_to_boards(states):
             out[:, 0, r, c] = (states[:, 0] & bit) != 0
             out[:, 1, r, c] = (states[:, 1] & bit) != 0
     return out
+
+
+def save_examples(path, history):
+    """`history`: iterable of (boards [n,2,6,7], pis [n,7], vs [n]) -> "AZEX0001" file (module docstring)."""
+    history = list(history)
+    with open(path, "wb") as f:
+        f.write(b"AZEX0001")
+        np.array([len(history)] + [h[2].shape[0] for h in history], np.int64).tofile(f)
+        for i in range(3):
+            for h in history:
+                np.ascontiguousarray(h[i], np.float32).tofile(f)
+
+
+def load_examples(path):
+    with open(path, "rb") as f:
+        if f.read(8) != b"AZEX0001":
+            raise ValueError(f"{path}: not an AZEX0001 examples file")
+        H = int(np.fromfile(f, np.int64, 1)[0])
+        lens = [int(x) for x in np.fromfile(f, np.int64, H)]
+        boards = [np.fromfile(f, np.float32, n * 84).reshape(n, 2, 6, 7) for n in lens]
+        pis = [np.fromfile(f, np.float32, n * 7).reshape(n, 7) for n in lens]
+        vs = [np.fromfile(f, np.float32, n) for n in lens]
+    if any(v.shape[0] != n for v, n in zip(vs, lens)):
+        raise ValueError(f"{path}: truncated")
+    return list(zip(boards, pis, vs))
+
+
+def _mix64(x):
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def shuffle_permutation(n, seed, iteration):
+    """Fisher-Yates with the build's counter RNG (the reference shuffles with SmallRng, src/coach.rs:296-297; B7):
+    for i = n-1 .. 1: j = ((draw(seed, iteration, i, 5) >> 32) * (i + 1)) >> 32; swap(perm[i], perm[j]).
+    Same permutation as include/az_host.hpp shuffle_permutation."""
+    i = np.arange(n, dtype=np.uint64)
+    key = _mix64(_mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF)) ^ np.uint64(iteration))
+    r = _mix64(_mix64(key ^ i) ^ np.uint64(5))
+    j = ((r >> np.uint64(32)) * (i + np.uint64(1))) >> np.uint64(32)
+    perm = list(range(n))
+    for k in range(n - 1, 0, -1):
+        t = int(j[k])
+        perm[k], perm[t] = perm[t], perm[k]
+    return np.array(perm, np.int64)

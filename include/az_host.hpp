@@ -8,11 +8,17 @@
 //   AsyncMcts<G>          src/async_mcts.rs:14-115    -> AsyncMcts (az_tree_* entry points, one tree)
 //   arena::play_game(s)   src/arena.rs:7-99           -> play_game, play_games (closures, Heap's order)
 //   Coach::execute_episode src/coach.rs:104-157       -> execute_episode
+//   Coach::setup / learn  src/coach.rs:38-103, :169-396 -> Coach (az_selfplay, az_net_train, az_arena; one call each)
 // Header-only; links against libaz_engine.so.  Nothing here touches oracle/.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <filesystem>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -237,5 +243,178 @@ inline std::vector<TrainingSample> execute_episode(const AsyncMcts& mcts, size_t
         }
     }
 }
+
+// ---- Coach (src/coach.rs:17-396) ----------------------------------------------------------------------------------
+// The iteration loop around the engine: self-play episodes -> replay window -> <iter>.examples -> shuffle ->
+// NNet::train(samples, model_id, model_id + 1) -> arena of new vs old -> accept iff nwins + pwins > 0 and
+// nwins / (nwins + pwins) >= update_threshold.  Self-play, training and the arena are ONE engine call each.
+// The Python host (alphazero-rs_amd/coach.py) runs the same sequence with the same seeds and writes the same files.
+//
+// <dir>/<iter>.examples ("AZEX0001", the build's own format; the reference's is bincode, src/coach.rs:159-167, A14):
+//   char magic[8]; int64 H; int64 lens[H]; f32 boards[N][2][6][7]; f32 pis[N][7]; f32 vs[N]   (N = sum lens; the whole
+//   `history` deque, oldest entry first).   <dir>/<model_id>.aznet = az_net_save.
+struct HistoryEntry { std::vector<float> boards, pis, vs; size_t len() const { return vs.size(); } };
+
+// Fisher-Yates with the build's counter RNG (the reference shuffles with SmallRng, src/coach.rs:296-297; B7):
+// for i = n-1 .. 1: j = ((draw(seed, iteration, i, 5) >> 32) * (i + 1)) >> 32; swap(perm[i], perm[j])
+inline std::vector<int64_t> shuffle_permutation(size_t n, uint64_t seed, uint64_t iteration) {
+    std::vector<int64_t> perm(n);
+    for (size_t i = 0; i < n; ++i) perm[i] = (int64_t)i;
+    for (size_t i = n; i-- > 1;) {
+        const uint64_t r = mix64(mix64(mix64(mix64(seed) ^ iteration) ^ (uint64_t)i) ^ 5ull);
+        const size_t j = (size_t)(((r >> 32) * (uint64_t)(i + 1)) >> 32);
+        std::swap(perm[i], perm[j]);
+    }
+    return perm;
+}
+
+class Coach {
+  public:
+    struct Report { size_t iteration, samples, nwins, pwins, draws, model_id; bool accepted; std::vector<float> losses; };
+
+    // Coach::setup(checkpoint_directory, + the reference's 14 numeric parameters), src/coach.rs:38-103
+    static Coach setup(Engine& e, const std::string& checkpoint_directory, size_t mcts_reserve_size, float update_threshold,
+                       size_t temp_threshold, size_t max_history_length, size_t max_queue_length, size_t inference_batch_size,
+                       size_t num_episode_threads, size_t num_arena_games, size_t num_iters, size_t num_eps, size_t num_sims,
+                       size_t num_sim_threads, size_t max_depth, int32_t cpuct) {
+        if (inference_batch_size == 0 || num_sims % inference_batch_size != 0)
+            throw Panic("assertion failed: num_sims % inference_batch_size == 0");        // src/coach.rs:83
+        if (num_sim_threads != 1) throw Panic("the engine runs one simulation per tree at a time (num_sim_threads = 1)");
+        Coach c(e);
+        c.dir_ = checkpoint_directory;
+        c.mcts_reserve_size = mcts_reserve_size; c.update_threshold = update_threshold; c.temp_threshold = temp_threshold;
+        c.max_history_length = max_history_length; c.max_queue_length = max_queue_length;
+        c.num_episode_threads = num_episode_threads; c.num_arena_games = num_arena_games; c.num_iters = num_iters;
+        c.num_eps = num_eps; c.num_sims = num_sims; c.max_depth = max_depth; c.cpuct = cpuct;
+        namespace fs = std::filesystem;
+        fs::create_directories(c.dir_);
+        long best = -1;                                        // resume from the largest numeric stem (:55-81)
+        for (auto& ent : fs::directory_iterator(c.dir_)) {
+            const std::string stem = ent.path().stem().string();
+            if (ent.path().extension() != ".examples" || stem.empty() || stem.find_first_not_of("0123456789") != std::string::npos) continue;
+            best = std::max(best, std::stol(stem));
+        }
+        if (best >= 0) { c.load_train_examples((size_t)best); c.start_iteration = (size_t)best + 1; }
+        return c;
+    }
+
+    std::string examples_path(size_t iteration) const { return dir_ + "/" + std::to_string(iteration) + ".examples"; }
+
+    void save_train_examples(size_t iteration) const {          // src/coach.rs:159-167
+        FILE* f = std::fopen(examples_path(iteration).c_str(), "wb");
+        if (!f) throw Panic("cannot write " + examples_path(iteration));
+        const int64_t H = (int64_t)history.size();
+        std::fwrite("AZEX0001", 1, 8, f);
+        std::fwrite(&H, sizeof H, 1, f);
+        for (auto& h : history) { const int64_t n = (int64_t)h.len(); std::fwrite(&n, sizeof n, 1, f); }
+        for (auto& h : history) std::fwrite(h.boards.data(), sizeof(float), h.boards.size(), f);
+        for (auto& h : history) std::fwrite(h.pis.data(), sizeof(float), h.pis.size(), f);
+        for (auto& h : history) std::fwrite(h.vs.data(), sizeof(float), h.vs.size(), f);
+        std::fclose(f);
+    }
+
+    void load_train_examples(size_t iteration) {
+        FILE* f = std::fopen(examples_path(iteration).c_str(), "rb");
+        if (!f) throw Panic("cannot read " + examples_path(iteration));
+        char magic[8];
+        int64_t H = 0;
+        bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "AZEX0001", 8) == 0 && std::fread(&H, sizeof H, 1, f) == 1 && H >= 0;
+        std::vector<int64_t> lens((size_t)(ok ? H : 0));
+        ok = ok && std::fread(lens.data(), sizeof(int64_t), lens.size(), f) == lens.size();
+        history.clear();
+        for (int64_t n : lens) { HistoryEntry h; h.boards.resize((size_t)n * 84); h.pis.resize((size_t)n * 7); h.vs.resize((size_t)n); history.push_back(std::move(h)); }
+        for (auto& h : history) ok = ok && std::fread(h.boards.data(), sizeof(float), h.boards.size(), f) == h.boards.size();
+        for (auto& h : history) ok = ok && std::fread(h.pis.data(), sizeof(float), h.pis.size(), f) == h.pis.size();
+        for (auto& h : history) ok = ok && std::fread(h.vs.data(), sizeof(float), h.vs.size(), f) == h.vs.size();
+        std::fclose(f);
+        if (!ok) throw Panic("malformed " + examples_path(iteration));
+    }
+
+    // the self-play fan-out of src/coach.rs:241-272: num_eps x execute_episode, emitted with both symmetries
+    HistoryEntry execute_episodes(size_t model_id, size_t iteration, uint64_t seed) {
+        az_selfplay_params p{};
+        p.n_games = (int32_t)num_eps; p.concurrent = (int32_t)std::min(num_episode_threads, num_eps);
+        p.num_sims = (int32_t)num_sims; p.temp_threshold = (int32_t)temp_threshold; p.max_depth = (int32_t)max_depth;
+        p.cpuct = cpuct; p.model_id = (int32_t)model_id; p.symmetries = 1; p.reserve = mcts_reserve_size; p.seed = seed;
+        p.first_game_id = (uint64_t)(iteration * num_eps);
+        const size_t cap = num_eps * 42 * 2;
+        HistoryEntry h;
+        h.boards.resize(cap * 84); h.pis.resize(cap * 7); h.vs.resize(cap);
+        az_samples out{};
+        out.capacity = (int64_t)cap; out.boards = h.boards.data(); out.pis = h.pis.data(); out.zs = h.vs.data();
+        e_.check(az_selfplay(e_.raw(), &p, &out));
+        const size_t n = (size_t)out.count;
+        h.boards.resize(n * 84); h.pis.resize(n * 7); h.vs.resize(n);
+        return h;
+    }
+
+    // Coach::learn(skip_first_play), src/coach.rs:169-396.  Engine model slots: `model_id` is the current net,
+    // `model_id + 1` the candidate.
+    std::vector<Report> learn(bool skip_first_play, uint64_t seed, size_t model_id = 0) {
+        std::vector<Report> report;
+        for (size_t iteration = start_iteration; iteration < start_iteration + num_iters; ++iteration) {
+            if (!skip_first_play || iteration > start_iteration) {
+                HistoryEntry h = execute_episodes(model_id, iteration, seed);
+                if (h.len() > max_queue_length) {                   // keep the newest max_queue_length (:275-277)
+                    const size_t drop = h.len() - max_queue_length;
+                    h.boards.erase(h.boards.begin(), h.boards.begin() + (std::ptrdiff_t)(drop * 84));
+                    h.pis.erase(h.pis.begin(), h.pis.begin() + (std::ptrdiff_t)(drop * 7));
+                    h.vs.erase(h.vs.begin(), h.vs.begin() + (std::ptrdiff_t)drop);
+                }
+                history.push_back(std::move(h));
+            }
+            if (history.size() > max_history_length) history.pop_front();      // :285-288
+            save_train_examples(iteration);                                       // :291-293
+            size_t n = 0;
+            for (auto& h : history) n += h.len();
+            if (n == 0) throw Panic("assertion failed: training set is empty");   // :305
+            std::vector<float> ab, ap, av;
+            ab.reserve(n * 84); ap.reserve(n * 7); av.reserve(n);
+            for (auto& h : history) { ab.insert(ab.end(), h.boards.begin(), h.boards.end()); ap.insert(ap.end(), h.pis.begin(), h.pis.end()); av.insert(av.end(), h.vs.begin(), h.vs.end()); }
+            const std::vector<int64_t> perm = shuffle_permutation(n, seed, iteration);   // :296-297
+            std::vector<float> sb(n * 84), sp(n * 7), sv(n);
+            for (size_t i = 0; i < n; ++i) {
+                const size_t src = (size_t)perm[i];
+                std::memcpy(&sb[i * 84], &ab[src * 84], 84 * sizeof(float));
+                std::memcpy(&sp[i * 7], &ap[src * 7], 7 * sizeof(float));
+                sv[i] = av[src];
+            }
+            e_.check(az_set_option(e_.raw(), "train_seed", (int64_t)(seed + iteration)));
+            e_.check(az_net_train(e_.raw(), (int32_t)model_id, (int32_t)model_id + 1, sb.data(), sp.data(), sv.data(), (int64_t)n));   // :329
+            e_.check(az_net_save(e_.raw(), (int32_t)model_id + 1, (dir_ + "/" + std::to_string(model_id + 1) + ".aznet").c_str()));
+            Report r{};
+            r.iteration = iteration; r.samples = n; r.model_id = model_id;
+            r.losses.resize(2 * (size_t)az_net_train_history(e_.raw(), nullptr, 0));
+            az_net_train_history(e_.raw(), r.losses.data(), (int32_t)(r.losses.size() / 2));
+            // arena: new (first listed) vs old, both seatings (:333-375)
+            az_arena_params a{};
+            a.num_games = (int32_t)num_arena_games; a.num_sims = (int32_t)num_sims; a.max_depth = (int32_t)max_depth; a.cpuct = cpuct;
+            a.new_model_id = (int32_t)model_id + 1; a.old_model_id = (int32_t)model_id; a.reserve = mcts_reserve_size;
+            a.seed = seed + 7919ull * (uint64_t)(iteration + 1);
+            uint64_t wld[3] = {0, 0, 0};
+            e_.check(az_arena(e_.raw(), &a, wld, nullptr));
+            r.nwins = (size_t)wld[0]; r.pwins = (size_t)wld[1]; r.draws = (size_t)wld[2];
+            std::printf("NEW/PREV WINS : %zu / %zu; DRAWS : %zu\n", r.nwins, r.pwins, r.draws);        // :381
+            r.accepted = !(r.pwins + r.nwins == 0 || (float)r.nwins / (float)(r.pwins + r.nwins) < update_threshold);   // :383-390
+            std::printf(r.accepted ? "ACCEPTING NEW MODEL\n" : "REJECTING NEW MODEL\n");
+            if (r.accepted) ++model_id;
+            report.push_back(std::move(r));
+        }
+        this->model_id = model_id;
+        return report;
+    }
+
+    std::deque<HistoryEntry> history;
+    size_t start_iteration = 0, model_id = 0;
+    size_t mcts_reserve_size = 0, temp_threshold = 0, max_history_length = 0, max_queue_length = 0, num_episode_threads = 0,
+           num_arena_games = 0, num_iters = 0, num_eps = 0, num_sims = 0, max_depth = 0;
+    float update_threshold = 0.f;
+    int32_t cpuct = 1;
+
+  private:
+    explicit Coach(Engine& e) : e_(e) {}
+    Engine& e_;
+    std::string dir_;
+};
 
 }  // namespace az_host

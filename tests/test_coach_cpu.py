@@ -134,13 +134,18 @@ def test_coach_learn_loop(mods, oracle, tmp_path):
     assert c.model_id == sum(r["accepted"] for r in rep)
     # files: <iter>.examples per iteration, <id>.aznet per candidate
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".examples")) == ["0.examples", "1.examples", "2.examples"]
-    z = np.load(os.path.join(tmp_path, "2.examples"), allow_pickle=False)
-    assert z["lens"].tolist() == [h[2].shape[0] for h in c.history] and z["boards"].shape[1:] == (2, 6, 7)
+    z = coach.load_examples(os.path.join(tmp_path, "2.examples"))
+    assert [h[2].shape[0] for h in z] == [h[2].shape[0] for h in c.history] and z[0][0].shape[1:] == (2, 6, 7)
+    for got, want in zip(z, c.history):
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    with open(os.path.join(tmp_path, "2.examples"), "rb") as f:
+        assert f.read(8) == b"AZEX0001"
     # the stored tuples are the oracle's execute_episode tuples incl. the mirrored twins
-    first_iter = np.load(os.path.join(tmp_path, "0.examples"), allow_pickle=False)
+    first_iter = coach.load_examples(os.path.join(tmp_path, "0.examples"))
     if rep[0]["model_id"] == 0:
-        assert np.array_equal(first_iter["boards"], ref0["boards"]) and np.array_equal(first_iter["pis"], ref0["pis"])
-        assert np.array_equal(first_iter["vs"], ref0["zs"])
+        assert len(first_iter) == 1
+        assert np.array_equal(first_iter[0][0], ref0["boards"]) and np.array_equal(first_iter[0][1], ref0["pis"])
+        assert np.array_equal(first_iter[0][2], ref0["zs"])
 
 
 def test_coach_resume_and_queue_limit(mods, oracle, tmp_path):

@@ -1,12 +1,55 @@
-"""Coach::learn end to end on the GPU (config 5 in miniature): self-play with the bf16 MFMA net, NNet::train with
-the torch trainer on the same device, weights uploaded under the next model id, arena gate, examples + weights files."""
+"""Coach::learn end to end on the GPU (config 5 in miniature): self-play with the bf16 MFMA net, NNet::train (the
+engine's own f32 trainer, or the torch trainer on the same device), weights stored under the next model id, arena
+gate, examples + weights files; the Python host and the C++ host (include/az_host.hpp) must agree byte for byte."""
+import json
 import os
+import subprocess
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_python_and_cpp_coach_agree(engine_mod, tmp_path):
+    """The same configuration through alphazero-rs_amd/coach.py and through az_host::Coach: same reports, and the
+    examples files and candidate weights they write are byte-identical (self-play, shuffle, NNet::train on the device
+    and the arena are all deterministic functions of the seed)."""
+    from alphazero_rs_amd.coach import Coach
+    C, seed = 128, 11
+    pydir, cdir = os.path.join(tmp_path, "py"), os.path.join(tmp_path, "cpp")
+    e = engine_mod.Engine(device=0, max_batch=256, net_channels=C)
+    try:
+        e.net_init_random(0, 3)
+        e.set_option("train_epochs", 2)
+        msgs = []
+        coach = Coach.setup(e, pydir, 1000000, 0.55, 15, 3, 100000, 1, 64, 16, 2, 48, 25, 1, 1000, 1, log=msgs.append)
+        rep = coach.learn(seed=seed)
+    finally:
+        e.close()
+    exe = os.path.join(tmp_path, "test_coach")
+    libdir = os.path.dirname(engine_mod.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_coach.cpp"), "-o", exe, "-L", libdir, "-laz_engine",
+                           f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe, cdir, str(C), str(seed)], check=True, stdout=subprocess.PIPE, text=True).stdout
+    crep = json.loads([l for l in out.strip().splitlines() if l.startswith("[")][-1])
+    assert len(rep) == len(crep) == 2
+    for a, b in zip(rep, crep):
+        for k in ("iteration", "samples", "nwins", "pwins", "draws", "accepted", "model_id"):
+            assert a[k] == b[k], (k, a, b)
+        assert np.allclose(np.array(a["losses"]).reshape(-1), b["losses"], rtol=1e-6)
+        assert a["nwins"] + a["pwins"] + a["draws"] == 16 and a["samples"] > 0 and len(a["losses"]) == 2
+    files = sorted(os.listdir(pydir))
+    assert files == sorted(os.listdir(cdir)) and "0.examples" in files and "1.examples" in files and "1.aznet" in files
+    for f in files:
+        with open(os.path.join(pydir, f), "rb") as x, open(os.path.join(cdir, f), "rb") as y:
+            assert x.read() == y.read(), f
+    assert any(m.startswith("NEW/PREV WINS : ") for m in msgs)
 
 
 def test_coach_learn_on_gpu(engine_mod, tmp_path):
@@ -39,8 +82,8 @@ def test_coach_learn_on_gpu(engine_mod, tmp_path):
         from alphazero_rs_amd.trainer import PolicyValueNet
         net = PolicyValueNet(C, p1, torch.device("cpu"))
         net.eval()
-        z = np.load(os.path.join(tmp_path, "1.examples"), allow_pickle=False)
-        boards = z["boards"][:64]
+        from alphazero_rs_amd.coach import load_examples
+        boards = load_examples(os.path.join(tmp_path, "1.examples"))[0][0][:64]
         with torch.no_grad():
             lg, vv = net(torch.from_numpy(boards))
         gpi, gv = e.predict(boards, 1)
