@@ -24,9 +24,12 @@ def main():
     ap.add_argument("--arena", type=int, default=40)         # num_arena_games, :64
     ap.add_argument("--slots", type=int, default=8192)       # concurrent games (num_episode_threads, :63)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--trainer", default="engine", choices=["engine", "torch"])   # NNet::train: az_net_train or autograd
+    ap.add_argument("--epochs", type=int, default=10)        # connect_four_net.py:13
     a = ap.parse_args()
     e = azeng.Engine(device=0, max_batch=max(a.slots, a.arena, 128), net_channels=a.channels)
     e.net_init_random(0, a.seed)
+    e.set_option("train_epochs", a.epochs)
     coach = Coach.setup(e, a.checkpoint,
                         1000000,   # mcts_reserve_size
                         0.6,       # update_threshold
@@ -42,7 +45,7 @@ def main():
                         1,         # num_sim_threads
                         1000,      # max_depth
                         1,         # cpuct
-                        trainer=Trainer(channels=a.channels))
+                        trainer=Trainer(channels=a.channels, epochs=a.epochs) if a.trainer == "torch" else None)
     for r in coach.learn(skip_first_play=False, seed=a.seed):
         print(r["iteration"], "samples", r["samples"], "new/prev/draw", r["nwins"], r["pwins"], r["draws"],
               "accepted" if r["accepted"] else "rejected", "loss", r["losses"][-1])

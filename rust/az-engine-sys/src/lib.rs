@@ -46,6 +46,11 @@ extern "C" {
     pub fn az_net_get_params(e: *mut az_engine, model_id: i32, params: *mut f32, n: i64) -> c_int;
     pub fn az_net_predict(e: *mut az_engine, model_id: i32, boards: *const f32, b: i32, pi: *mut f32, v: *mut f32) -> c_int;
     pub fn az_net_train(e: *mut az_engine, prev_id: i32, id: i32, boards: *const f32, pis: *const f32, vs: *const f32, n: i64) -> c_int;
+    pub fn az_net_train_history(e: *const az_engine, out: *mut f32, cap_epochs: i32) -> i32;
+    pub fn az_net_train_begin(e: *mut az_engine, prev_id: i32) -> c_int;
+    pub fn az_net_train_step(e: *mut az_engine, boards: *const f32, pis: *const f32, vs: *const f32, b: i32, mask_seed: u64,
+                             apply: i32, loss_out: *mut f32, grads_out: *mut f32) -> c_int;
+    pub fn az_net_train_end(e: *mut az_engine, model_id: i32) -> c_int;
     pub fn az_tree_create(e: *mut az_engine, n_games: i32, reserve: u64, num_sims: i32, max_depth: i32,
                           model_id: i32, cpuct: i32, out: *mut *mut az_tree) -> c_int;
     pub fn az_tree_destroy(t: *mut az_tree);
