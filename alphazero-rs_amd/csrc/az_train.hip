@@ -469,6 +469,8 @@ struct Trainer {
     double *partial = nullptr, *loss_totals = nullptr;
     float* splitk = nullptr;           // partial sums of the split-K GEMMs
     StepState* step_state = nullptr;
+    StepState* host_state = nullptr;   // pinned ring: source of the asynchronous per-step uploads of trainer_step
+    uint32_t host_state_next = 0;
     EpochCounters* counters = nullptr;
     bool use_graph = true;
     size_t splitk_floats = 0;
@@ -483,6 +485,7 @@ struct Trainer {
 };
 
 constexpr int RED_PARTS = 32;
+constexpr uint32_t HOST_STATE_RING = 64;   // trainer_step's callers synchronise at least this often (az_net_train_step: every step)
 
 Trainer* trainer_create(int channels, const char** err) {
     if (channels % 128 != 0 || channels < 128) { if (err) *err = "net_channels must be a multiple of 128"; return nullptr; }
@@ -518,6 +521,7 @@ Trainer* trainer_create(int channels, const char** err) {
     ok &= (t->partial = t->dalloc<double>((size_t)RED_PARTS * std::max<size_t>(C, 1024) * 2)) != nullptr;
     ok &= (t->loss_totals = t->dalloc<double>(2)) != nullptr;
     ok &= (t->step_state = t->dalloc<StepState>(1)) != nullptr;
+    ok &= hipHostMalloc((void**)&t->host_state, HOST_STATE_RING * sizeof(StepState), hipHostMallocDefault) == hipSuccess;
     ok &= (t->counters = t->dalloc<EpochCounters>(1)) != nullptr;
     t->splitk_floats = (size_t)32 << 20;      // 128 MiB
     ok &= (t->splitk = t->dalloc<float>(t->splitk_floats)) != nullptr;
@@ -529,6 +533,7 @@ Trainer* trainer_create(int channels, const char** err) {
 void trainer_destroy(Trainer* t) {
     if (!t) return;
     for (void* p : t->dev) (void)hipFree(p);
+    if (t->host_state) (void)hipHostFree(t->host_state);
     delete t;
 }
 
@@ -698,7 +703,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
 bool trainer_step(Trainer* t, const TrainHyper& h, const float* d_boards, const float* d_pis, const float* d_vs, int b,
                   uint64_t mask_seed, bool apply, hipStream_t s) {
     if (!t || b <= 1 || b > TRAIN_MAX_BATCH) return false;
-    StepState st{};
+    StepState& st = t->host_state[t->host_state_next++ % HOST_STATE_RING];
     st.mask_seed = mask_seed;
     const double p1 = t->pow1 * (double)h.beta1, p2 = t->pow2 * (double)h.beta2;
     st.bc1 = (float)(1.0 - p1);

@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -111,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and run the gather even at world size 1 (rehearsal)")
     args = ap.parse_args()
     episodes = args.episodes or 4 * args.games
@@ -241,6 +244,26 @@ def main():
                 line["cpu_baseline"] = {"error": repr(ex)}
         else:
             line["cpu_baseline"] = None
+        if world == 1 and args.net == "conv" and not args.no_train_probe:
+            # auxiliary, outside the timed region and not part of `value`: NNet::train (az_net_train, f32 MFMA kernels) on
+            # synthetic samples at the recipe's batch of 64 -- the other dense workload of the Coach loop
+            try:
+                rng = np.random.default_rng(0)
+                nb, bs = 200, 64
+                tb = (rng.random((nb * bs, 2, 6, 7)) < 0.2).astype(np.float32)
+                tp = rng.dirichlet(np.ones(7), nb * bs).astype(np.float32)
+                tv = rng.choice([-1.0, 1.0], nb * bs).astype(np.float32)
+                e.set_option("train_epochs", 1)
+                e.set_option("train_batch", bs)
+                e.train(0, 1, tb[: 4 * bs], tp[: 4 * bs], tv[: 4 * bs])
+                t1 = time.perf_counter()
+                e.train(0, 1, tb, tp, tv)
+                dtt = time.perf_counter() - t1
+                line["nnet_train"] = {"ms_per_step": dtt / nb * 1e3, "samples_per_sec": nb * bs / dtt, "batch": bs, "steps": nb,
+                                      "dtype": "f32", "tflops": 3 * FLOP_PER_LEAF * bs / (dtt / nb) / 1e12,
+                                      "note": "az_net_train wall time incl. upload of the samples; ~3x forward FLOPs per sample"}
+            except Exception as ex:
+                line["nnet_train"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
     e.close()
     if use_dist:

@@ -233,3 +233,42 @@ def test_coach_two_ranks_match_single_process(mods, oracle, tmp_path):
         assert np.allclose(params, eng.params[1], atol=1e-5)
     # the 5 episodes were sharded 3 + 2 by global id
     assert got[0][6] == [("selfplay", 3, 0, 0)] and got[1][6] == [("selfplay", 2, 3, 0)]
+
+
+def test_examples_file_and_shuffle_are_the_documented_formats(mods, tmp_path):
+    """`<iter>.examples` = "AZEX0001" | int64 H | int64 lens[H] | boards | pis | vs (raw f32), and the shuffle is the
+    Fisher-Yates walk over the counter RNG that include/az_host.hpp implements too (known answers pinned here)."""
+    coach, _ = mods
+    rng = np.random.default_rng(0)
+    hist = [(rng.random((n, 2, 6, 7)).astype(np.float32), rng.random((n, 7)).astype(np.float32), rng.random(n).astype(np.float32))
+            for n in (3, 0, 5)]
+    path = os.path.join(tmp_path, "7.examples")
+    coach.save_examples(path, hist)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"AZEX0001" and len(raw) == 8 + 8 * 4 + 8 * 92 * 4
+    assert np.frombuffer(raw[8:40], np.int64).tolist() == [3, 3, 0, 5]
+    assert np.array_equal(np.frombuffer(raw[40:40 + 3 * 84 * 4], np.float32), hist[0][0].reshape(-1))
+    back = coach.load_examples(path)
+    assert len(back) == 3 and all(np.array_equal(a, b) for h, g in zip(hist, back) for a, b in zip(h, g))
+    with open(path, "wb") as f:
+        f.write(b"NOTAZEX0" + raw[8:])
+    with pytest.raises(ValueError):
+        coach.load_examples(path)
+    p = coach.shuffle_permutation(10, seed=3, iteration=2)
+    assert sorted(p.tolist()) == list(range(10))
+    assert p.tolist() == coach.shuffle_permutation(10, 3, 2).tolist()
+    assert p.tolist() != coach.shuffle_permutation(10, 3, 3).tolist() and p.tolist() != coach.shuffle_permutation(10, 4, 2).tolist()
+    # scalar restatement of the documented walk
+    def mix64(x):
+        x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return z ^ (z >> 31)
+    want = list(range(10))
+    for i in range(9, 0, -1):
+        r = mix64(mix64(mix64(mix64(3) ^ 2) ^ i) ^ 5)
+        j = ((r >> 32) * (i + 1)) >> 32
+        want[i], want[j] = want[j], want[i]
+    assert p.tolist() == want
+    assert coach.shuffle_permutation(0, 1, 1).tolist() == [] and coach.shuffle_permutation(1, 1, 1).tolist() == [0]
