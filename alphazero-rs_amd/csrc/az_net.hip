@@ -60,47 +60,59 @@ AZ_D uint32_t pack_bf16x2(float lo, float hi) {
 
 // ---- conv1: 3x3 'same', 2 -> C, reading the bitboards (K4 + first conv fused) -------------------------
 // out: act1 [n][8][9][C] bf16, interior rows 1..6 / cols 1..7 (the zero halo is conv2's 'same' padding).
-// One thread = one board position x 8 output channels (one 16-byte store).
+// One WAVE = one board, a lane = 8 output channels (one 16-byte store per position; lanes c8 = lane, lane+64, ...).
+// The stone tests are wave-uniform; the vector unit adds the <= 18 weight rows that hit a stone, in the fixed
+// (ky, kx, plane) order, and packs.  (With one wave per POSITION the kernel was bound by the latency of the
+// dependent bitboard load, 84 serial loads per wave: 150 us per 8192 boards.)
 __global__ __launch_bounds__(256) void k_conv1(const EvalBatch eb, const float* __restrict__ w /*[18][C]*/,
                                                const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out, int C) {
     // The folded weights (18 x C f32 = 36 KiB at C = 512) are staged in LDS once per block; blocks are persistent
-    // (grid-stride over (leaf, position, 8-channel group) items), so the tap loop reads LDS instead of L2.
+    // (grid-stride over (leaf, position) items), so the tap loop reads LDS instead of L2.
     extern __shared__ __attribute__((aligned(16))) float w_lds[];        // [18][C] + [C] bias
     for (int i = threadIdx.x; i < 18 * C / 4; i += blockDim.x) ((float4*)w_lds)[i] = ((const float4*)w)[i];
     for (int i = threadIdx.x; i < C / 4; i += blockDim.x) ((float4*)(w_lds + 18 * C))[i] = ((const float4*)bias)[i];
     __syncthreads();
     const int cg = C / 8;
-    const size_t total = (size_t)(*eb.n) * 42 * cg;
-    for (size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(tid % cg);
-        const int pos = (int)((tid / cg) % 42);
-        const size_t b = tid / ((size_t)cg * 42);
-        const int y = pos / 7, x = pos % 7;
-        const ulonglong2 s = eb.state[b];
-        const float4* bp = (const float4*)(w_lds + 18 * C + c8 * 8);
-        float4 a0 = bp[0], a1 = bp[1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t boards = *eb.n;
+    const uint32_t stride = gridDim.x * 4u;
+    // one wave = one board (its 42 positions in turn): the dependent bitboard load is paid once per 42 KiB of output
+    for (uint32_t b = blockIdx.x * 4u + (uint32_t)wave; b < boards; b += stride) {
+        const ulonglong2 sv = eb.state[b];
+        const uint32_t m_lo = __builtin_amdgcn_readfirstlane((uint32_t)sv.x), m_hi = __builtin_amdgcn_readfirstlane((uint32_t)(sv.x >> 32));
+        const uint32_t t_lo = __builtin_amdgcn_readfirstlane((uint32_t)sv.y), t_hi = __builtin_amdgcn_readfirstlane((uint32_t)(sv.y >> 32));
+        const uint64_t mine = ((uint64_t)m_hi << 32) | m_lo, theirs = ((uint64_t)t_hi << 32) | t_lo;
+        for (int y = 0; y < 6; ++y)
+            for (int x = 0; x < 7; ++x) {
+                uint16_t* orow = out + (((size_t)b * 8 + (y + 1)) * 9 + (x + 1)) * (size_t)C;
+                for (int c8 = lane; c8 < cg; c8 += 64) {
+                    const float4* bp = (const float4*)(w_lds + 18 * C + c8 * 8);
+                    float4 a0 = bp[0], a1 = bp[1];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = y + ky - 1, ix = x + kx - 1;
-                if (iy < 0 || iy >= 6 || ix < 0 || ix >= 7) continue;
-                const uint64_t bit = 1ull << (ix * 7 + (5 - iy));
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int iy = y + ky - 1, ix = x + kx - 1;
+                            if (iy < 0 || iy >= 6 || ix < 0 || ix >= 7) continue;
+                            const uint64_t bit = 1ull << (ix * 7 + (5 - iy));
 #pragma unroll
-                for (int ci = 0; ci < 2; ++ci) {
-                    if (!((ci == 0 ? s.x : s.y) & bit)) continue;
-                    const float4* wp = (const float4*)(w_lds + ((ky * 3 + kx) * 2 + ci) * C + c8 * 8);
-                    const float4 w0 = wp[0], w1 = wp[1];
-                    a0.x += w0.x; a0.y += w0.y; a0.z += w0.z; a0.w += w0.w;
-                    a1.x += w1.x; a1.y += w1.y; a1.z += w1.z; a1.w += w1.w;
+                            for (int ci = 0; ci < 2; ++ci) {
+                                if (!((ci == 0 ? mine : theirs) & bit)) continue;
+                                const float4* wp = (const float4*)(w_lds + ((ky * 3 + kx) * 2 + ci) * C + c8 * 8);
+                                const float4 w0 = wp[0], w1 = wp[1];
+                                a0.x += w0.x; a0.y += w0.y; a0.z += w0.z; a0.w += w0.w;
+                                a1.x += w1.x; a1.y += w1.y; a1.z += w1.z; a1.w += w1.w;
+                            }
+                        }
+                    uint4 o;
+                    o.x = pack_bf16x2(fmaxf(a0.x, 0.0f), fmaxf(a0.y, 0.0f));
+                    o.y = pack_bf16x2(fmaxf(a0.z, 0.0f), fmaxf(a0.w, 0.0f));
+                    o.z = pack_bf16x2(fmaxf(a1.x, 0.0f), fmaxf(a1.y, 0.0f));
+                    o.w = pack_bf16x2(fmaxf(a1.z, 0.0f), fmaxf(a1.w, 0.0f));
+                    *(uint4*)(orow + c8 * 8) = o;
                 }
             }
-        uint4 o;
-        o.x = pack_bf16x2(fmaxf(a0.x, 0.0f), fmaxf(a0.y, 0.0f));
-        o.y = pack_bf16x2(fmaxf(a0.z, 0.0f), fmaxf(a0.w, 0.0f));
-        o.z = pack_bf16x2(fmaxf(a1.x, 0.0f), fmaxf(a1.y, 0.0f));
-        o.w = pack_bf16x2(fmaxf(a1.z, 0.0f), fmaxf(a1.w, 0.0f));
-        *(uint4*)(out + (((b * 8 + (y + 1)) * 9 + (x + 1)) * (size_t)C + c8 * 8)) = o;
     }
 }
 
@@ -889,8 +901,8 @@ void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t
         (void)hipEventRecord(rec.e0, s);
     }
     {
-        const size_t threads = (size_t)rows_hint * 42 * (C / 8);
-        const size_t blocks = std::min<size_t>((threads + 255) / 256, 256 * 4);      // 4 persistent blocks per CU (38 KiB LDS each)
+        const size_t waves = (size_t)rows_hint;                                        // one wave per board
+        const size_t blocks = std::min<size_t>((waves + 3) / 4, 256 * 4);            // 4 persistent blocks per CU (38 KiB LDS each)
         hipLaunchKernelGGL(k_conv1, dim3((unsigned)blocks), dim3(256), (size_t)(19 * C) * sizeof(float), s, eb, n->w1, n->b1,
                            n->act1, C);
     }
