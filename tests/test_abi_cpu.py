@@ -71,3 +71,27 @@ def test_host_helpers_match_oracle(engine_mod, oracle):
                 break
             s = n2
         assert np.array_equal(engine_mod.c4_features(*s), oracle.c4_features(*s))
+
+
+def test_cpp_host_mirror_rules_and_shuffle(oracle, tmp_path):
+    """include/az_host.hpp without an engine: the Connect Four rules on bitboards agree with the oracle on the
+    reference's diagonal game (connect_four_game.rs:244-264), and the counter-RNG shuffle is the Python host's."""
+    import json
+    import subprocess
+    from alphazero_rs_amd import coach
+    exe = os.path.join(tmp_path, "test_host_cpu")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_host_cpu.cpp"), "-o", exe])
+    for n, seed, it in ((10, 3, 2), (1000, 123456789, 17), (1, 0, 0)):
+        got = json.loads(subprocess.run([exe, str(n), str(seed), str(it)], check=True, stdout=subprocess.PIPE, text=True).stdout)
+        assert got["perm"] == coach.shuffle_permutation(n, seed, it).tolist()
+    # replay the diagonal game on the oracle's canonical bitboards: player +1 moves on even plies
+    s, ended = (0, 0), []
+    for ply, a in enumerate([0, 1, 1, 2, 2, 3, 2, 3, 3, 6, 3]):
+        s = oracle.c4_play(s[0], s[1], a)               # canonical: (side to move, other) after the move
+        e = oracle.c4_ended(*s)                         # from the side to move's view: -1 = the mover just won
+        ended.append(0 if e == 0 else (1 if (e < 0) == (ply % 2 == 0) else -1))
+    assert got["ended"] == ended and ended[-1] == 1 and sum(ended[:-1]) == 0
+    # after 11 plies player -1 is to move: canonical (mine, theirs) = (minus, plus)
+    assert (got["canon_plus"], got["canon_minus"]) == s == (got["minus"], got["plus"])
+    assert got["valid"] == [(oracle.c4_valid_mask(*s) >> c) & 1 for c in range(7)] and got["features_sum"] == 11
