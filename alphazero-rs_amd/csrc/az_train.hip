@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- C[M][N] (+)= A(M x K) * B(K x N) (+ bias[N]) on the f32 matrix cores -------------------------------------
 // A element (m,k) = A[m*sAm + k*sAk], B element (k,n) = B[k*sBk + n*sBn]: one of each pair of strides is 1, which
 // selects the vector-load direction (A_K1: A contiguous along k; B_N1: B contiguous along n).  Tiles are staged
-// k-major in LDS (As[k][m], Bs[k][n], row stride 80 floats: the four k rows a wave reads sit 16 banks apart).
+// k-major in LDS (As[k][m], Bs[k][n], row stride TM + 20 floats: the four k rows a wave reads sit 20 banks apart).
 struct GemmF32 {
     const float* A; int64_t sAm, sAk;
     const float* B; int64_t sBk, sBn;
@@ -42,7 +42,7 @@ struct GemmF32 {
     int splits;
 };
 
-constexpr int TBM = 64, TBN = 64, TBK = 16, TLD = 84;
+constexpr int TBK = 16;
 
 AZ_D float4 ld4_guard(const float* p, int valid) {   // up to 4 consecutive elements, zero-filled
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -54,43 +54,52 @@ AZ_D float4 ld4_guard(const float* p, int valid) {   // up to 4 consecutive elem
     return v;
 }
 
-// Split-K: a GEMM whose output has few 64x64 tiles (the FCs at batch 64, conv4) is cut along K into blockIdx.z
-// slices so that every CU holds several blocks (that, not a deep software pipeline, is what hides the global-load
-// latency of the short K loop); the slices are summed in a fixed order by k_splitk_reduce, so the result does not
-// depend on scheduling.  The next tile's global loads are issued before the current tile's MFMAs.
-template <int A_K1, int B_N1>
+// Block tile TM x TM (64 or 128), 4 waves in 2 x 2, each wave (TM/32)^2 MFMA tiles of 16 x 16.  The 128 tile halves the
+// L2 -> CU bytes per flop (the three conv2-sized GEMMs of a step are stream-bound with 64 x 64 tiles); the 64 tile keeps
+// the small GEMMs (FCs, conv4) spread over the chip.
+// Split-K: a GEMM whose output has few tiles is cut along K into blockIdx.z slices so that every CU holds several
+// blocks (that, not a deep software pipeline, is what hides the global-load latency of the short K loop); the slices
+// are summed in a fixed order by k_splitk_reduce, so the result does not depend on scheduling.  The next tile's
+// global loads are issued before the current tile's MFMAs.
+template <int A_K1, int B_N1, int TM>
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
+    constexpr int TLD = TM + 20;            // row stride of the k-major LDS tiles: 16-byte aligned rows, 20 banks apart
+    constexpr int P = TM / 64;              // float4 loads per thread and operand
+    constexpr int MT = TM / 32;             // 16 x 16 MFMA tiles per wave and dimension
     __shared__ __attribute__((aligned(16))) float As[TBK][TLD];
     __shared__ __attribute__((aligned(16))) float Bs[TBK][TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
     const int kbeg = blockIdx.z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
-    f32x4 acc[2][2];
+    f32x4 acc[MT][MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = lane >> 4;
-    // this thread's slice of the A and B tiles: 4 consecutive elements along the contiguous direction
-    const int a_r = A_K1 ? tid >> 2 : tid >> 4, a_q = A_K1 ? (tid & 3) * 4 : (tid & 15) * 4;
-    const int b_r = B_N1 ? tid >> 4 : tid >> 2, b_q = B_N1 ? (tid & 15) * 4 : (tid & 3) * 4;
-    float4 va, vb;
+    // this thread's slices of the A and B tiles: P x 4 consecutive elements along the contiguous direction.
+    // contiguous along k (A_K1 / !B_N1): row (tid>>2) + 64*p, k quad (tid&3)*4;
+    // contiguous along m/n: k row (tid / (TM/4)) + (1024/TM)*p, quad (tid % (TM/4))*4
+    constexpr int QPR = TM / 4, KPP = 1024 / TM;
+    const int a_r = A_K1 ? tid >> 2 : tid / QPR, a_q = A_K1 ? (tid & 3) * 4 : (tid % QPR) * 4;
+    const int b_r = B_N1 ? tid / QPR : tid >> 2, b_q = B_N1 ? (tid % QPR) * 4 : (tid & 3) * 4;
+    float4 va[P], vb[P];
 #define AZ_TLOAD(k0_)                                                                                          \
-    {                                                                                                          \
-        va = make_float4(0.f, 0.f, 0.f, 0.f);                                                                  \
-        vb = make_float4(0.f, 0.f, 0.f, 0.f);                                                                  \
-        if (A_K1) { if (m0 + a_r < g.M) va = ld4_guard(g.A + (int64_t)(m0 + a_r) * g.sAm + ((k0_) + a_q), kend - ((k0_) + a_q)); } \
-        else { if ((k0_) + a_r < kend) va = ld4_guard(g.A + (int64_t)((k0_) + a_r) * g.sAk + (m0 + a_q), g.M - (m0 + a_q)); }      \
-        if (B_N1) { if ((k0_) + b_r < kend) vb = ld4_guard(g.B + (int64_t)((k0_) + b_r) * g.sBk + (n0 + b_q), g.N - (n0 + b_q)); } \
-        else { if (n0 + b_r < g.N) vb = ld4_guard(g.B + (int64_t)(n0 + b_r) * g.sBn + ((k0_) + b_q), kend - ((k0_) + b_q)); }      \
+    _Pragma("unroll") for (int p_ = 0; p_ < P; ++p_) {                                                         \
+        va[p_] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+        vb[p_] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+        if (A_K1) { const int r_ = a_r + 64 * p_; if (m0 + r_ < g.M) va[p_] = ld4_guard(g.A + (int64_t)(m0 + r_) * g.sAm + ((k0_) + a_q), kend - ((k0_) + a_q)); } \
+        else { const int r_ = a_r + KPP * p_; if ((k0_) + r_ < kend) va[p_] = ld4_guard(g.A + (int64_t)((k0_) + r_) * g.sAk + (m0 + a_q), g.M - (m0 + a_q)); }      \
+        if (B_N1) { const int r_ = b_r + KPP * p_; if ((k0_) + r_ < kend) vb[p_] = ld4_guard(g.B + (int64_t)((k0_) + r_) * g.sBk + (n0 + b_q), g.N - (n0 + b_q)); } \
+        else { const int r_ = b_r + 64 * p_; if (n0 + r_ < g.N) vb[p_] = ld4_guard(g.B + (int64_t)(n0 + r_) * g.sBn + ((k0_) + b_q), kend - ((k0_) + b_q)); }      \
     }
 #define AZ_TSTORE()                                                                                            \
-    {                                                                                                          \
-        if (A_K1) { As[a_q + 0][a_r] = va.x; As[a_q + 1][a_r] = va.y; As[a_q + 2][a_r] = va.z; As[a_q + 3][a_r] = va.w; } \
-        else *(float4*)&As[a_r][a_q] = va;                                                                     \
-        if (B_N1) *(float4*)&Bs[b_r][b_q] = vb;                                                                \
-        else { Bs[b_q + 0][b_r] = vb.x; Bs[b_q + 1][b_r] = vb.y; Bs[b_q + 2][b_r] = vb.z; Bs[b_q + 3][b_r] = vb.w; } \
+    _Pragma("unroll") for (int p_ = 0; p_ < P; ++p_) {                                                         \
+        if (A_K1) { const int r_ = a_r + 64 * p_; As[a_q + 0][r_] = va[p_].x; As[a_q + 1][r_] = va[p_].y; As[a_q + 2][r_] = va[p_].z; As[a_q + 3][r_] = va[p_].w; } \
+        else *(float4*)&As[a_r + KPP * p_][a_q] = va[p_];                                                      \
+        if (B_N1) *(float4*)&Bs[b_r + KPP * p_][b_q] = vb[p_];                                                 \
+        else { const int r_ = b_r + 64 * p_; Bs[b_q + 0][r_] = vb[p_].x; Bs[b_q + 1][r_] = vb[p_].y; Bs[b_q + 2][r_] = vb[p_].z; Bs[b_q + 3][r_] = vb[p_].w; } \
     }
     if (kbeg < kend) {
         AZ_TLOAD(kbeg);
@@ -103,13 +112,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int k = kk * 4 + fk;
-            const float a0 = As[k][wm * 32 + fr], a1 = As[k][wm * 32 + 16 + fr];
-            const float b0 = Bs[k][wn * 32 + fr], b1 = Bs[k][wn * 32 + 16 + fr];
+            float a[MT], b[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { a[i] = As[k][wm * (TM / 2) + i * 16 + fr]; b[i] = Bs[k][wn * (TM / 2) + i * 16 + fr]; }
             // the B tile is the instruction's first operand: D[n][m], a lane holds 4 consecutive n of one row m
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, a0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, a0, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, a1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, a1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (more) AZ_TSTORE();
@@ -119,12 +129,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
 #undef AZ_TSTORE
     float* cbase = g.splits > 1 ? g.C + (int64_t)blockIdx.z * g.M * g.N : g.C;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 32 + i * 16 + fr;
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * (TM / 2) + i * 16 + fr;
         if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 32 + j * 16 + fk * 4;
+        for (int j = 0; j < MT; ++j) {
+            const int n = n0 + wn * (TM / 2) + j * 16 + fk * 4;
             float* c = cbase + (int64_t)m * g.ldc + n;
             if (n + 3 < g.N && ((((uintptr_t)c) & 15) == 0)) {
                 float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
@@ -580,9 +590,12 @@ inline dim3 grid1(int64_t n, int block = 256, int cap = 4096) { return dim3((uns
 // split-K plan + launch (ws = workspace of ws_floats floats for the partial sums)
 template <int A_K1, int B_N1>
 void launch_gemm_f32(GemmF32 g, float* ws, size_t ws_floats, hipStream_t s) {
-    const int tiles = ((g.M + TBM - 1) / TBM) * ((g.N + TBN - 1) / TBN);
+    // 128 x 128 tiles when K is long and the output still yields >= 64 of them (conv2 / conv3 forward, dgrad, wgrad), else 64 x 64
+    const bool big = g.K >= 256 && ((g.M + 127) / 128) * ((g.N + 127) / 128) >= 64;
+    const int TM = big ? 128 : 64;
+    const int tiles = ((g.M + TM - 1) / TM) * ((g.N + TM - 1) / TM);
     const int ksteps = (g.K + TBK - 1) / TBK;
-    int splits = std::max(1, std::min(1536 / std::max(tiles, 1), ksteps / 8));
+    int splits = std::max(1, std::min((big ? 768 : 1536) / std::max(tiles, 1), ksteps / 8));
     while (splits > 1 && (size_t)splits * g.M * g.N > ws_floats) --splits;
     int k_per = ((ksteps + splits - 1) / splits) * TBK;
     splits = (g.K + k_per - 1) / k_per;
@@ -592,7 +605,9 @@ void launch_gemm_f32(GemmF32 g, float* ws, size_t ws_floats, hipStream_t s) {
     const int64_t ldc = g.ldc;
     const float* bias = g.bias;
     if (splits > 1) { g.C = ws; g.ldc = g.N; g.bias = nullptr; }
-    hipLaunchKernelGGL((k_gemm_f32<A_K1, B_N1>), dim3((g.N + TBN - 1) / TBN, (g.M + TBM - 1) / TBM, splits), dim3(256), 0, s, g);
+    const dim3 grid((g.N + TM - 1) / TM, (g.M + TM - 1) / TM, splits);
+    if (big) hipLaunchKernelGGL((k_gemm_f32<A_K1, B_N1, 128>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm_f32<A_K1, B_N1, 64>), grid, dim3(256), 0, s, g);
     if (splits > 1)
         hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)g.M * g.N), dim3(256), 0, s, ws, splits, g.M, g.N, out, ldc, bias);
 }
