@@ -97,7 +97,6 @@ struct TreeHost {
         d.leaf = mem.alloc<uint32_t>(G);
         d.leaf_kind = mem.alloc<uint32_t>(G);
         d.leaf_val = mem.alloc<float>(G);
-        d.leaf_state = mem.alloc<ulonglong2>(G);
         d.slot_of = mem.alloc<int32_t>(G);
         d.err = mem.alloc<uint32_t>(ERR_COUNT);
         d.stat = mem.alloc<uint64_t>((size_t)G * ST_COUNT);
@@ -199,16 +198,14 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
                 const NetModel& net, int rows_hint, hipStream_t s = nullptr) {
     if (!s) s = e->stream;
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
-    launch_root_prepare(th.d, d_root_states, s);
-    launch_compact(th.d, th.eb, s);
+    launch_root_prepare(th.d, th.eb, d_root_states, s);
     net_forward(e, net, th.eb, rows_hint, s);
     launch_backup(th.d, th.eb, 1, s);
     for (int i = 0; i < num_sims; ++i) {
         hipEvent_t t0 = nullptr;
         if (e->prof.on) t0 = e->prof.begin(s);
-        launch_select(th.d, sp, s);
+        launch_select(th.d, th.eb, sp, s);
         if (e->prof.on) e->prof.end(t0, RG_TREE, s);
-        launch_compact(th.d, th.eb, s);
         if (e->prof.on) t0 = e->prof.begin(s);
         net_forward(e, net, th.eb, rows_hint, s);
         if (e->prof.on) { e->prof.end(t0, RG_NET, s); t0 = e->prof.begin(s); }

@@ -31,7 +31,6 @@ struct TreeDev {
     uint32_t* leaf;      // [G] node the simulation stopped on
     uint32_t* leaf_kind; // [G] LeafKind
     float* leaf_val;     // [G] value when LEAF_VALUE
-    ulonglong2* leaf_state; // [G] canonical state of the leaf when LEAF_EVAL (dense copy for the batch assembly)
     int32_t* slot_of;    // [G] row of this tree's leaf in the eval batch (LEAF_EVAL)
     // diagnostics
     uint32_t* err;       // [ERR_COUNT]
@@ -101,9 +100,8 @@ struct ArenaDev {
 // ---- launchers (all asynchronous on `s`) --------------------------------------
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s,
                         const ulonglong2* roots = nullptr /*[G] root states, nullptr = initial board*/);
-void launch_root_prepare(const TreeDev& t, const ulonglong2* root_states, hipStream_t s);
-void launch_select(const TreeDev& t, SearchParams sp, hipStream_t s);
-void launch_compact(const TreeDev& t, const EvalBatch& eb, hipStream_t s);
+void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const ulonglong2* root_states, hipStream_t s);
+void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipStream_t s);
 void launch_backup(const TreeDev& t, const EvalBatch& eb, int apply_only, hipStream_t s);
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s);

@@ -118,8 +118,31 @@ __global__ __launch_bounds__(256) void k_reset_trees(TreeDev t, const uint8_t* f
     }
 }
 
+// ---- inference batch assembly (src/async_mcts.rs:137-151 restated) -------------------------------------------------
+// A tree whose leaf goes to the net takes the next row of the eval batch: one atomicAdd per wave (8 trees), rows in lane
+// order inside the wave.  The row ORDER of a batch therefore depends on which wave's atomic lands first; the results do
+// not, because a row's (pi, v) is independent of its position and of the batch's composition (tests/test_net_gpu.py,
+// test_net_rows_are_batch_independent) and every tree finds its own row through slot_of.  k_backup resets the counter.
+// (A separate single-block compaction kernel with rows in tree order cost 15.6 us per simulation step: 25 % of the
+// tree-only time, 1.3 % with the conv net.)
+AZ_D void batch_append(const TreeDev& t, const EvalBatch& eb, int g, bool want, uint64_t m_, uint64_t t_) {
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(eb.n, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (want) {
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        t.slot_of[g] = (int32_t)slot;
+        eb.tree[slot] = (uint32_t)g;
+        eb.state[slot] = make_ulonglong2(m_, t_);
+    }
+}
+
 // ---- get_action_prob prologue: root lookup (src/async_mcts.rs:81) + S10 + S1 -------------
-__global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, const ulonglong2* root_states) {
+__global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, const ulonglong2* root_states) {
     int tid = blockIdx.x * 64 + threadIdx.x;
     int g = tid >> 3, sub = tid & 7;
     if (g >= t.G) return;
@@ -159,7 +182,6 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, const ulonglong2
         t.root[g] = (root == NONE) ? 0u : root;
         t.leaf[g] = (root == NONE) ? 0u : root;
         t.leaf_kind[g] = kind;
-        t.leaf_state[g] = s;
         t.path_len[g] = 0;
         if (root == NONE || kind == LEAF_NONE) {
             // nothing to evaluate; a failed root also deactivates the tree for this search
@@ -167,10 +189,11 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, const ulonglong2
         }
         t.stat[(size_t)g * ST_COUNT + ST_EXPANSIONS] += n_exp;
     }
+    batch_append(t, eb, g, sub == 0 && kind == LEAF_EVAL, s.x, s.y);
 }
 
 // ---- search_iteration: select + expand (src/async_mcts.rs:226-299, Appendix A of SURVEY.md) ----
-__global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
+__global__ __launch_bounds__(64) void k_select(TreeDev t, EvalBatch eb, SearchParams sp) {
     int tid = blockIdx.x * 64 + threadIdx.x;
     int g = tid >> 3, sub = tid & 7;
     if (g >= t.G) return;
@@ -256,7 +279,6 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
         t.leaf[g] = cur;
         t.leaf_kind[g] = kind;
         t.leaf_val[g] = val;
-        if (kind == LEAF_EVAL) t.leaf_state[g] = make_ulonglong2(leaf_m, leaf_t);
         t.path_len[g] = plen;
         uint64_t* st = t.stat + (size_t)g * ST_COUNT;
         st[ST_SIMS] += 1;
@@ -265,79 +287,14 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, SearchParams sp) {
         st[ST_TERMINAL_HITS] += n_term;
         st[ST_DEPTH_SUM] += n_depth;
     }
-}
-
-// ---- inference batch assembly (src/async_mcts.rs:137-151 restated): deterministic compaction ----
-__global__ __launch_bounds__(1024) void k_compact(TreeDev t, EvalBatch eb) {
-    // Round r covers trees [r*1024, (r+1)*1024): coalesced flag loads, one ballot per wave, then a scan over the
-    // (round, wave) counts.  Rows come out in ascending tree order (deterministic batches).  Rounds are processed
-    // 8 at a time with all of a chunk's (coalesced) loads issued before the first use.
-    __shared__ uint32_t cnt[1024];                          // [round*16 + wave], rounds <= 64 (G <= 65536)
-    __shared__ uint32_t total_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rounds = (t.G + 1023) >> 10;
-    cnt[tid] = 0;
-    __syncthreads();
-    for (int r0 = 0; r0 < rounds; r0 += 8) {
-        uint32_t kind[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = ((r0 + i) << 10) + tid;
-            kind[i] = (r0 + i < rounds && g < t.G) ? t.leaf_kind[g] : (uint32_t)LEAF_NONE;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const unsigned long long m = __ballot(kind[i] == LEAF_EVAL);
-            if (lane == 0 && r0 + i < rounds) cnt[(r0 + i) * 16 + wave] = (uint32_t)__popcll(m);
-        }
-    }
-    __syncthreads();
-    const uint32_t mine = cnt[tid];
-    for (int off = 1; off < 1024; off <<= 1) {              // inclusive Hillis-Steele scan over the 1024 entries
-        uint32_t v = tid >= off ? cnt[tid - off] : 0u;
-        __syncthreads();
-        cnt[tid] += v;
-        __syncthreads();
-    }
-    if (tid == 1023) total_s = cnt[1023];
-    const uint32_t excl = cnt[tid] - mine;
-    __syncthreads();
-    cnt[tid] = excl;                                        // exclusive prefix per (round, wave)
-    __syncthreads();
-    for (int r0 = 0; r0 < rounds; r0 += 8) {
-        uint32_t kind[8];
-        ulonglong2 st[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = ((r0 + i) << 10) + tid;
-            const bool in = r0 + i < rounds && g < t.G;
-            kind[i] = in ? t.leaf_kind[g] : (uint32_t)LEAF_NONE;
-            if (in) st[i] = t.leaf_state[g];        // dense copy written by k_select / k_root_prepare (no tree gather here)
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = ((r0 + i) << 10) + tid;
-            const bool f = kind[i] == LEAF_EVAL;
-            const unsigned long long m = __ballot(f);
-            if (r0 + i < rounds && g < t.G) {
-                if (f) {
-                    const uint32_t slot = cnt[(r0 + i) * 16 + wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    t.slot_of[g] = (int32_t)slot;
-                    eb.tree[slot] = (uint32_t)g;
-                    eb.state[slot] = st[i];
-                } else {
-                    t.slot_of[g] = -1;
-                }
-            }
-        }
-    }
-    if (tid == 0) *eb.n = total_s;
+    batch_append(t, eb, g, sub == 0 && kind == LEAF_EVAL, leaf_m, leaf_t);
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
 __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, int apply_only) {
     int tid = blockIdx.x * 64 + threadIdx.x;
     int g = tid >> 3, sub = tid & 7;
+    if (tid == 0) *eb.n = 0;            // the batch has been consumed (nothing in this kernel reads the count): next select starts at row 0
     if (g >= t.G) return;
     const uint32_t kind = t.leaf_kind[g];
     if (kind == LEAF_NONE) return;
@@ -611,14 +568,11 @@ static inline int group_blocks(int G) { return (G * LANES + 63) / 64; }
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags, hipStream_t s, const ulonglong2* roots) {
     hipLaunchKernelGGL(k_reset_trees, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags), roots);
 }
-void launch_root_prepare(const TreeDev& t, const ulonglong2* root_states, hipStream_t s) {
-    hipLaunchKernelGGL(k_root_prepare, dim3(group_blocks(t.G)), dim3(64), 0, s, t, root_states);
+void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const ulonglong2* root_states, hipStream_t s) {
+    hipLaunchKernelGGL(k_root_prepare, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, root_states);
 }
-void launch_select(const TreeDev& t, SearchParams sp, hipStream_t s) {
-    hipLaunchKernelGGL(k_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, sp);
-}
-void launch_compact(const TreeDev& t, const EvalBatch& eb, hipStream_t s) {
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, t, eb);
+void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipStream_t s) {
+    hipLaunchKernelGGL(k_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, sp);
 }
 void launch_backup(const TreeDev& t, const EvalBatch& eb, int apply_only, hipStream_t s) {
     hipLaunchKernelGGL(k_backup, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, apply_only);
