@@ -320,7 +320,7 @@ const char* az_last_error(const az_engine* e) { return e ? e->err.c_str() : "nul
 az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (!e || !key) return AZ_ERR_BAD_ARGUMENT;
     if (std::strcmp(key, "gemm_variant") == 0 &&
-        (value == 0 || value == 1 || value == 2 || value == 5 || (value >= 11 && value <= 17))) {
+        (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || (value >= 11 && value <= 17))) {
         convnet_set_variant((int)value);
         return AZ_OK;
     }

@@ -603,6 +603,174 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
     }
 }
 
+// ---- conv2 image-resident, TWO independent workgroups per CU ---------------------------------------------------------
+// k_conv_img's 8 waves share one barrier, so the two waves of every SIMD run in lockstep: both in their MFMA clusters
+// (contending for the matrix pipe), then both parked at the wait / barrier (pipe idle; SQ_WAIT_INST_ANY 42 %,
+// SQ_WAIT_ANY 38 % of wave cycles).  Here the same per-wave work (128 rows x 64 columns, 8 x 4 accumulators) is packaged
+// as workgroups of 4 waves -- tile = 6 boards x 128 channels, LDS = one image buffer (32 KiB) + two weight buffers
+// (16 KiB each) = 64 KiB -- so two workgroups fit a CU and every SIMD holds one wave of each: their barriers are
+// independent and their phases drift apart.  The price is a single image buffer (the image switch every 9 K-steps is
+// exposed inside a workgroup and covered by the other one).  Same K order: bit-identical.
+constexpr int HBN2_ = 128;
+
+template <int LAYER>
+__global__ __launch_bounds__(256, 2) void k_conv_img2(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32768];   // img | w[2] (16 KiB each)
+    const int n_boards = (int)(*d.n_dev);
+    const int M = n_boards * 42;
+    const int C = d.cin;
+    const int NT = d.N / HBN2_;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * IMG_NB, n0 = ntile * HBN2_;
+    if (b0 >= n_boards) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    if (tid < 8) *(uint4*)(smem + IMG_ZERO_ROW * 128 + tid * 16) = make_uint4(0, 0, 0, 0);
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    // image DMA map: piece q (0..7) of wave w = LDS rows (q*4 + w)*8 + lrow; rows >= 252 are not loaded
+    uint32_t i_ob[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int r = (q * 4 + wave) * 8 + lrow;
+        r = r < IMG_ROWS ? r : IMG_ROWS - 1;
+        int b = b0 + r / 42;
+        b = b < n_boards ? b : n_boards - 1;
+        const int p = r % 42, y = p / 7, x = p - y * 7;
+        i_ob[q] = (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8) * 2u;
+    }
+    const bool i_last_ok = (7 * 4 + wave) * 8 + lrow < IMG_ROWS;          // only piece 7 can run past row 251
+    // weight DMA map: piece q (0..3) of wave w = tile rows (q*4 + w)*8 + lrow
+    const uint32_t b_ob0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
+    const uint32_t b_stepb = 64u * (uint32_t)d.K;                        // 32 weight rows, in bytes
+    const uint32_t b_ob1 = b_ob0 + b_stepb, b_ob2 = b_ob0 + 2u * b_stepb, b_ob3 = b_ob0 + 3u * b_stepb;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define AZ_2DMA_W(kk_, buf_)                                                                                 \
+    {                                                                                                        \
+        unsigned char* lb = smem + 32768 + (buf_) * 16384 + wave * 1024;                                     \
+        const char* wbase = (const char*)(d.W + (kk_));                                                      \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);                 \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 4096), 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 8192), 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 12288), 16, 0, 0);         \
+    }
+#define AZ_2DMA_IMG(cb_)                                                                                     \
+    {                                                                                                        \
+        unsigned char* la = smem + wave * 1024;                                                              \
+        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_)                                                     \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
+        if (i_last_ok) __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[7]), (lds_ptr)(la + 7 * 4096), 16, 0, 0); \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    uint32_t rowmask[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int ml = wr * 128 + mt * 16 + frow;
+        const int p = ml % 42, y = p / 7, x = p - y * 7;
+        uint32_t mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            if (ml < IMG_ROWS && iy >= 0 && iy < 6 && ix >= 0 && ix < 7) mask |= 1u << t;
+        }
+        rowmask[mt] = (uint32_t)ml | (mask << 16);
+    }
+    const int b_row0 = 32768 + (wc * 64 + frow) * 128;
+    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
+#define AZ_2LDA(dst_, mt0_, ks_)                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+        const uint32_t rm_ = rowmask[(mt0_) + i_];                                                           \
+        const int r_ = ((rm_ >> tapbit) & 1u) ? (int)(rm_ & 0xFFFFu) + dt : IMG_ZERO_ROW;                    \
+        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
+    }
+#define AZ_2LDB(dst_, wb_, coff_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        dst_[i_] = *(const bf16x8*)((wb_) + b_row0 + i_ * 2048 + (coff_));
+#define AZ_2MMA(mt0_, fb_, fa_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+    const int ncb = C / 64;
+    const int nk = ncb * 9;
+    AZ_2DMA_W(0, 0);
+    AZ_2DMA_IMG(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cb = 0, tap = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            const int ntap = tap == 8 ? 0 : tap + 1, ncbi = tap == 8 ? cb + 1 : cb;
+            AZ_2DMA_W(ntap * C + ncbi * 64, (kt + 1) & 1);
+        }
+        const unsigned char* sW = smem + (kt & 1) * 16384;       // b_row0 already carries the 32 KiB image offset
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int dt = (ky - 1) * 7 + (kx - 1);
+        const int tapbit = 16 + tap;
+        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+        AZ_2LDB(fbX, sW, coffB0);
+        AZ_2LDA(faX, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_2LDA(faY, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_2MMA(0, fbX, faX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_2LDB(fbY, sW, coffB1);
+        AZ_2LDA(faX, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_2MMA(4, fbX, faY);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_2LDA(faY, 4, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_2MMA(0, fbY, faX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_2MMA(4, fbY, faY);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (++tap == 9) {
+            tap = 0;
+            ++cb;
+            if (cb < ncb) {                    // image switch: everybody is past the barrier, i.e. done with image cb-1
+                AZ_2DMA_IMG(cb);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    }
+#undef AZ_2DMA_W
+#undef AZ_2DMA_IMG
+#undef AZ_2LDA
+#undef AZ_2LDB
+#undef AZ_2MMA
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ml = wr * 128 + mt * 16 + frow;
+            const int m = b0 * 42 + ml;
+            if (ml >= IMG_ROWS || m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
 // ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
 // one wave per sample; lane holds 8 of the 512 inputs.
 __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_t* __restrict__ x /*[n][512] bf16*/,
@@ -812,22 +980,25 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
     convnet_set_params(net, p.data(), L.total);
 }
 
-int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants 0, 1, 2, 5 are bit-identical:
+int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants 0, 1, 2, 3, 5 are bit-identical:
                           // 0: 128x128 register-staged tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3(/conv4);
-                          // 2: + hand-phased fragment prefetch; 5 (default): conv2 image-resident (k_conv_img), rest as 2;
-                          // 11-17: timing ablations / clock stamps of variant 2 (WRONG results, tools/ only).
-                          // Rejected and removed after measurement (numbers in profiles/README.md, code in git history):
-                          // 4-stage ring, XCD column remap, third weight buffer, late / spread DMA issue, mid barrier,
-                          // 32x32x16 MFMA shape, non-temporal cache policy.
+                          // 2: + hand-phased fragment prefetch; 3: conv2 image-resident, one 8-wave workgroup per CU
+                          // (k_conv_img), rest as 2; 5 (default): conv2 image-resident, two 4-wave workgroups per CU
+                          // (k_conv_img2), rest as 2; 11-17: timing ablations / clock stamps of variant 2 (WRONG results,
+                          // tools/ only).  Rejected and removed after measurement (numbers in profiles/README.md, code in
+                          // git history): 4-stage ring, XCD column remap, third weight buffer, late / spread DMA issue, mid
+                          // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
+                          // split, cross-step fragment prefetch, weights straight into registers.
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
 
 template <int LAYER>
 static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     const int v = g_gemm_variant;
-    if (v == 5 && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
+    if ((v == 3 || v == 5) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
         const int t8 = (tiles + 7) / 8 * 8;
-        hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
+        if (v == 5) hipLaunchKernelGGL((k_conv_img2<LAYER>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
     const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_hint >= 4096)))) &&

@@ -93,9 +93,9 @@ az_status az_create(const az_config* cfg, az_engine** out);
 void az_destroy(az_engine* e);
 const char* az_last_error(const az_engine* e);
 /* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
- * net uses (0 = 128x128 register-staged tiles for every layer, 1 / 2 = 256x256 LDS-DMA tiles, 5 = default, conv2
- * image-resident; 11-17 = timing ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 5 are
- * bit-identical. "conv4_big" = 0 / 1 / 2 (auto). Unknown keys or values return AZ_ERR_BAD_ARGUMENT. */
+ * net uses (0 = 128x128 register-staged tiles for every layer, 1 / 2 = 256x256 LDS-DMA tiles, 3 = conv2 image-resident
+ * in one 8-wave workgroup per CU, 5 = default, conv2 image-resident in two 4-wave workgroups per CU; 11-17 = timing
+ * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto). Unknown keys or values return AZ_ERR_BAD_ARGUMENT. */
 az_status az_set_option(az_engine* e, const char* key, int64_t value);
 az_status az_get_stats(az_engine* e, az_stats* out);
 az_status az_reset_stats(az_engine* e);

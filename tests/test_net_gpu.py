@@ -77,15 +77,15 @@ def test_net_rows_are_batch_independent(conv_engine, oracle):
 
 
 def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
-    """The four implicit-GEMM kernel sets (128x128 register-staged, 256x256 LDS-DMA unphased / phased, image-resident
-    conv2) sum every output row's K terms in the same order: their results are identical bit for bit, at ragged and
+    """The implicit-GEMM kernel sets (128x128 register-staged, 256x256 LDS-DMA unphased / phased, image-resident conv2
+    as one 8-wave or two 4-wave workgroups per CU) sum every output row's K terms in the same order: their results are identical bit for bit, at ragged and
     tile-aligned batch sizes, so the A/B switch never changes what a search sees."""
     conv_engine.net_init_random(5, seed=21)
     try:
         for n in (1, 257, 1530):
             states = random_states(oracle, n, seed=900 + n)
             outs = []
-            for variant in (0, 1, 2, 5):
+            for variant in (0, 1, 2, 3, 5):
                 conv_engine.set_option("gemm_variant", variant)
                 outs.append(conv_engine.predict_states(states, 5))
             for pi, v in outs[1:]:
@@ -95,7 +95,7 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
             pi, v = conv_engine.predict_states(states, 5)
             assert np.array_equal(pi, outs[0][0]) and np.array_equal(v, outs[0][1])
         with pytest.raises(Exception):
-            conv_engine.set_option("gemm_variant", 3)         # removed variants are refused, not silently mapped
+            conv_engine.set_option("gemm_variant", 4)         # removed variants are refused, not silently mapped
     finally:
         conv_engine.set_option("gemm_variant", 5)
         conv_engine.set_option("conv4_big", 2)

@@ -10,7 +10,7 @@ e = azeng.Engine(device=0, max_batch=B, profile=True)
 e.net_init_random(0, 1)
 uniq = random_states(512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, B)]
-VARS = tuple(int(x) for x in os.environ.get('VARS', '0,2,5').split(','))
+VARS = tuple(int(x) for x in os.environ.get('VARS', '0,2,3,5').split(','))
 outs = {}
 for v in VARS:
     e.set_option("gemm_variant", v)
