@@ -25,7 +25,7 @@ def main():
     write, nw = fold(sys.argv[2], "WRITE_SIZE")
     line = json.loads([l for l in open(sys.argv[3]).read().splitlines() if l.startswith("{")][-1])
     leaf_evals = line["leaf_evals_per_sec"] * line["ms_per_step"] * line["steps"] / 1e3
-    conv = [k for k in fetch if "k_conv_img" in k]
+    conv = [k for k in fetch if "k_conv_img" in k]   # k_conv_img2<1> (default) or k_conv_img<1>
     launches = nf[conv[0]] if conv else max(nf.values())
     per_launch_leaves = leaf_evals / launches
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --episodes 8192 "
