@@ -22,6 +22,7 @@ panicking.
 """
 import collections
 import os
+import time
 
 import numpy as np
 
@@ -112,8 +113,11 @@ class Coach:
         rank, world = self._world()
         report = []
         for iteration in range(self.start_iteration, self.start_iteration + self.num_iters):
+            t_play = t_train = t_arena = 0.0
             if not skip_first_play or iteration > self.start_iteration:
+                t0 = time.perf_counter()
                 boards, pis, vs = self.execute_episodes(model_id, iteration, seed)
+                t_play = time.perf_counter() - t0
                 if vs.shape[0] > self.max_queue_length:                 # :275-277: keep the newest max_queue_length
                     boards, pis, vs = boards[-self.max_queue_length:], pis[-self.max_queue_length:], vs[-self.max_queue_length:]
                 self.history.append((boards, pis, vs))
@@ -127,6 +131,7 @@ class Coach:
             assert allv.shape[0] > 0                                    # :305
             perm = shuffle_permutation(allv.shape[0], seed, iteration)  # :296-297 shuffle
             allb, allp, allv = allb[perm], allp[perm], allv[perm]
+            t0 = time.perf_counter()
             if self.trainer is None:                                    # :329 -> NNet::train(samples, id, id + 1)
                 self.engine.set_option("train_seed", seed + iteration)
                 losses = self.engine.train(model_id, model_id + 1, allb, allp, allv)
@@ -135,6 +140,8 @@ class Coach:
                 new = self.trainer.train(prev, allb, allp, allv, seed=seed + iteration)
                 self.engine.net_set_params(model_id + 1, new)
                 losses = list(self.trainer.history)
+            t_train = time.perf_counter() - t0
+            t0 = time.perf_counter()
             if rank == 0:
                 self.engine.net_save(model_id + 1, os.path.join(self.dir, f"{model_id + 1}.aznet"))
             # arena: new (first listed) vs old, both seatings (:333-375); games sharded by global index across ranks,
@@ -159,12 +166,14 @@ class Coach:
                 wld, _ = self.engine.arena(self.num_arena_games, self.num_sims, new_model_id=model_id + 1, old_model_id=model_id,
                                            seed=a_seed, max_depth=self.max_depth, cpuct=self.cpuct,
                                            reserve=self.mcts_reserve_size)
+            t_arena = time.perf_counter() - t0
             nwins, pwins, draws = int(wld[0]), int(wld[1]), int(wld[2])
             self.log(f"NEW/PREV WINS : {nwins} / {pwins}; DRAWS : {draws}")            # :381
             accepted = not (pwins + nwins == 0 or nwins / (pwins + nwins) < self.update_threshold)   # :383-390
             self.log("ACCEPTING NEW MODEL" if accepted else "REJECTING NEW MODEL")
             report.append({"iteration": iteration, "samples": int(allv.shape[0]), "nwins": nwins, "pwins": pwins,
-                           "draws": draws, "accepted": accepted, "losses": losses, "model_id": model_id})
+                           "draws": draws, "accepted": accepted, "losses": losses, "model_id": model_id,
+                           "seconds": {"selfplay": t_play, "train": t_train, "arena": t_arena}})
             if accepted:
                 model_id += 1
         self.model_id = model_id

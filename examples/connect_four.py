@@ -48,7 +48,8 @@ def main():
                         trainer=Trainer(channels=a.channels, epochs=a.epochs) if a.trainer == "torch" else None)
     for r in coach.learn(skip_first_play=False, seed=a.seed):
         print(r["iteration"], "samples", r["samples"], "new/prev/draw", r["nwins"], r["pwins"], r["draws"],
-              "accepted" if r["accepted"] else "rejected", "loss", r["losses"][-1])
+              "accepted" if r["accepted"] else "rejected", "loss", r["losses"][-1],
+              "seconds", {k: round(v, 2) for k, v in r["seconds"].items()})
     e.close()
 
 
