@@ -414,21 +414,19 @@ __global__ __launch_bounds__(64) void k_heads_loss(const float* __restrict__ a, 
     }
 }
 
-// fixed-order sum of the per-sample losses into the running totals (one thread: b <= 256)
-__global__ void k_loss_accumulate(const float* __restrict__ sample_loss, int b, double* __restrict__ totals) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double lp = 0.0, lv = 0.0;
-    for (int j = 0; j < b; ++j) { lp += sample_loss[2 * j]; lv += sample_loss[2 * j + 1]; }
-    totals[0] += lp / b;
-    totals[1] += lv / b;
-}
-
 // d pi_w[k][o] = sum_j a[j][k] dhead[j][o], d v_w[k] = sum_j a[j][k] dhead[j][7]; biases = column sums of dhead;
 // da[j][k] = sum_o dhead[j][o] pi_w[k][o] + dhead[j][7] v_w[k]
 __global__ void k_heads_bwd(const float* __restrict__ a, const float* __restrict__ dhead, const float* __restrict__ pi_w,
                             const float* __restrict__ v_w, int b, float* __restrict__ d_pi_w, float* __restrict__ d_pi_b,
-                            float* __restrict__ d_v_w, float* __restrict__ d_v_b, float* __restrict__ da) {
+                            float* __restrict__ d_v_w, float* __restrict__ d_v_b, float* __restrict__ da,
+                            const float* __restrict__ sample_loss, double* __restrict__ totals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {       // fixed-order sum of the per-sample losses into the running totals (b <= 256)
+        double lp = 0.0, lv = 0.0;
+        for (int j = 0; j < b; ++j) { lp += sample_loss[2 * j]; lv += sample_loss[2 * j + 1]; }
+        totals[0] += lp / b;
+        totals[1] += lv / b;
+    }
     if (i < 512 * 8) {
         const int k = i >> 3, o = i & 7;
         float s = 0.0f;
@@ -684,10 +682,9 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     }
     hipLaunchKernelGGL(k_heads_loss, dim3(b), dim3(64), 0, s, t->a[5], P + L.pi_w, P + L.pi_b, P + L.v_w, P + L.v_b, d_pis, d_vs, b,
                        t->dhead, t->sample_loss, t->logits);
-    hipLaunchKernelGGL(k_loss_accumulate, dim3(1), dim3(64), 0, s, t->sample_loss, b, t->loss_totals);
     // ---- backward ----
     hipLaunchKernelGGL(k_heads_bwd, grid1(std::max<int64_t>(512 * 8 + 8, (int64_t)b * 512)), dim3(256), 0, s, t->a[5], t->dhead,
-                       P + L.pi_w, P + L.v_w, b, G + L.pi_w, G + L.pi_b, G + L.v_w, G + L.v_b, t->dact);
+                       P + L.pi_w, P + L.v_w, b, G + L.pi_w, G + L.pi_b, G + L.v_w, G + L.v_b, t->dact, t->sample_loss, t->loss_totals);
     for (int l = 5; l >= 0; --l) {
         const LayerDef& d = ld[l];
         // t->dact holds d loss / d a[l]  ->  dz (through dropout, ReLU and BatchNorm)
