@@ -230,6 +230,22 @@ def test_full_size_properties(engine):
     assert np.array_equal(zs[0::2], zs[1::2])
 
 
+def test_full_size_spot_check_against_oracle(engine, oracle):
+    """BASELINE config-2 size (8192 concurrent games, 100 sims/move) with the hash net: 40 game ids picked at random
+    from the 8192 are replayed one by one on the oracle and must match move for move, tuple for tuple (the oracle
+    alone would need minutes for all of them; game g depends only on (seed, g), never on its neighbours)."""
+    n, sims, seed = 8192, 100, 21
+    got = engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=seed, want_boards=False)
+    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
+    assert offs[-1] == got["count"]
+    for g in np.random.default_rng(0).choice(n, size=40, replace=False):
+        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=seed, first_game_id=int(g))
+        L = int(ref["game_len"][0])
+        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
+        lo, hi = offs[g], offs[g + 1]
+        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+
+
 # ---- arena::play_games (C16) -----------------------------------------------------------------------
 @pytest.mark.parametrize("num,sims", [(2, 25), (12, 50), (64, 100)])
 def test_arena_matches_play_games(engine, oracle, engine_mod, num, sims):
