@@ -771,6 +771,165 @@ __global__ __launch_bounds__(256, 2) void k_conv_img2(const GemmDesc d) {
     }
 }
 
+// ---- conv3 ('valid' 3x3, [6][7][C] -> [4][5][C]) image-resident, two 4-wave workgroups per CU --------------------------
+// The lockstep argument of k_conv_img2 for conv3.  Tile = 12 boards (240 output rows, padded to 256) x 128 channels, waves
+// 2 x 2 with 128 rows x 64 columns each (8 x 4 accumulators, 64 MFMAs per K-step).  LDS = the 12 boards' input image (504
+// rows x 128 B = 63 KiB, one buffer) + ONE 16 KiB weight buffer = 80 KiB: both 32-deep halves of the step's weight
+// fragments are read into registers first, a barrier behind those reads frees the buffer, and the next weight tile is
+// DMA'd under the rest of the step.  L2 -> LDS traffic is 23 KiB per K-step for 3.9 MFLOP (k_gemm256: 64 KiB for 8.4).
+// A 'valid' conv needs no padding logic: output (y, x) of a board reads image row (y+ky)*7 + (x+kx).  Same K order:
+// bit-identical.
+constexpr int C3_NB = 12, C3_ROWS = C3_NB * 20, C3_IMG_ROWS = C3_NB * 42;
+
+template <int LAYER>
+__global__ __launch_bounds__(256, 2) void k_conv3_img2(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[65536 + 16384];   // img (63 KiB used) | w
+    const int n_boards = (int)(*d.n_dev);
+    const int M = n_boards * 20;
+    const int C = d.cin;
+    const int NT = d.N / 128;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * C3_NB, n0 = ntile * 128;
+    if (b0 >= n_boards) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    // image DMA: piece q (0..15) of wave w = LDS rows (q*4 + w)*8 + lrow of the 504 input rows (12 boards x 42 positions)
+    uint32_t i_ob[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        int r = (q * 4 + wave) * 8 + lrow;
+        r = r < C3_IMG_ROWS ? r : C3_IMG_ROWS - 1;
+        int g = b0 * 42 + r;
+        g = g < n_boards * 42 ? g : n_boards * 42 - 1;
+        i_ob[q] = (uint32_t)(g * C + chunk * 8) * 2u;
+    }
+    const bool i_last_ok = (15 * 4 + wave) * 8 + lrow < C3_IMG_ROWS;       // only piece 15 of wave 3 runs past row 503
+    // weight DMA: piece q (0..3) of wave w = tile rows (q*4 + w)*8 + lrow
+    const uint32_t b_ob0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
+    const uint32_t b_stepb = 64u * (uint32_t)d.K;                        // 32 weight rows, in bytes
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define AZ_3DMA_W(kk_)                                                                                       \
+    {                                                                                                        \
+        unsigned char* lb = smem + 65536 + wave * 1024;                                                      \
+        const char* wbase = (const char*)(d.W + (kk_));                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                     \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0 + (uint32_t)q_ * b_stepb), (lds_ptr)(lb + q_ * 4096), 16, 0, 0); \
+    }
+#define AZ_3DMA_IMG(cb_)                                                                                     \
+    {                                                                                                        \
+        unsigned char* la = smem + wave * 1024;                                                              \
+        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 15; ++q_)                                                    \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
+        if (i_last_ok) __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[15]), (lds_ptr)(la + 15 * 4096), 16, 0, 0); \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    int rbase[8];                       // image row of tap (0,0) for this lane's row of each of the 8 row tiles
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        int ml = wr * 128 + mt * 16 + frow;
+        ml = ml < C3_ROWS ? ml : 0;
+        const int bl = ml / 20, p = ml - bl * 20, y = p / 5, x = p - y * 5;
+        rbase[mt] = bl * 42 + y * 7 + x;
+    }
+    const int b_row0 = 65536 + (wc * 64 + frow) * 128;
+    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
+#define AZ_3LDA(dst_, mt0_, ks_)                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+        const int r_ = rbase[(mt0_) + i_] + dt;                                                              \
+        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
+    }
+#define AZ_3LDB(dst_, coff_)                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        dst_[i_] = *(const bf16x8*)(smem + b_row0 + i_ * 2048 + (coff_));
+#define AZ_3MMA(mt0_, fb_, fa_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+    const int ncb = C / 64;
+    const int nk = ncb * 9;
+    AZ_3DMA_W(0);
+    AZ_3DMA_IMG(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cb = 0, tap = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int dt = ky * 7 + kx;
+        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+        AZ_3LDB(fbX, coffB0);
+        AZ_3LDB(fbY, coffB1);
+        AZ_3LDA(faX, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the step's weight fragments are in registers: free the buffer
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            const int ntap = tap == 8 ? 0 : tap + 1, ncbi = tap == 8 ? cb + 1 : cb;
+            AZ_3DMA_W(ntap * C + ncbi * 64);
+        }
+        AZ_3LDA(faY, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_3MMA(0, fbX, faX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_3LDA(faX, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_3MMA(4, fbX, faY);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_3LDA(faY, 4, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_3MMA(0, fbY, faX);
+        __builtin_amdgcn_sched_barrier(0);
+        AZ_3MMA(4, fbY, faY);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (++tap == 9) {
+            tap = 0;
+            ++cb;
+            if (cb < ncb) {                    // image switch (single buffer): covered by the CU's other workgroup
+                AZ_3DMA_IMG(cb);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    }
+#undef AZ_3DMA_W
+#undef AZ_3DMA_IMG
+#undef AZ_3LDA
+#undef AZ_3LDB
+#undef AZ_3MMA
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ml = wr * 128 + mt * 16 + frow;
+            const int m = b0 * 20 + ml;
+            if (ml >= C3_ROWS || m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
 // ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
 // one wave per sample; lane holds 8 of the 512 inputs.
 __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_t* __restrict__ x /*[n][512] bf16*/,
@@ -983,8 +1142,8 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
 int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants 0, 1, 2, 3, 5 are bit-identical:
                           // 0: 128x128 register-staged tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3(/conv4);
                           // 2: + hand-phased fragment prefetch; 3: conv2 image-resident, one 8-wave workgroup per CU
-                          // (k_conv_img), rest as 2; 5 (default): conv2 image-resident, two 4-wave workgroups per CU
-                          // (k_conv_img2), rest as 2; 11-17: timing ablations / clock stamps of variant 2 (WRONG results,
+                          // (k_conv_img), rest as 2; 5 (default): conv2 and conv3 image-resident, two 4-wave workgroups per
+                          // CU (k_conv_img2, k_conv3_img2), rest as 2; 11-17: timing ablations / clock stamps of variant 2 (WRONG results,
                           // tools/ only).  Rejected and removed after measurement (numbers in profiles/README.md, code in
                           // git history): 4-stage ring, XCD column remap, third weight buffer, late / spread DMA issue, mid
                           // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
@@ -1003,6 +1162,12 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     }
     const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_hint >= 4096)))) &&
                      d.N % HBN_ == 0;
+    if (v == 5 && LAYER == 2 && d.N % 128 == 0 && d.cin % 64 == 0 && d.rows_per_sample == 20) {   // conv3 image-resident
+        const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
+        const int t8 = (tiles + 7) / 8 * 8;
+        hipLaunchKernelGGL((k_conv3_img2<LAYER>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
+        return;
+    }
     if (big) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
