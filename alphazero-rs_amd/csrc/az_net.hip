@@ -771,63 +771,68 @@ __global__ __launch_bounds__(256, 2) void k_conv_img2(const GemmDesc d) {
     }
 }
 
-// ---- conv3 ('valid' 3x3, [6][7][C] -> [4][5][C]) image-resident, two 4-wave workgroups per CU --------------------------
-// The lockstep argument of k_conv_img2 for conv3.  Tile = 12 boards (240 output rows, padded to 256) x 128 channels, waves
-// 2 x 2 with 128 rows x 64 columns each (8 x 4 accumulators, 64 MFMAs per K-step).  LDS = the 12 boards' input image (504
-// rows x 128 B = 63 KiB, one buffer) + ONE 16 KiB weight buffer = 80 KiB: both 32-deep halves of the step's weight
+// ---- 'valid' 3x3 convs (conv3: [6][7][C] -> [4][5][C], conv4: [4][5][C] -> [2][3][C]) image-resident, two 4-wave
+// workgroups per CU ---------------------------------------------------------------------------------------------------
+// The lockstep argument of k_conv_img2 for the 'valid' convs.  Tile = NB boards (NB*OH*OW output rows, padded to 128 or
+// 256) x NCOL channels; every wave owns 128 rows x 64 columns (8 x 4 accumulators, 64 MFMAs per K-step):
+//   conv3: NB = 12 (240 of 256 rows), NCOL = 128, waves 2 x 2; LDS = 63 KiB image + 16 KiB weights
+//   (conv4: NB = 19 (114 of 128 rows), NCOL = 256, waves 1 x 4, 47.5 KiB image + 32 KiB weights -- measured neutral, not used)
+// i.e. 80 KiB = the boards' input image (one buffer) + ONE weight buffer: both 32-deep halves of the step's weight
 // fragments are read into registers first, a barrier behind those reads frees the buffer, and the next weight tile is
-// DMA'd under the rest of the step.  L2 -> LDS traffic is 23 KiB per K-step for 3.9 MFLOP (k_gemm256: 64 KiB for 8.4).
-// A 'valid' conv needs no padding logic: output (y, x) of a board reads image row (y+ky)*7 + (x+kx).  Same K order:
-// bit-identical.
-constexpr int C3_NB = 12, C3_ROWS = C3_NB * 20, C3_IMG_ROWS = C3_NB * 42;
-
-template <int LAYER>
-__global__ __launch_bounds__(256, 2) void k_conv3_img2(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[65536 + 16384];   // img (63 KiB used) | w
+// DMA'd under the rest of the step.  A 'valid' conv needs no padding logic: output (y, x) of a board reads image row
+// (y+ky)*IW + (x+kx).  Same K order: bit-identical.
+template <int LAYER, int NB, int IH, int IW, int WN>
+__global__ __launch_bounds__(256, 2) void k_conv_valid_img2(const GemmDesc d) {
+    constexpr int OH = IH - 2, OW = IW - 2, OUT_PER = OH * OW, IN_PER = IH * IW;
+    constexpr int OUT_ROWS = NB * OUT_PER, IMG_R = NB * IN_PER;
+    constexpr int NCOL = WN == 4 ? 256 : 128;
+    constexpr int IMG_BYTES = (IMG_R * 128 + 1023) / 1024 * 1024;
+    constexpr int IPIECES = (IMG_R + 31) / 32, WPIECES = NCOL / 32;       // 1 KiB DMA pieces per wave
+    static_assert(IMG_BYTES + NCOL * 128 <= 81920, "two workgroups must fit a CU's 160 KiB");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IMG_BYTES + NCOL * 128];   // img | w
     const int n_boards = (int)(*d.n_dev);
-    const int M = n_boards * 20;
+    const int M = n_boards * OUT_PER;
     const int C = d.cin;
-    const int NT = d.N / 128;
+    const int NT = d.N / NCOL;
     const int id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
     const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int b0 = mtile * C3_NB, n0 = ntile * 128;
+    const int b0 = mtile * NB, n0 = ntile * NCOL;
     if (b0 >= n_boards) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = WN == 4 ? 0 : wave >> 1, wc = WN == 4 ? wave : wave & 1;
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ lrow;
-    // image DMA: piece q (0..15) of wave w = LDS rows (q*4 + w)*8 + lrow of the 504 input rows (12 boards x 42 positions)
-    uint32_t i_ob[16];
+    // image DMA: piece q of wave w = LDS rows (q*4 + w)*8 + lrow of the NB boards' IN_PER input rows each
+    uint32_t i_ob[IPIECES];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < IPIECES; ++q) {
         int r = (q * 4 + wave) * 8 + lrow;
-        r = r < C3_IMG_ROWS ? r : C3_IMG_ROWS - 1;
-        int g = b0 * 42 + r;
-        g = g < n_boards * 42 ? g : n_boards * 42 - 1;
+        r = r < IMG_R ? r : IMG_R - 1;
+        int g = b0 * IN_PER + r;
+        g = g < n_boards * IN_PER ? g : n_boards * IN_PER - 1;
         i_ob[q] = (uint32_t)(g * C + chunk * 8) * 2u;
     }
-    const bool i_last_ok = (15 * 4 + wave) * 8 + lrow < C3_IMG_ROWS;       // only piece 15 of wave 3 runs past row 503
-    // weight DMA: piece q (0..3) of wave w = tile rows (q*4 + w)*8 + lrow
+    // weight DMA: piece q of wave w = tile rows (q*4 + w)*8 + lrow
     const uint32_t b_ob0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
     const uint32_t b_stepb = 64u * (uint32_t)d.K;                        // 32 weight rows, in bytes
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
 #define AZ_3DMA_W(kk_)                                                                                       \
     {                                                                                                        \
-        unsigned char* lb = smem + 65536 + wave * 1024;                                                      \
+        unsigned char* lb = smem + IMG_BYTES + wave * 1024;                                                  \
         const char* wbase = (const char*)(d.W + (kk_));                                                      \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < WPIECES; ++q_)                                               \
             __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0 + (uint32_t)q_ * b_stepb), (lds_ptr)(lb + q_ * 4096), 16, 0, 0); \
     }
 #define AZ_3DMA_IMG(cb_)                                                                                     \
     {                                                                                                        \
         unsigned char* la = smem + wave * 1024;                                                              \
         const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < 15; ++q_)                                                    \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
-        if (i_last_ok) __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[15]), (lds_ptr)(la + 15 * 4096), 16, 0, 0); \
+        _Pragma("unroll") for (int q_ = 0; q_ < IPIECES; ++q_)                                               \
+            if ((q_ * 4 + wave) * 8 + lrow < IMG_R)                                                          \
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
     }
     f32x4 acc[8][4];
 #pragma unroll
@@ -839,11 +844,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3_img2(const GemmDesc d) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         int ml = wr * 128 + mt * 16 + frow;
-        ml = ml < C3_ROWS ? ml : 0;
-        const int bl = ml / 20, p = ml - bl * 20, y = p / 5, x = p - y * 5;
-        rbase[mt] = bl * 42 + y * 7 + x;
+        ml = ml < OUT_ROWS ? ml : 0;
+        const int bl = ml / OUT_PER, p = ml - bl * OUT_PER, y = p / OW, x = p - y * OW;
+        rbase[mt] = bl * IN_PER + y * IW + x;
     }
-    const int b_row0 = 65536 + (wc * 64 + frow) * 128;
+    const int b_row0 = IMG_BYTES + (wc * 64 + frow) * 128;
     const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
 #define AZ_3LDA(dst_, mt0_, ks_)                                                                             \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
@@ -866,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_img2(const GemmDesc d) {
     int cb = 0, tap = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const int ky = tap / 3, kx = tap - ky * 3;
-        const int dt = ky * 7 + kx;
+        const int dt = ky * IW + kx;
         bf16x8 fbX[4], fbY[4], faX[4], faY[4];
         AZ_3LDB(fbX, coffB0);
         AZ_3LDB(fbY, coffB1);
@@ -917,8 +922,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_img2(const GemmDesc d) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int ml = wr * 128 + mt * 16 + frow;
-            const int m = b0 * 20 + ml;
-            if (ml >= C3_ROWS || m >= M) continue;
+            const int m = b0 * OUT_PER + ml;
+            if (ml >= OUT_ROWS || m >= M) continue;
             float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
                   r3 = acc[mt][nt][3] + bv.w;
             if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
@@ -929,6 +934,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_img2(const GemmDesc d) {
         }
     }
 }
+constexpr int C3_NB = 12;     // (conv4 as <L, 19, 4, 5, 4> is bit-identical too and was measured neutral: it stays on k_gemm256)
 
 // ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
 // one wave per sample; lane holds 8 of the 512 inputs.
@@ -1162,10 +1168,10 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     }
     const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_hint >= 4096)))) &&
                      d.N % HBN_ == 0;
-    if (v == 5 && LAYER == 2 && d.N % 128 == 0 && d.cin % 64 == 0 && d.rows_per_sample == 20) {   // conv3 image-resident
+    if constexpr (LAYER == 2) if (v == 5 && d.N % 128 == 0 && d.cin % 64 == 0 && d.rows_per_sample == 20) {   // conv3 image-resident
         const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
         const int t8 = (tiles + 7) / 8 * 8;
-        hipLaunchKernelGGL((k_conv3_img2<LAYER>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL((k_conv_valid_img2<LAYER, C3_NB, 6, 7, 2>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
         return;
     }
     if (big) {
