@@ -235,6 +235,7 @@ def main():
         if not args.no_profile and st["tree_ms"] > 0:
             line["tree_hbm"] = {"achieved_GBps": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
                                 "frac": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "frac_of_measured_copy_bw": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9 / 6290.0,
                                 "algorithmic_bytes_per_sim": st["tree_bytes"] / max(1, st["simulations"]),
                                 "mean_depth": st["depth_sum"] / max(1, st["simulations"])}
         if world == 1 and not args.no_cpu_baseline and args.net == "conv":
