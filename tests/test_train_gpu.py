@@ -238,6 +238,26 @@ def test_az_net_train_is_the_documented_sequence_of_steps(tengine):
             tengine.set_option(key, val)
 
 
+def test_train_on_very_few_samples(tengine):
+    """len(examples) < batch_size: one step per epoch on a batch drawn with replacement (connect_four_net.py:127-130
+    would compute 0 batches; the build keeps at least one), all-identical rows included (BatchNorm variance 0)."""
+    boards, pis, vs = make_batch(3, seed=2)
+    tengine.net_init_random(12, seed=4)
+    for key, val in (("train_epochs", 2), ("train_batch", 64)):
+        tengine.set_option(key, val)
+    try:
+        for n in (3, 1):
+            hist = tengine.train(12, 13, boards[:n], pis[:n], vs[:n])
+            assert len(hist) == 2 and all(np.isfinite(h).all() for h in hist)
+            p = tengine.net_get_params(13)
+            assert np.isfinite(p).all() and not np.array_equal(p, tengine.net_get_params(12))
+            pi, v = tengine.predict(boards[:n], 13)
+            assert np.isfinite(pi).all() and np.isfinite(v).all()
+    finally:
+        for key, val in (("train_epochs", 10), ("train_batch", 64)):
+            tengine.set_option(key, val)
+
+
 def test_train_argument_checks(tengine, engine_mod):
     boards, pis, vs = make_batch(4, seed=1)
     e2 = engine_mod.Engine(device=0, max_batch=256, net_channels=C)
