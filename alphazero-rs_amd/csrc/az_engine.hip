@@ -81,7 +81,8 @@ struct Profiler {
 struct TreeHost {
     DeviceMem mem;
     TreeDev d{};
-    EvalBatch eb{};
+    EvalBatch eb{};         // eval batch of even simulations (and of the root evaluation)
+    EvalBatch eb2{};        // eval batch of odd simulations: k_backup_select ping-pongs between the two
     void create(int G, uint64_t R, uint32_t H, int log_cap) {
         d.G = G; d.R = (uint32_t)R; d.H = H;
         size_t slots = (size_t)G * R;
@@ -110,13 +111,15 @@ struct TreeHost {
         HIPCHK(hipMemset(d.log_len, 0, G * sizeof(uint32_t)));
         HIPCHK(hipMemset(d.active, 1, G));
         HIPCHK(hipMemset(d.leaf_kind, 0, G * sizeof(uint32_t)));
-        eb.cap = G;
-        eb.n = mem.alloc<uint32_t>(1);
-        eb.tree = mem.alloc<uint32_t>(G);
-        eb.state = mem.alloc<ulonglong2>(G);
-        eb.pi = mem.alloc<float>((size_t)G * 8);
-        eb.v = mem.alloc<float>(G);
-        HIPCHK(hipMemset(eb.n, 0, sizeof(uint32_t)));
+        for (EvalBatch* b : {&eb, &eb2}) {
+            b->cap = G;
+            b->n = mem.alloc<uint32_t>(1);
+            b->tree = mem.alloc<uint32_t>(G);
+            b->state = mem.alloc<ulonglong2>(G);
+            b->pi = mem.alloc<float>((size_t)G * 8);
+            b->v = mem.alloc<float>(G);
+            HIPCHK(hipMemset(b->n, 0, sizeof(uint32_t)));
+        }
     }
 };
 
@@ -198,20 +201,23 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
                 const NetModel& net, int rows_hint, hipStream_t s = nullptr) {
     if (!s) s = e->stream;
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
+    // root: prepare (its leaf goes to batch 0), predict; then num_sims x {backup of the previous leaf + select of the next
+    // (one launch, the new leaf goes to the other batch), predict}; a last backup closes the search.
     launch_root_prepare(th.d, th.eb, d_root_states, s);
     net_forward(e, net, th.eb, rows_hint, s);
-    launch_backup(th.d, th.eb, 1, s);
+    const EvalBatch* B[2] = {&th.eb, &th.eb2};
     for (int i = 0; i < num_sims; ++i) {
         hipEvent_t t0 = nullptr;
         if (e->prof.on) t0 = e->prof.begin(s);
-        launch_select(th.d, th.eb, sp, s);
-        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
-        if (e->prof.on) t0 = e->prof.begin(s);
-        net_forward(e, net, th.eb, rows_hint, s);
-        if (e->prof.on) { e->prof.end(t0, RG_NET, s); t0 = e->prof.begin(s); }
-        launch_backup(th.d, th.eb, 0, s);
-        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
+        launch_backup_select(th.d, *B[i & 1], *B[(i + 1) & 1], sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
+        if (e->prof.on) { e->prof.end(t0, RG_TREE, s); t0 = e->prof.begin(s); }
+        net_forward(e, net, *B[(i + 1) & 1], rows_hint, s);
+        if (e->prof.on) e->prof.end(t0, RG_NET, s);
     }
+    hipEvent_t t0 = nullptr;
+    if (e->prof.on) t0 = e->prof.begin(s);
+    launch_backup(th.d, *B[num_sims & 1], 0, s);
+    if (e->prof.on) e->prof.end(t0, RG_TREE, s);
 }
 
 void resolve_profile(az_engine* e) {

@@ -103,6 +103,9 @@ void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr 
 void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const ulonglong2* root_states, hipStream_t s);
 void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipStream_t s);
 void launch_backup(const TreeDev& t, const EvalBatch& eb, int apply_only, hipStream_t s);
+// backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf appended to eb_next) in one launch
+void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, SearchParams sp, int apply_only,
+                          hipStream_t s);
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);

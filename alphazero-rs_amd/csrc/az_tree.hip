@@ -193,10 +193,7 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, co
 }
 
 // ---- search_iteration: select + expand (src/async_mcts.rs:226-299, Appendix A of SURVEY.md) ----
-__global__ __launch_bounds__(64) void k_select(TreeDev t, EvalBatch eb, SearchParams sp) {
-    int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid >> 3, sub = tid & 7;
-    if (g >= t.G) return;
+AZ_D void select_body(const TreeDev& t, const EvalBatch& eb, const SearchParams& sp, int g, int sub) {
     if (!t.active[g]) {
         if (sub == 0) t.leaf_kind[g] = LEAF_NONE;
         return;
@@ -291,11 +288,7 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, EvalBatch eb, SearchPa
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
-__global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, int apply_only) {
-    int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid >> 3, sub = tid & 7;
-    if (tid == 0) *eb.n = 0;            // the batch has been consumed (nothing in this kernel reads the count): next select starts at row 0
-    if (g >= t.G) return;
+AZ_D void backup_body(const TreeDev& t, const EvalBatch& eb, int apply_only, int g, int sub) {
     const uint32_t kind = t.leaf_kind[g];
     if (kind == LEAF_NONE) return;
     const size_t base = (size_t)g * t.R;
@@ -400,6 +393,38 @@ AZ_D RootPolicy root_policy(const TreeDev& t, int g, int sub, float temp, uint64
         out.pi = __fdiv_rn(x, sum);
     }
     return out;
+}
+
+__global__ __launch_bounds__(64) void k_select(TreeDev t, EvalBatch eb, SearchParams sp) {
+    const int tid = blockIdx.x * 64 + threadIdx.x;
+    const int g = tid >> 3, sub = tid & 7;
+    if (g >= t.G) return;
+    select_body(t, eb, sp, g, sub);
+}
+
+__global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, int apply_only) {
+    const int tid = blockIdx.x * 64 + threadIdx.x;
+    const int g = tid >> 3, sub = tid & 7;
+    if (tid == 0) *eb.n = 0;            // the batch has been consumed (nothing in this kernel reads the count)
+    if (g >= t.G) return;
+    backup_body(t, eb, apply_only, g, sub);
+}
+
+// backup of simulation i and select of simulation i+1 in one launch: both belong to the same 8 lanes of the same tree and
+// nothing else touches that tree in between.  The leaf of i+1 goes into the OTHER eval batch (eb_next; its count was
+// zeroed by the previous launch, this one zeroes eb_prev's), so the two ping-pong.
+__global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, SearchParams sp,
+                                                      int apply_only) {
+    const int tid = blockIdx.x * 64 + threadIdx.x;
+    const int g = tid >> 3, sub = tid & 7;
+    if (tid == 0) *eb_prev.n = 0;
+    if (g >= t.G) return;
+    backup_body(t, eb_prev, apply_only, g, sub);
+    // the counters this tree's other lanes just wrote are read by the selection below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    select_body(t, eb_next, sp, g, sub);
 }
 
 __global__ __launch_bounds__(64) void k_root_policy(TreeDev t, float temp, uint64_t seed, uint64_t first_game_id,
@@ -576,6 +601,10 @@ void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipSt
 }
 void launch_backup(const TreeDev& t, const EvalBatch& eb, int apply_only, hipStream_t s) {
     hipLaunchKernelGGL(k_backup, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, apply_only);
+}
+void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, SearchParams sp, int apply_only,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_backup_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, sp, apply_only);
 }
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s) {
