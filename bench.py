@@ -210,12 +210,12 @@ def main():
         roof = None
         if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:
             ach = st["net_conv2_flops"] / (st["net_conv2_ms"] * 1e-3) / 1e12
-            # HBM traffic of the same kernel from the committed PMC passes (profiles/r01j_pmc_traffic.json: separate
+            # HBM traffic of the same kernel from the committed PMC passes (profiles/r01k_pmc_traffic.json: separate
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command -- tools/collect_profiles.sh, gfx950 correction
             # applied), scaled by this run's mean leaves per launch.  bench.py cannot collect PMC counters itself.
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")))
                 per_leaf = pmc["kernels"]["void az::k_conv_img2<1>"]["hbm_bytes_per_leaf"]
                 traffic = per_leaf * (st["net_conv2_flops"] / st["net_launches"]) / (2.0 * 42 * 512 * 4608)
             except Exception:
