@@ -100,6 +100,62 @@ def cpu_baseline(params, channels, sims, mean_plies=None, budget_s=20.0, seed=1)
     }
 
 
+def self_launch(n):
+    """`python3 bench.py --gpus N` without torchrun: start N ranks (one per GPU) under torch.distributed.run as a CHILD
+    process -- never an exec, and before anything in this process has initialised the GPU -- and pass its output through.
+    Rank 0 of the children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_dist(args, rank, world):
+    """--dry-dist gloo: the launcher, process group, barrier/timing protocol and the ONE gather of bench.py's N-rank path
+    on CPU with synthetic tuples in place of the engine's output (CPU tests; nothing here is a measurement)."""
+    import torch
+    import torch.distributed as dist
+    from alphazero_rs_amd import dist as azdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(args.dry_dist)
+    episodes = args.episodes or 64
+
+    def step(i):
+        first = (i * world + rank) * episodes
+        g = torch.Generator().manual_seed(first)
+        n = episodes * 7 + rank
+        packed = azdist.pack_samples(torch.randint(0, 2**40, (n, 2), generator=g), torch.rand((n, 7), generator=g),
+                                     torch.rand(n, generator=g))
+        gathered, counts = azdist.gather_samples(packed, dst=0)
+        if rank == 0 and int(counts.sum()) != gathered.shape[0]:
+            raise RuntimeError("gather_samples: count mismatch")
+        return n
+    for i in range(args.warmup):
+        step(i)
+    dist.barrier()
+    t0 = time.perf_counter()
+    tuples = sum(step(args.warmup + i) for i in range(args.steps))
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    agg = torch.tensor([tuples], dtype=torch.float64)
+    dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "selfplay_games_per_sec", "value": 0.0, "unit": "games/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": float(t.item()) / max(1, args.steps) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": f"DRY RUN of the {world}-rank launcher + gather over {args.dry_dist}: no engine, no GPU",
+                                     "parallelism": f"games-sharded x{world}"},
+                          "dry_run": True, "tuples_gathered": float(agg.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,8 +171,15 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and run the gather even at world size 1 (rehearsal)")
+    ap.add_argument("--dry-dist", default="", choices=["", "gloo"],
+                    help="rehearse the N-rank launcher + gather on CPU over gloo with synthetic tuples (no engine, no GPU; value = 0)")
     args = ap.parse_args()
     episodes = args.episodes or 4 * args.games
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python3 bench.py --gpus N`: this parent never touches the GPU (no torch import, no engine); it starts the
+        # N ranks as children of torch.distributed.run and relays their output and exit code
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -125,6 +188,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_dist:
+        return dry_dist(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)

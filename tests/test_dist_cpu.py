@@ -90,3 +90,30 @@ def test_pack_roundtrip_and_symmetries():
     one = torch.tensor([[1 << (2 * 7 + 3), 1 << (6 * 7)]], dtype=torch.int64)
     m, _, _ = azdist.expand_symmetries(one, tp[:1], tz[:1])
     assert m[1, 0].item() == 1 << (4 * 7 + 3) and m[1, 1].item() == 1
+
+
+def test_bench_self_launch_dry_dist_world2():
+    """`python3 bench.py --gpus 2` with no torchrun around it: the parent (which never imports torch or the engine) starts
+    the two ranks itself; with --dry-dist gloo they rehearse the process group, the barrier/MAX-over-ranks timing and the
+    gather on CPU and rank 0 prints exactly one JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dry-dist", "gloo"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dry_run"] is True
+    assert d["tuples_gathered"] == 2 * (64 * 7) * 2 + 2       # both ranks' tuples of both timed steps reached rank 0's count
+
+
+def test_bench_parent_does_not_touch_the_gpu():
+    """The self-launch branch sits before the first torch / engine import of bench.py (a process that has initialised the GPU
+    must not start the ranks)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("self_launch(args.gpus)") < main.index("import torch")
+    launch = src[src.index("def self_launch("):src.index("def dry_dist(")]
+    assert "import torch" not in launch and "engine" not in launch and "subprocess.call" in launch and "os.exec" not in launch
