@@ -132,6 +132,10 @@ AZ_HD float c4_feature(uint64_t mine, uint64_t theirs, int plane, int r, int c) 
     return ((plane == 0 ? mine : theirs) & bit) ? 1.0f : 0.0f;
 }
 AZ_HD uint32_t c4_hash(uint64_t mine, uint64_t theirs) { return (uint32_t)mix64(mine ^ mix64(theirs)); }
+// One-word identity of a canonical state (49 bits, never 0): mask + bottom row puts a single 1 above every column's stones,
+// adding `mine` fills in the mover's stones below it.
+constexpr uint64_t C4_BOTTOM = 1ull | (1ull << 7) | (1ull << 14) | (1ull << 21) | (1ull << 28) | (1ull << 35) | (1ull << 42);
+AZ_HD uint64_t c4_key(uint64_t mine, uint64_t theirs) { return mine + (mine | theirs) + C4_BOTTOM; }
 
 // test-fixture net (exact in f32); oracle twin: hashnet_eval in oracle/az_oracle_games.hpp
 AZ_HD void hashnet_eval(uint64_t mine, uint64_t theirs, uint64_t salt, float* pi, float* v) {

@@ -49,9 +49,37 @@ struct EvalBatch {
     uint32_t* n;          // device: rows in this batch
     uint32_t* tree;       // [cap] row -> tree index
     ulonglong2* state;    // [cap] canonical state to featurise (to_features, connect_four_game.rs:219-237)
-    float* pi;            // [cap*8] net output, 7 used
+    float* pi;            // [cap*8] net output: pi[0..6], v repeated in slot 7
     float* v;             // [cap]
+    // ---- leaf de-duplication (src == nullptr: off, every requested row is evaluated) -------------------------------
+    // Thousands of games share their openings, and a row's (pi, v) depends on nothing but its state (BatchNorm is folded,
+    // every row's K-sum has one order), so evaluating a state once per batch -- or once per call, through the engine's
+    // evaluation cache -- is bit-exact.  The per-tree analogue in the reference is `seen` (src/node.rs:282-289).
+    // k_dedup gives every requested row r a source src[r]: a row u of the UNIQUE batch (ustate/upi/uv, *un rows: what the
+    // net really runs on), a slot of the batch's election table whose winner holds u, or an entry of the evaluation cache.
+    uint32_t* src;        // [cap] SRC_* tagged
+    uint32_t* un;         // device: unique rows of this batch
+    ulonglong2* ustate;   // [cap]
+    float* upi;           // [cap*8]
+    float* uv;            // [cap]
+    unsigned long long* tkey;   // [tmask+1] election table: (epoch << 49) | state key, stale epochs count as empty
+    uint32_t* tuniq;      // [tmask+1] unique row of the slot's winner
+    uint32_t tmask;
 };
+constexpr uint32_t SRC_TABLE = 0x80000000u, SRC_CACHE = 0x40000000u, SRC_INDEX = 0x3FFFFFFFu;
+
+// Evaluation cache of the engine: state key (49 bits) | model tag (15 bits) -> (pi[7], v), 8-way buckets of one 64-byte key
+// line.  Filled by the trees whose row was evaluated (in the backup kernels), read by k_dedup (a later kernel on the same
+// stream), never evicted; entries of a model die with its tag (a new tag per weight upload).  key == nullptr: off.
+struct EvalCache {
+    unsigned long long* key;   // [(bmask+1)*8], 0 = empty
+    float* pv;                 // [(bmask+1)*8][8]
+    uint32_t bmask;            // buckets - 1
+    uint32_t max_stones;       // only states with at most this many stones are inserted
+    unsigned long long tag;    // model tag, already shifted to bits 49..63
+    unsigned long long* stat;  // [DD_COUNT] requested / executed / cache hits / in-batch duplicates / inserts
+};
+enum DedupStat { DD_REQUESTED = 0, DD_EXECUTED, DD_CACHE_HITS, DD_BATCH_DUPS, DD_INSERTS, DD_COUNT };
 
 struct SearchParams {
     uint32_t max_depth;
@@ -102,10 +130,12 @@ void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr 
                         const ulonglong2* roots = nullptr /*[G] root states, nullptr = initial board*/);
 void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const ulonglong2* root_states, hipStream_t s);
 void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipStream_t s);
-void launch_backup(const TreeDev& t, const EvalBatch& eb, int apply_only, hipStream_t s);
+void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s);
 // backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf appended to eb_next) in one launch
-void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, SearchParams sp, int apply_only,
-                          hipStream_t s);
+void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
+                          int apply_only, hipStream_t s);
+// rows [0, *eb.n) -> src[] + the unique batch (eb.src != nullptr); epoch in [1, 32767], the caller clears tkey when it wraps
+void launch_dedup(const EvalBatch& eb, const EvalCache& ec, uint32_t epoch, hipStream_t s);
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);

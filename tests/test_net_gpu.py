@@ -101,6 +101,44 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
         conv_engine.set_option("conv4_big", 2)
 
 
+def test_net_parity_at_bench_scale(engine, oracle):
+    """The regime bench.py drives the net in (NNet::predict on the full batch, src/async_mcts.rs:150-151): ONE call of 8192 rows
+    and one ragged call of 5003 rows (not a multiple of any tile: 6- and 12-board image tiles, 128/256-row GEMM tiles, the
+    8-XCD tile remap with more than one grid round, conv4 on either kernel) must equal, bit for bit, the same rows predicted
+    in chunks of 256 -- the chunk size test_net_matches_torch_reference pins to the torch reference -- for the default and
+    the plain kernel set; plus one direct comparison with the bf16-emulating torch reference at 4096 rows."""
+    engine.net_init_random(20, seed=31)
+    states = random_states(oracle, 8192, seed=77)
+    try:
+        engine.set_option("gemm_variant", 5)
+        engine.set_option("conv4_big", 2)
+        ref_pi = np.empty((8192, 7), np.float32)
+        ref_v = np.empty(8192, np.float32)
+        for o in range(0, 8192, 256):
+            ref_pi[o:o + 256], ref_v[o:o + 256] = engine.predict_states(states[o:o + 256], 20)
+        for variant in (5, 0):
+            for big in (0, 1, 2):
+                engine.set_option("gemm_variant", variant)
+                engine.set_option("conv4_big", big)
+                for n in (8192, 5003):
+                    pi, v = engine.predict_states(states[:n], 20)
+                    assert np.array_equal(pi, ref_pi[:n]) and np.array_equal(v, ref_v[:n]), (variant, big, n)
+        # a different row order through the full-size kernels (rows land in other tiles / XCDs)
+        engine.set_option("gemm_variant", 5)
+        engine.set_option("conv4_big", 2)
+        perm = np.random.default_rng(3).permutation(8192)
+        pi, v = engine.predict_states(states[perm], 20)
+        assert np.array_equal(pi, ref_pi[perm]) and np.array_equal(v, ref_v[perm])
+    finally:
+        engine.set_option("gemm_variant", 5)
+        engine.set_option("conv4_big", 2)
+    n = 4096
+    boards = np.stack([oracle.c4_features(int(m), int(t)) for m, t in states[:n]])
+    rpi, rv = forward_ref(engine.net_get_params(20), boards, C, emulate_bf16=True)
+    assert np.abs(ref_pi[:n] - rpi).max() <= 2e-3, np.abs(ref_pi[:n] - rpi).max()
+    assert np.abs(ref_v[:n] - rv).max() <= 6e-3, np.abs(ref_v[:n] - rv).max()
+
+
 def test_init_random_and_checkpoint_roundtrip(conv_engine, oracle, tmp_path):
     conv_engine.net_init_random(4, seed=11)
     p = conv_engine.net_get_params(4)
