@@ -44,6 +44,7 @@ struct NetModel {
     int kind = -1;
     uint64_t salt = 0;
     ConvNet* conv = nullptr;
+    uint64_t cache_tag = 0;     // evaluation-cache tag of the current weights (0 = none yet); new tag per upload
 };
 
 // timed regions (profile mode): event pairs recorded on the engine stream, resolved at sync points
@@ -78,11 +79,24 @@ struct Profiler {
     ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
 
+inline uint32_t next_pow2_u32(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return (uint32_t)p;
+}
+
 struct TreeHost {
     DeviceMem mem;
     TreeDev d{};
     EvalBatch eb{};         // eval batch of even simulations (and of the root evaluation)
     EvalBatch eb2{};        // eval batch of odd simulations: k_backup_select ping-pongs between the two
+    uint32_t dd_epoch = 0;  // election-table epoch of the last k_dedup launch (both batches share the counter)
+    // unique-row view of a batch: what the net runs on when de-duplication is on
+    static EvalBatch unique_view(const EvalBatch& b) {
+        EvalBatch u{};
+        u.cap = b.cap; u.n = b.un; u.tree = b.tree; u.state = b.ustate; u.pi = b.upi; u.v = b.uv;
+        return u;
+    }
     void create(int G, uint64_t R, uint32_t H, int log_cap) {
         d.G = G; d.R = (uint32_t)R; d.H = H;
         size_t slots = (size_t)G * R;
@@ -119,6 +133,18 @@ struct TreeHost {
             b->pi = mem.alloc<float>((size_t)G * 8);
             b->v = mem.alloc<float>(G);
             HIPCHK(hipMemset(b->n, 0, sizeof(uint32_t)));
+            // de-duplication arrays (used when the engine's "eval_dedup" applies to the net of a search)
+            b->src = mem.alloc<uint32_t>(G);
+            b->un = mem.alloc<uint32_t>(1);
+            b->ustate = mem.alloc<ulonglong2>(G);
+            b->upi = mem.alloc<float>((size_t)G * 8);
+            b->uv = mem.alloc<float>(G);
+            const uint32_t tsize = next_pow2_u32(4ull * (uint64_t)std::max(G, 16));
+            b->tkey = mem.alloc<unsigned long long>(tsize);
+            b->tuniq = mem.alloc<uint32_t>(tsize);
+            b->tmask = tsize - 1;
+            HIPCHK(hipMemset(b->un, 0, sizeof(uint32_t)));
+            HIPCHK(hipMemset(b->tkey, 0, (size_t)tsize * 8));
         }
     }
 };
@@ -161,6 +187,16 @@ struct az_engine {
     uint64_t train_seed = 0;
     int train_graph = 1;
     std::vector<float> train_history;              // (loss_pi, loss_v) mean per epoch of the last az_net_train
+    // leaf de-duplication + evaluation cache (az_set_option "eval_dedup", "eval_cache_log2", "eval_cache_max_stones",
+    // "eval_cache_persist")
+    int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
+    int eval_cache_log2 = 24;       // entries = 2^log2 (40 B each); 0 = no cache, in-batch de-duplication only
+    int eval_cache_max_stones = 42;
+    int eval_cache_persist = 0;     // 0: az_selfplay / az_arena / az_tree_get_action_prob start from an empty cache
+    DeviceMem cache_mem;
+    EvalCache cache{};              // key == nullptr until first use
+    int cache_alloc_log2 = -1;
+    uint64_t next_cache_tag = 1;    // 15 bits; wrapping clears the cache
 };
 
 struct az_tree {
@@ -194,29 +230,103 @@ void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int row
     }
 }
 
+bool dedup_applies(const az_engine* e, const NetModel& net) {
+    return e->eval_dedup == 2 || (e->eval_dedup == 1 && net.kind == AZ_NET_CONV);
+}
+
+// The engine's evaluation cache, allocated on first use; (re)sized by "eval_cache_log2".
+void ensure_cache(az_engine* e) {
+    if (e->cache_alloc_log2 == e->eval_cache_log2) return;
+    e->cache_mem.release();
+    e->cache = EvalCache{};
+    e->cache.stat = e->cache_mem.alloc<unsigned long long>(DD_COUNT);
+    HIPCHK(hipMemset(e->cache.stat, 0, DD_COUNT * sizeof(unsigned long long)));
+    if (e->eval_cache_log2 >= 3) {
+        const size_t entries = (size_t)1 << e->eval_cache_log2;
+        e->cache.key = e->cache_mem.alloc<unsigned long long>(entries);
+        e->cache.pv = e->cache_mem.alloc<float>(entries * 8);
+        e->cache.bmask = (uint32_t)(entries / 8 - 1);
+        HIPCHK(hipMemset(e->cache.key, 0, entries * 8));
+    }
+    e->cache_alloc_log2 = e->eval_cache_log2;
+}
+void clear_cache(az_engine* e, hipStream_t s) {
+    if (e->cache.key) HIPCHK(hipMemsetAsync(e->cache.key, 0, ((size_t)e->cache.bmask + 1) * 64, s));
+}
+// a new tag for a model's new weights: its old entries can never match again
+void retag_model(az_engine* e, NetModel& m) {
+    if (e->next_cache_tag > 0x7FFFull) {
+        if (e->cache.key) HIPCHK(hipMemset(e->cache.key, 0, ((size_t)e->cache.bmask + 1) * 64));
+        for (auto& kv : e->nets) kv.second.cache_tag = 0;
+        e->next_cache_tag = 1;
+    }
+    m.cache_tag = e->next_cache_tag++;
+}
+// cache view for one search (key == nullptr when only in-batch de-duplication is wanted or nothing applies)
+EvalCache cache_for(az_engine* e, NetModel& net) {
+    EvalCache c{};
+    if (!dedup_applies(e, net)) return c;
+    ensure_cache(e);
+    if (net.cache_tag == 0) retag_model(e, net);
+    c = e->cache;
+    c.max_stones = (uint32_t)e->eval_cache_max_stones;
+    c.tag = (unsigned long long)net.cache_tag << 49;
+    return c;
+}
+// fold the device-side de-duplication counters into the engine stats (after a stream sync)
+void harvest_dedup(az_engine* e) {
+    if (!e->cache.stat) return;
+    unsigned long long h[DD_COUNT];
+    HIPCHK(hipMemcpy(h, e->cache.stat, sizeof h, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->cache.stat, 0, sizeof h));
+    e->stats.leaf_rows_requested += h[DD_REQUESTED];
+    e->stats.leaf_rows_executed += h[DD_EXECUTED];
+    e->stats.eval_cache_hits += h[DD_CACHE_HITS];
+    e->stats.eval_batch_dups += h[DD_BATCH_DUPS];
+    e->stats.eval_cache_inserts += h[DD_INSERTS];
+}
+
+// NNet::predict for the leaves of one simulation step: with de-duplication the net runs on the batch's unique rows
+void eval_batch(az_engine* e, TreeHost& th, const NetModel& net, const EvalBatch& eb, const EvalCache& ec, bool dedup, int rows_hint,
+                hipStream_t s) {
+    if (!dedup) { net_forward(e, net, eb, rows_hint, s); return; }
+    if (++th.dd_epoch > 0x7FFFu) {          // 15-bit epoch wrapped: stale keys could look current again
+        HIPCHK(hipMemsetAsync(th.eb.tkey, 0, ((size_t)th.eb.tmask + 1) * 8, s));
+        HIPCHK(hipMemsetAsync(th.eb2.tkey, 0, ((size_t)th.eb2.tmask + 1) * 8, s));
+        th.dd_epoch = 1;
+    }
+    launch_dedup(eb, ec, th.dd_epoch, s);
+    net_forward(e, net, TreeHost::unique_view(eb), rows_hint, s);
+}
+
 // get_action_prob body shared by every entry point: S10/S1 prologue, then num_sims x
 // {select+expand, compact, predict, mask+store+backup}  (src/async_mcts.rs:81-82, :191-217).
 // rows_hint = host-side upper bound on the leaf batch (trees still searching): sizes the net's grids and picks tiles
 void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int num_sims, SearchParams sp,
-                const NetModel& net, int rows_hint, hipStream_t s = nullptr) {
+                NetModel& net, int rows_hint, hipStream_t s = nullptr) {
     if (!s) s = e->stream;
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
+    const bool dedup = dedup_applies(e, net);
+    const EvalCache ec = cache_for(e, net);
+    // without de-duplication the kernels must take the direct path: hide the batches' src arrays
+    EvalBatch b0 = th.eb, b1 = th.eb2;
+    if (!dedup) { b0.src = nullptr; b0.un = nullptr; b1.src = nullptr; b1.un = nullptr; }
     // root: prepare (its leaf goes to batch 0), predict; then num_sims x {backup of the previous leaf + select of the next
     // (one launch, the new leaf goes to the other batch), predict}; a last backup closes the search.
-    launch_root_prepare(th.d, th.eb, d_root_states, s);
-    net_forward(e, net, th.eb, rows_hint, s);
-    const EvalBatch* B[2] = {&th.eb, &th.eb2};
+    launch_root_prepare(th.d, b0, d_root_states, s);
+    eval_batch(e, th, net, b0, ec, dedup, rows_hint, s);
+    const EvalBatch* B[2] = {&b0, &b1};
     for (int i = 0; i < num_sims; ++i) {
         hipEvent_t t0 = nullptr;
         if (e->prof.on) t0 = e->prof.begin(s);
-        launch_backup_select(th.d, *B[i & 1], *B[(i + 1) & 1], sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
+        launch_backup_select(th.d, *B[i & 1], *B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
         if (e->prof.on) { e->prof.end(t0, RG_TREE, s); t0 = e->prof.begin(s); }
-        net_forward(e, net, *B[(i + 1) & 1], rows_hint, s);
+        eval_batch(e, th, net, *B[(i + 1) & 1], ec, dedup, rows_hint, s);
         if (e->prof.on) e->prof.end(t0, RG_NET, s);
     }
     hipEvent_t t0 = nullptr;
     if (e->prof.on) t0 = e->prof.begin(s);
-    launch_backup(th.d, *B[num_sims & 1], 0, s);
+    launch_backup(th.d, *B[num_sims & 1], ec, 0, s);
     if (e->prof.on) e->prof.end(t0, RG_TREE, s);
 }
 
@@ -230,7 +340,9 @@ void resolve_profile(az_engine* e) {
 }
 
 // fold the per-tree counters into the engine stats and clear them
-void harvest_stats(az_engine* e, TreeHost& th) {
+void harvest_stats(az_engine* e, TreeHost& th, const NetModel& net) {
+    harvest_dedup(e);
+    const bool dedup = dedup_applies(e, net);
     std::vector<uint64_t> h((size_t)th.d.G * ST_COUNT);
     HIPCHK(hipMemcpy(h.data(), th.d.stat, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(th.d.stat, 0, h.size() * sizeof(uint64_t)));
@@ -240,6 +352,7 @@ void harvest_stats(az_engine* e, TreeHost& th) {
         sims += st[ST_SIMS];
         e->stats.expansions += st[ST_EXPANSIONS];
         e->stats.leaf_evals += st[ST_LEAF_EVALS];
+        if (!dedup) { e->stats.leaf_rows_requested += st[ST_LEAF_EVALS]; e->stats.leaf_rows_executed += st[ST_LEAF_EVALS]; }
         e->stats.link_hits += st[ST_LINK_HITS];
         e->stats.terminal_hits += st[ST_TERMINAL_HITS];
         depth += st[ST_DEPTH_SUM];
@@ -345,6 +458,10 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = buf;       // returned through az_last_error
         return AZ_OK;
     }
+    if (std::strcmp(key, "eval_dedup") == 0 && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "eval_cache_log2") == 0 && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "eval_cache_max_stones") == 0 && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "eval_cache_persist") == 0 && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
     if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {
         convnet_set_conv4_big((int)value);
         return AZ_OK;
@@ -383,6 +500,7 @@ az_status az_net_set_kind(az_engine* e, int32_t model_id, az_net_kind kind, uint
     m.kind = kind;
     // two hash nets with the same salt but different model ids differ (oracle: HashNet::predict)
     m.salt = salt + (uint64_t)model_id * 0x51ED27ull;
+    m.cache_tag = 0;
     return AZ_OK;
 }
 
@@ -406,6 +524,7 @@ az_status az_net_init_random(az_engine* e, int32_t model_id, uint64_t seed) {
         if (st) return st;
         convnet_init_random(m->conv, seed);
         m->kind = AZ_NET_CONV;
+        m->cache_tag = 0;
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
@@ -422,6 +541,7 @@ az_status az_net_set_params(az_engine* e, int32_t model_id, const float* params,
         if (st) return st;
         if (!convnet_set_params(m->conv, params, n)) return fail(e, AZ_ERR_HIP, "convnet_set_params failed");
         m->kind = AZ_NET_CONV;
+        m->cache_tag = 0;
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
@@ -733,11 +853,12 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
         HIPCHK(hipMemcpyAsync(t->d_root_states, states, (size_t)G * 16, hipMemcpyDefault, e->stream));
         HIPCHK(hipMemsetAsync(d.active, 1, G, e->stream));
         SearchParams sp{(uint32_t)t->max_depth, (float)t->cpuct};
+        if (!e->eval_cache_persist) clear_cache(e, e->stream);
         run_search(e, t->th, t->d_root_states, t->num_sims, sp, *net, G);
         launch_root_policy(d, temp, seed, first_game_id, t->d_pi, t->d_counts, t->d_q, e->stream);
         HIPCHK(hipStreamSynchronize(e->stream));
         resolve_profile(e);
-        harvest_stats(e, t->th);
+        harvest_stats(e, t->th, *net);
         e->stats.moves += (uint64_t)G;
         st = check_tree_errors(e, t->th);
         if (st) return st;
@@ -807,6 +928,7 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         if (p->record_evals > 0 && C != n_games)
             return fail(e, AZ_ERR_BAD_ARGUMENT, "record_evals needs concurrent == n_games");
         launch_reset_trees(th.d, nullptr, s);
+        if (!e->eval_cache_persist) clear_cache(e, s);
         SearchParams sp{(uint32_t)p->max_depth, (float)p->cpuct};
         SelfplayMoveParams mp{p->seed, p->first_game_id, p->temp_threshold, C < n_games ? 1 : 0};
         uint32_t* h_ctr = nullptr;
@@ -835,7 +957,7 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
                 break;
             }
         }
-        harvest_stats(e, th);
+        harvest_stats(e, th, *net);
         if (result == AZ_OK) result = check_tree_errors(e, th);
         if (result) return result;
         // offsets (host prefix sum over n_games plies) and emit
@@ -944,6 +1066,10 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         HIPCHK(hipMemcpy(ad.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
         launch_reset_trees(tn.d, nullptr, s);
         launch_reset_trees(to.d, nullptr, s);
+        if (!e->eval_cache_persist) clear_cache(e, s);
+        // both models' tags are fixed before the two streams fork (retagging may clear the cache)
+        (void)cache_for(e, *net_new);
+        (void)cache_for(e, *net_old);
         SearchParams sp{(uint32_t)p->max_depth, (float)p->cpuct};
         az_status result = AZ_OK;
         // The two searches of a ply touch disjoint trees and (for two different models) disjoint net workspaces:
@@ -979,8 +1105,8 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
             if (ctr[1]) { result = fail(e, AZ_ERR_INVALID_MOVE, "arena: action is not valid (src/arena.rs:31-35)"); break; }
             if (ctr[0] == 0) break;
         }
-        harvest_stats(e, tn);
-        harvest_stats(e, to);
+        harvest_stats(e, tn, *net_new);
+        harvest_stats(e, to, *net_old);
         if (result == AZ_OK) result = check_tree_errors(e, tn);
         if (result == AZ_OK) result = check_tree_errors(e, to);
         if (result) return result;

@@ -38,7 +38,7 @@ __global__ void k_net_fixture(EvalBatch eb, int kind, uint64_t salt) {
     }
 #pragma unroll
     for (int a = 0; a < ACTIONS; ++a) eb.pi[(size_t)i * 8 + a] = pi[a];
-    eb.pi[(size_t)i * 8 + 7] = 0.0f;
+    eb.pi[(size_t)i * 8 + 7] = v;            // (pi, v) as one 32-byte row: what the backup lanes read
     eb.v[i] = v;
 }
 
@@ -970,8 +970,9 @@ __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_
         for (int a = 0; a < ACTIONS; ++a) { e[a] = expf(o[a] - mx); sum += e[a]; }
 #pragma unroll
         for (int a = 0; a < ACTIONS; ++a) eb.pi[(size_t)wave * 8 + a] = e[a] / sum;
-        eb.pi[(size_t)wave * 8 + 7] = 0.f;
-        eb.v[wave] = tanhf(o[7]);
+        const float vv = tanhf(o[7]);
+        eb.pi[(size_t)wave * 8 + 7] = vv;        // (pi, v) as one 32-byte row: what the backup lanes read
+        eb.v[wave] = vv;
     }
 }
 

@@ -288,7 +288,32 @@ AZ_D void select_body(const TreeDev& t, const EvalBatch& eb, const SearchParams&
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
-AZ_D void backup_body(const TreeDev& t, const EvalBatch& eb, int apply_only, int g, int sub) {
+// `seen`-style sharing of evaluations across trees: a tree whose row was really evaluated publishes (pi, v) under its
+// state's key.  Bucket = one 64-byte line of 8 keys; lane j looks at way j, lane 0 claims the first empty way with a CAS
+// (another inserter may have taken it: try the next empty one), then lanes 0..7 write the 32-byte payload.  Readers are
+// k_dedup launches LATER on the same stream, so a claimed key always has its payload by the time it can be matched.
+AZ_D void cache_insert(const EvalCache& ec, uint64_t m, uint64_t th, float pv, int sub) {
+    if ((uint32_t)__popcll(m | th) > ec.max_stones) return;
+    const unsigned long long key = c4_key(m, th) | ec.tag;
+    const uint32_t bucket = (uint32_t)(mix64(key) >> 20) & ec.bmask;
+    unsigned long long* keys = ec.key + (size_t)bucket * 8;
+    uint32_t empties = gballot(keys[sub] == 0ull);
+    uint32_t way = NONE;
+    while (empties) {
+        const uint32_t w = (uint32_t)__ffs((int)empties) - 1u;
+        unsigned long long prev = 0ull;
+        if (sub == 0) prev = atomicCAS(&keys[w], 0ull, key);
+        prev = ((unsigned long long)gshfl((uint32_t)(prev >> 32), 0) << 32) | gshfl((uint32_t)prev, 0);
+        if (prev == 0ull) { way = w; break; }
+        if (prev == key) return;                     // already published
+        empties &= empties - 1u;
+    }
+    if (way == NONE) return;                         // bucket full: not cached
+    ec.pv[((size_t)bucket * 8 + way) * 8 + sub] = pv;
+    if (sub == 0) atomicAdd(&ec.stat[DD_INSERTS], 1ull);
+}
+
+AZ_D void backup_body(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g, int sub) {
     const uint32_t kind = t.leaf_kind[g];
     if (kind == LEAF_NONE) return;
     const size_t base = (size_t)g * t.R;
@@ -296,9 +321,22 @@ AZ_D void backup_body(const TreeDev& t, const EvalBatch& eb, int apply_only, int
     float val;
     if (kind == LEAF_EVAL) {
         const int slot = t.slot_of[g];
-        float p = sub < ACTIONS ? eb.pi[(size_t)slot * 8 + sub] : 0.0f;
-        const float v = eb.v[slot];
         const ulonglong2 s = t.state[base + leaf];
+        float pv;                                   // lanes 0..6: pi[sub], lane 7: v
+        if (eb.src) {
+            const uint32_t src = eb.src[slot];
+            if (src & SRC_CACHE) {
+                pv = ec.pv[(size_t)(src & SRC_INDEX) * 8 + sub];
+            } else {
+                const uint32_t u = (src & SRC_TABLE) ? eb.tuniq[src & SRC_INDEX] : src;
+                pv = eb.upi[(size_t)u * 8 + sub];
+                if (!(src & SRC_TABLE) && ec.key) cache_insert(ec, s.x, s.y, pv, sub);
+            }
+        } else {
+            pv = eb.pi[(size_t)slot * 8 + sub];
+        }
+        float p = sub < ACTIONS ? pv : 0.0f;
+        const float v = gshflf(pv, 7);
         if (t.log_cap > 0) {
             uint32_t n = t.log_len[g];
             if (n < (uint32_t)t.log_cap) {
@@ -402,29 +440,95 @@ __global__ __launch_bounds__(64) void k_select(TreeDev t, EvalBatch eb, SearchPa
     select_body(t, eb, sp, g, sub);
 }
 
-__global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, int apply_only) {
+__global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCache ec, int apply_only) {
     const int tid = blockIdx.x * 64 + threadIdx.x;
     const int g = tid >> 3, sub = tid & 7;
-    if (tid == 0) *eb.n = 0;            // the batch has been consumed (nothing in this kernel reads the count)
+    if (tid == 0) { *eb.n = 0; if (eb.un) *eb.un = 0; }   // the batch has been consumed (nothing in this kernel reads the counts)
     if (g >= t.G) return;
-    backup_body(t, eb, apply_only, g, sub);
+    backup_body(t, eb, ec, apply_only, g, sub);
 }
 
 // backup of simulation i and select of simulation i+1 in one launch: both belong to the same 8 lanes of the same tree and
 // nothing else touches that tree in between.  The leaf of i+1 goes into the OTHER eval batch (eb_next; its count was
 // zeroed by the previous launch, this one zeroes eb_prev's), so the two ping-pong.
-__global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, SearchParams sp,
-                                                      int apply_only) {
+__global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec,
+                                                      SearchParams sp, int apply_only) {
     const int tid = blockIdx.x * 64 + threadIdx.x;
     const int g = tid >> 3, sub = tid & 7;
-    if (tid == 0) *eb_prev.n = 0;
+    if (tid == 0) { *eb_prev.n = 0; if (eb_prev.un) *eb_prev.un = 0; }
     if (g >= t.G) return;
-    backup_body(t, eb_prev, apply_only, g, sub);
+    backup_body(t, eb_prev, ec, apply_only, g, sub);
     // the counters this tree's other lanes just wrote are read by the selection below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     select_body(t, eb_next, sp, g, sub);
+}
+
+// ---- leaf de-duplication: one thread per requested row ------------------------------------------------------------------
+// 1. evaluation cache: the row's bucket is one 64-byte line of 8 keys; a match ends the row (src = cache entry).
+// 2. election table (open addressing, linear probe): the first row to CAS its key in wins and takes the next row of the
+//    unique batch (one atomicAdd per wave); later rows with the same key point at the winner's slot.  A slot whose epoch
+//    is not this launch's counts as empty, so the table is never cleared between launches (the caller clears it when the
+//    15-bit epoch wraps).
+__global__ __launch_bounds__(256) void k_dedup(EvalBatch eb, EvalCache ec, uint32_t epoch) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = *eb.n;
+    const int lane = (int)(threadIdx.x & 63);
+    bool winner = false, hit = false, dup = false;
+    ulonglong2 s = make_ulonglong2(0ull, 0ull);
+    if (r < n) {
+        s = eb.state[r];
+        const unsigned long long key = c4_key(s.x, s.y);
+        if (ec.key) {
+            const unsigned long long ck = key | ec.tag;
+            const uint32_t bucket = (uint32_t)(mix64(ck) >> 20) & ec.bmask;
+            const ulonglong4* kp = (const ulonglong4*)(ec.key + (size_t)bucket * 8);
+            const ulonglong4 k0 = kp[0], k1 = kp[1];
+            const int way = k0.x == ck ? 0 : k0.y == ck ? 1 : k0.z == ck ? 2 : k0.w == ck ? 3 :
+                            k1.x == ck ? 4 : k1.y == ck ? 5 : k1.z == ck ? 6 : k1.w == ck ? 7 : -1;
+            if (way >= 0) { hit = true; eb.src[r] = SRC_CACHE | (bucket * 8u + (uint32_t)way); }
+        }
+        if (!hit) {
+            const unsigned long long mine = key | ((unsigned long long)epoch << 49);
+            uint32_t pos = (uint32_t)(mix64(key) >> 24) & eb.tmask;
+            for (;;) {
+                unsigned long long cur = eb.tkey[pos];
+                if ((cur >> 49) != (unsigned long long)epoch) {          // empty or stale: try to take it
+                    const unsigned long long prev = atomicCAS(&eb.tkey[pos], cur, mine);
+                    if (prev == cur) { winner = true; break; }
+                    cur = prev;                                          // somebody else took it first
+                    if ((cur >> 49) != (unsigned long long)epoch) continue;   // (a stale value replaced by another stale one cannot happen; retry anyway)
+                }
+                if (cur == mine) { dup = true; eb.src[r] = SRC_TABLE | pos; break; }
+                pos = (pos + 1u) & eb.tmask;
+            }
+            if (winner) eb.src[r] = pos;            // provisional: replaced by the unique row below
+        }
+    }
+    // unique rows: one atomicAdd per wave
+    const unsigned long long wm = __ballot(winner);
+    if (wm) {
+        const int leader = __ffsll((long long)wm) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(eb.un, (uint32_t)__popcll(wm));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (winner) {
+            const uint32_t u = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+            eb.tuniq[eb.src[r]] = u;
+            eb.src[r] = u;
+            eb.ustate[u] = s;
+        }
+    }
+    if (ec.stat) {
+        const unsigned long long hm = __ballot(hit), dm = __ballot(dup), am = __ballot(r < n);
+        if (am && lane == __ffsll((long long)am) - 1) {
+            atomicAdd(&ec.stat[DD_REQUESTED], (unsigned long long)__popcll(am));
+            if (wm) atomicAdd(&ec.stat[DD_EXECUTED], (unsigned long long)__popcll(wm));
+            if (hm) atomicAdd(&ec.stat[DD_CACHE_HITS], (unsigned long long)__popcll(hm));
+            if (dm) atomicAdd(&ec.stat[DD_BATCH_DUPS], (unsigned long long)__popcll(dm));
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_root_policy(TreeDev t, float temp, uint64_t seed, uint64_t first_game_id,
@@ -599,12 +703,15 @@ void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const ulonglong2
 void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipStream_t s) {
     hipLaunchKernelGGL(k_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, sp);
 }
-void launch_backup(const TreeDev& t, const EvalBatch& eb, int apply_only, hipStream_t s) {
-    hipLaunchKernelGGL(k_backup, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, apply_only);
+void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s) {
+    hipLaunchKernelGGL(k_backup, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, apply_only);
 }
-void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, SearchParams sp, int apply_only,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(k_backup_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, sp, apply_only);
+void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
+                          int apply_only, hipStream_t s) {
+    hipLaunchKernelGGL(k_backup_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, apply_only);
+}
+void launch_dedup(const EvalBatch& eb, const EvalCache& ec, uint32_t epoch, hipStream_t s) {
+    hipLaunchKernelGGL(k_dedup, dim3((eb.cap + 255) / 256), dim3(256), 0, s, eb, ec, epoch);
 }
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s) {

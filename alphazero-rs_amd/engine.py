@@ -43,7 +43,9 @@ class az_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("games", "moves", "simulations", "expansions", "leaf_evals", "link_hits",
                                           "terminal_hits", "depth_sum", "samples", "net_launches")] + \
                [(n, C.c_double) for n in ("net_conv2_ms", "net_conv2_flops", "net_total_ms", "net_total_flops",
-                                          "tree_ms", "tree_bytes", "device_ms")]
+                                          "tree_ms", "tree_bytes", "device_ms")] + \
+               [(n, C.c_uint64) for n in ("leaf_rows_requested", "leaf_rows_executed", "eval_cache_hits", "eval_batch_dups",
+                                          "eval_cache_inserts")]
 
 
 class az_selfplay_params(C.Structure):

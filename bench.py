@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
+    ap.add_argument("--dedup", type=int, default=1, choices=[0, 1], help="leaf de-duplication + per-call evaluation cache (bit-exact); 0 = every requested row runs")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and run the gather even at world size 1 (rehearsal)")
     ap.add_argument("--dry-dist", default="", choices=["", "gloo"],
                     help="rehearse the N-rank launcher + gather on CPU over gloo with synthetic tuples (no engine, no GPU; value = 0)")
@@ -205,6 +206,7 @@ def main():
     from alphazero_rs_amd import engine as azeng
     from alphazero_rs_amd import dist as azdist
     e = azeng.Engine(device=local_rank, max_batch=args.games, net_channels=args.channels, profile=not args.no_profile)
+    e.set_option("eval_dedup", args.dedup)
     if args.net == "conv":
         e.net_init_random(0, seed=args.seed)       # identical weights on every rank (replicated, 21.5 MB bf16)
     else:
@@ -250,11 +252,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        agg = torch.tensor([st["expansions"], st["simulations"], st["leaf_evals"], plies], dtype=torch.float64, device=dev)
+        agg = torch.tensor([st["expansions"], st["simulations"], st["leaf_evals"], plies, st["leaf_rows_executed"],
+                            st["eval_cache_hits"], st["eval_batch_dups"]], dtype=torch.float64, device=dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        expansions, simulations, leaf_evals, plies_all = (float(x) for x in agg.tolist())
+        expansions, simulations, leaf_evals, plies_all, rows_exec, cache_hits, batch_dups = (float(x) for x in agg.tolist())
     else:
         expansions, simulations, leaf_evals, plies_all = st["expansions"], st["simulations"], st["leaf_evals"], plies
+        rows_exec, cache_hits, batch_dups = st["leaf_rows_executed"], st["eval_cache_hits"], st["eval_batch_dups"]
 
     if rank == 0:
         games = episodes * args.steps * world
@@ -270,7 +274,13 @@ def main():
                        "sims_per_move": args.sims, "net": args.net, "parallelism": f"games-sharded x{world}"},
             "node_expansions_per_sec": expansions / dt, "simulations_per_sec": simulations / dt,
             "leaf_evals_per_sec": leaf_evals / dt, "mean_plies": plies_all / games,
-            "mfma_fraction_end_to_end": (leaf_evals / dt) * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12 * world) if args.net == "conv" else None,
+            # leaf de-duplication (bit-exact, az_engine.h "eval_dedup"): the trees REQUEST leaf_evals rows, the net EXECUTES
+            # only the distinct states not yet in this call's evaluation cache; every MFMA figure counts executed rows only
+            "leaf_rows": {"requested_per_sec": leaf_evals / dt, "executed_per_sec": rows_exec / dt,
+                          "executed_over_requested": rows_exec / max(1.0, leaf_evals),
+                          "cache_hits_over_requested": cache_hits / max(1.0, leaf_evals),
+                          "batch_duplicates_over_requested": batch_dups / max(1.0, leaf_evals), "dedup": args.dedup},
+            "mfma_fraction_end_to_end": (rows_exec / dt) * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12 * world) if args.net == "conv" else None,
         }
         roof = None
         if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:

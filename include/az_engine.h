@@ -85,6 +85,13 @@ typedef struct az_stats {
     double tree_ms;          /* summed select+backup kernel time (profile mode) */
     double tree_bytes;       /* summed algorithmic tree bytes, SURVEY.md 8d (profile mode) */
     double device_ms;        /* summed wall time spent inside engine calls */
+    /* leaf de-duplication ("eval_dedup"): requested = rows the trees asked for (== leaf_evals), executed = rows the net
+     * really ran (requested - cache hits - in-batch duplicates; == requested when de-duplication is off) */
+    uint64_t leaf_rows_requested;
+    uint64_t leaf_rows_executed;
+    uint64_t eval_cache_hits;
+    uint64_t eval_batch_dups;
+    uint64_t eval_cache_inserts;
 } az_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -95,7 +102,13 @@ const char* az_last_error(const az_engine* e);
 /* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
  * net uses (0 = 128x128 register-staged tiles for every layer, 1 / 2 = 256x256 LDS-DMA tiles, 3 = conv2 image-resident
  * in one 8-wave workgroup per CU, 5 = default, conv2 image-resident in two 4-wave workgroups per CU; 11-17 = timing
- * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto). Unknown keys or values return AZ_ERR_BAD_ARGUMENT. */
+ * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto).
+ * Leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
+ * src/node.rs:282-289): "eval_dedup" = 0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is
+ * evaluated once; "eval_cache_log2" = log2 entries of the engine's evaluation cache shared by all trees (default 24, 0 = none,
+ * 40 bytes per entry); "eval_cache_max_stones" = only states with at most that many stones are cached (default 42);
+ * "eval_cache_persist" = 0 (default): every az_selfplay / az_arena / az_tree_get_action_prob call starts from an empty cache,
+ * 1: entries live until the model's weights change.  Unknown keys or values return AZ_ERR_BAD_ARGUMENT. */
 az_status az_set_option(az_engine* e, const char* key, int64_t value);
 az_status az_get_stats(az_engine* e, az_stats* out);
 az_status az_reset_stats(az_engine* e);

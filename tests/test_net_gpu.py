@@ -215,3 +215,24 @@ def test_replay_parity_get_action_prob(conv_engine, oracle):
             assert np.array_equal(counts[g], ocnt)
             assert np.abs(pi[g] - opi).max() <= 1e-5 and np.abs(q[g] - oq).max() <= 1e-5   # north_star tolerance; in fact equal
             assert np.array_equal(pi[g], opi) and np.array_equal(q[g], oq)
+
+
+def test_dedup_is_bit_exact_with_the_conv_net(conv_engine, oracle):
+    """Leaf de-duplication + the evaluation cache on the real bf16 net: the same episodes with the switch off and on give
+    identical moves, pi and z, while the net runs on fewer rows (games from the empty board share their openings)."""
+    conv_engine.net_init_random(8, seed=13)
+    n, sims = 384, 40
+    runs = {}
+    try:
+        for mode in (0, 1):
+            conv_engine.set_option("eval_dedup", mode)
+            conv_engine.reset_stats()
+            runs[mode] = (conv_engine.selfplay(n_games=n, num_sims=sims, model_id=8, seed=5, concurrent=128), conv_engine.stats())
+    finally:
+        conv_engine.set_option("eval_dedup", 1)
+    (a, sa), (b, sb) = runs[0], runs[1]
+    for k in ("moves", "game_len", "pis", "zs", "states"):
+        assert np.array_equal(a[k], b[k]), k
+    assert sa["leaf_rows_executed"] == sa["leaf_rows_requested"] == sa["leaf_evals"] == sb["leaf_evals"]
+    assert sb["leaf_rows_requested"] == sb["leaf_evals"] == sb["leaf_rows_executed"] + sb["eval_cache_hits"] + sb["eval_batch_dups"]
+    assert sb["leaf_rows_executed"] < 0.9 * sb["leaf_rows_requested"], sb

@@ -19,6 +19,16 @@ def oracle_salt(model_id):
     return HASH_SALT + model_id * MODEL_SALT
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["dedup-conv-only", "dedup-every-net"])
+def dedup_mode(request, engine):
+    """Every test of this module runs twice: with the default setting (the stub / hash fixtures take the direct path) and
+    with leaf de-duplication + the evaluation cache switched on for EVERY net, so the election table, the unique batch,
+    the cache and the backup kernels' indirection are held to the same bit-exact bar against the oracle."""
+    engine.set_option("eval_dedup", request.param)
+    yield request.param
+    engine.set_option("eval_dedup", 1)
+
+
 def play_episode_lockstep(engine, oracle, n_games, sims, model_id, okind, osalt, temp_schedule, seed, max_moves=42):
     """Drives az_tree_get_action_prob move by move for n_games trees and the oracle's AsyncMcts alongside;
     every move compares pi / counts / Q, then plays the oracle-agreed move."""
@@ -405,3 +415,46 @@ def test_arena_shards_add_up(engine, oracle, engine_mod):
     assert np.array_equal(np.concatenate(parts), res) and tot.tolist() == wld.tolist()
     with pytest.raises(engine_mod.AzError):
         engine.arena(5, 10, new_model_id=51, old_model_id=50, first_game=18, total_games=20)
+
+
+def test_dedup_counters_and_cache_corner_cases(engine, oracle, dedup_mode):
+    """requested == executed + cache hits + in-batch duplicates == leaf_evals; a tiny cache that overflows its buckets, a
+    stone limit, a cache kept across calls and no cache at all change nothing in the results."""
+    if dedup_mode != 2:
+        pytest.skip("needs de-duplication on the hash net")
+    n, sims = 160, 25
+    ref = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=8, threads=8)
+    try:
+        hits_first = None
+        for log2, stones, persist in ((24, 42, 0), (10, 42, 0), (24, 5, 0), (0, 42, 0), (12, 42, 1), (12, 42, 1)):
+            engine.set_option("eval_cache_log2", log2)
+            engine.set_option("eval_cache_max_stones", stones)
+            engine.set_option("eval_cache_persist", persist)
+            engine.reset_stats()
+            got = engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=8, concurrent=48)
+            _compare_selfplay(got, ref)
+            st = engine.stats()
+            assert st["leaf_rows_requested"] == st["leaf_evals"] > 0
+            assert st["leaf_rows_requested"] == st["leaf_rows_executed"] + st["eval_cache_hits"] + st["eval_batch_dups"], st
+            assert st["eval_batch_dups"] > 0                      # 48 games from the empty board share their openings
+            if log2 == 0:
+                assert st["eval_cache_hits"] == 0 and st["eval_cache_inserts"] == 0
+            elif persist and hits_first is not None:
+                # second call on a kept cache: what the first call published is found again, little is left to insert
+                assert st["eval_cache_hits"] > hits_first and st["eval_cache_inserts"] <= st["leaf_rows_executed"]
+            else:
+                assert st["eval_cache_hits"] > 0 and 0 < st["eval_cache_inserts"] <= st["leaf_rows_executed"]
+                if persist:
+                    hits_first = st["eval_cache_hits"]
+            if log2 == 10:
+                assert st["eval_cache_inserts"] <= 1024
+        # a new net under the same model id must not see the old net's cached rows (persist is still on)
+        engine.net_set_kind(10, 1, HASH_SALT + 1)
+        got = engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=8, concurrent=48)
+        ref2 = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10) + 1, seed=8, threads=8)
+        _compare_selfplay(got, ref2)
+    finally:
+        engine.net_set_kind(10, 1, HASH_SALT)
+        engine.set_option("eval_cache_log2", 24)
+        engine.set_option("eval_cache_max_stones", 42)
+        engine.set_option("eval_cache_persist", 0)
