@@ -174,6 +174,9 @@ struct az_engine {
     az_stats stats{};
     Profiler prof;
     NetProfile netprof;
+    // activation workspaces of the conv net: [0] the engine stream, [1] a second concurrent stream (az_arena's old-model
+    // search); created on first use, shared by every model id
+    NetWorkspace* ws[2] = {nullptr, nullptr};
     // eval log of the last az_selfplay
     std::vector<int32_t> sp_log_count;
     std::vector<uint64_t> sp_log_states;
@@ -190,7 +193,7 @@ struct az_engine {
     // leaf de-duplication + evaluation cache (az_set_option "eval_dedup", "eval_cache_log2", "eval_cache_max_stones",
     // "eval_cache_persist")
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
-    int eval_cache_log2 = 24;       // entries = 2^log2 (40 B each); 0 = no cache, in-batch de-duplication only
+    int eval_cache_log2 = 26;       // entries = 2^log2 (40 B each: 2.7 GB); 0 = no cache, in-batch de-duplication only
     int eval_cache_max_stones = 42;
     int eval_cache_persist = 0;     // 0: az_selfplay / az_arena / az_tree_get_action_prob start from an empty cache
     DeviceMem cache_mem;
@@ -222,9 +225,19 @@ az_status fail_hip(az_engine* e, const HipFail& f) {
     return fail(e, AZ_ERR_HIP, buf);
 }
 
+NetWorkspace* workspace_for(az_engine* e, hipStream_t s) {
+    const int i = (s == e->stream) ? 0 : 1;
+    if (!e->ws[i]) {
+        const char* why = nullptr;
+        e->ws[i] = netws_create(e->cfg.net_channels, e->cfg.max_batch, &why);
+        if (!e->ws[i]) throw HipFail{hipErrorOutOfMemory, why ? why : "netws_create"};
+    }
+    return e->ws[i];
+}
+
 void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int rows_hint, hipStream_t s) {
     if (net.kind == AZ_NET_CONV) {
-        convnet_forward(net.conv, eb, rows_hint, s, e->prof.on ? &e->netprof : nullptr);
+        convnet_forward(net.conv, workspace_for(e, s), eb, rows_hint, s, e->prof.on ? &e->netprof : nullptr);
     } else {
         launch_net_fixture(eb, net.kind, net.salt, s);
     }
@@ -335,8 +348,7 @@ void resolve_profile(az_engine* e) {
     double ms[RG_COUNT] = {0, 0};
     e->prof.resolve(ms);
     e->stats.tree_ms += ms[RG_TREE];
-    for (auto& kv : e->nets)
-        if (kv.second.conv) convnet_resolve_profile(kv.second.conv, &e->netprof);
+    for (NetWorkspace* w : e->ws) netws_resolve_profile(w, &e->netprof);
 }
 
 // fold the per-tree counters into the engine stats and clear them
@@ -428,6 +440,7 @@ void az_destroy(az_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->nets) if (kv.second.conv) convnet_destroy(kv.second.conv);
+    for (NetWorkspace* w : e->ws) netws_destroy(w);
     trainer_destroy(e->trainer);
     { double ms[RG_COUNT] = {0, 0}; e->prof.resolve(ms); }
     (void)hipStreamDestroy(e->stream);
@@ -447,7 +460,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         // diagnostic (gemm_variant 13): median in-kernel clock of conv2's K loop for model `value`
         auto it = e->nets.find((int)value);
         std::vector<unsigned long long> st(2048);
-        if (it == e->nets.end() || !it->second.conv || !convnet_read_clock_stamps(it->second.conv, st.data()))
+        if (it == e->nets.end() || !it->second.conv || !netws_read_clock_stamps(e->ws[0], st.data()))
             return fail(e, AZ_ERR_BAD_ARGUMENT, "no conv net under that model id");
         std::vector<double> mhz;
         for (int i = 0; i < 1024; ++i) if (st[2 * i + 1]) mhz.push_back(100.0 * (double)st[2 * i] / (double)st[2 * i + 1]);
@@ -462,6 +475,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "eval_cache_log2") == 0 && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_max_stones") == 0 && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_persist") == 0 && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "conv1_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv1_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {
         convnet_set_conv4_big((int)value);
         return AZ_OK;
@@ -508,10 +522,21 @@ static az_status ensure_conv(az_engine* e, int32_t model_id, NetModel** out) {
     NetModel& m = e->nets[model_id];
     if (!m.conv) {
         const char* why = nullptr;
-        m.conv = convnet_create(e->cfg.net_channels, e->cfg.max_batch, &why);
+        m.conv = convnet_create(e->cfg.net_channels, &why);
         if (!m.conv) return fail(e, AZ_ERR_HIP, why ? why : "convnet_create failed");
     }
     *out = &m;
+    return AZ_OK;
+}
+
+az_status az_net_free(az_engine* e, int32_t model_id) {
+    if (!e) return AZ_ERR_BAD_ARGUMENT;
+    auto it = e->nets.find(model_id);
+    if (it == e->nets.end()) return fail(e, AZ_ERR_NO_MODEL, "model id not initialised");
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    if (it->second.conv) convnet_destroy(it->second.conv);
+    e->nets.erase(it);          // its evaluation-cache entries die with its tag
     return AZ_OK;
 }
 

@@ -8,7 +8,8 @@
 
 namespace az {
 
-struct ConvNet;   // weights + activation workspace, az_net.hip
+struct ConvNet;        // weights of one model id, az_net.hip
+struct NetWorkspace;   // activation workspace of one stream, az_net.hip
 
 // offsets of the flat f32 parameter vector (the weights file)
 struct Layout {
@@ -43,23 +44,28 @@ struct NetProfile {          // filled when profiling is on
 // pi = 1/7, v = +1 (kind 0) or the hash fixture (kind 1) for rows [0, *eb.n)
 void launch_net_fixture(const EvalBatch& eb, int kind, uint64_t salt, hipStream_t s);
 
-ConvNet* convnet_create(int channels, int max_batch, const char** err);
+// weights of one model id
+ConvNet* convnet_create(int channels, const char** err);
 void convnet_destroy(ConvNet* n);
+// activation workspace of one stream, shared by every model that runs on it
+NetWorkspace* netws_create(int channels, int max_batch, const char** err);
+void netws_destroy(NetWorkspace* ws);
 int64_t convnet_param_count(int channels);
 // raw f32 parameters (layout: DESIGN.md "weights file"); BN is folded and weights are
 // rounded to bf16 on upload.
 bool convnet_set_params(ConvNet* n, const float* host_params, int64_t count);
 bool convnet_get_params(const ConvNet* n, float* host_params, int64_t count);
 void convnet_init_random(ConvNet* n, uint64_t seed);
-// fold finished profile records into *prof (call after the stream has been synchronised)
-void convnet_resolve_profile(ConvNet* n, NetProfile* prof);
-// forward for rows [0, *eb.n); n_rows_hint = host-side upper bound used to size the grids.
-// If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
-// kernel-variant switch for A/B measurements (0 = 128x128 tiles everywhere, 1 = default)
+// fold finished profile records into *prof (call after the workspace's stream has been synchronised)
+void netws_resolve_profile(NetWorkspace* ws, NetProfile* prof);
+// kernel-variant switches for A/B measurements (az_set_option "gemm_variant", "conv4_big", "conv1_table")
 void convnet_set_variant(int v);
-// diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop
-bool convnet_read_clock_stamps(ConvNet* n, unsigned long long* out2048);
 void convnet_set_conv4_big(int v);
-void convnet_forward(ConvNet* n, const EvalBatch& eb, int n_rows_hint, hipStream_t s, NetProfile* prof);
+void convnet_set_conv1_table(int v);
+// diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop
+bool netws_read_clock_stamps(NetWorkspace* ws, unsigned long long* out2048);
+// forward for rows [0, *eb.n) of model n in workspace ws; n_rows_hint = host-side upper bound used to size the grids.
+// If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
+void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int n_rows_hint, hipStream_t s, NetProfile* prof);
 
 }  // namespace az

@@ -116,6 +116,57 @@ __global__ __launch_bounds__(256) void k_conv1(const EvalBatch eb, const float* 
     }
 }
 
+// ---- conv1 as a TABLE ---------------------------------------------------------------------------------------------
+// conv1's output at a board position depends on nothing but its 3x3 neighbourhood: 9 cells x {empty or outside the board,
+// mine, theirs} = 3^9 = 19683 patterns.  The table holds relu(conv1) for every pattern ([19683][C] bf16, 20 MB at C = 512,
+// built once per weight upload with k_conv1's own summation order, so the rows are bit-identical to what k_conv1 writes),
+// and conv2's image DMA gathers its 128-byte row segments straight from it (global_load_lds takes any per-lane source
+// address): no conv1 launch, no act1 round trip through HBM, and the hot patterns (empty neighbourhoods) live in L2.
+// pattern index = sum over taps t = ky*3 + kx of cell(y+ky-1, x+kx-1) * 3^t, cell = 0 empty/outside, 1 mine, 2 theirs.
+constexpr int CONV1_PATTERNS = 19683;
+AZ_HD uint32_t conv1_pattern(uint64_t mine, uint64_t theirs, int y /*row from the top*/, int x) {
+    uint32_t idx = 0, mul = 1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = y + ky - 1, ix = x + kx - 1;
+            if (iy >= 0 && iy < 6 && ix >= 0 && ix < 7) {
+                const uint64_t bit = 1ull << (ix * 7 + (5 - iy));
+                idx += ((mine & bit) ? 1u : (theirs & bit) ? 2u : 0u) * mul;
+            }
+            mul *= 3u;
+        }
+    return idx;
+}
+__global__ __launch_bounds__(64) void k_conv1_table(const float* __restrict__ w /*[18][C]*/, const float* __restrict__ bias /*[C]*/,
+                                                    uint16_t* __restrict__ table /*[19683][C]*/, int C) {
+    const int idx = blockIdx.x;
+    int cell[9], r = idx;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { cell[t] = r % 3; r /= 3; }
+    for (int c8 = threadIdx.x; c8 < C / 8; c8 += 64) {
+        const float4* bp = (const float4*)(bias + c8 * 8);
+        float4 a0 = bp[0], a1 = bp[1];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)                    // (ky, kx) order, then plane 0 (mine) before plane 1: k_conv1's order
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                if (cell[t] != ci + 1) continue;
+                const float4* wp = (const float4*)(w + (t * 2 + ci) * C + c8 * 8);
+                const float4 w0 = wp[0], w1 = wp[1];
+                a0.x += w0.x; a0.y += w0.y; a0.z += w0.z; a0.w += w0.w;
+                a1.x += w1.x; a1.y += w1.y; a1.z += w1.z; a1.w += w1.w;
+            }
+        uint4 o;
+        o.x = pack_bf16x2(fmaxf(a0.x, 0.0f), fmaxf(a0.y, 0.0f));
+        o.y = pack_bf16x2(fmaxf(a0.z, 0.0f), fmaxf(a0.w, 0.0f));
+        o.z = pack_bf16x2(fmaxf(a1.x, 0.0f), fmaxf(a1.y, 0.0f));
+        o.w = pack_bf16x2(fmaxf(a1.z, 0.0f), fmaxf(a1.w, 0.0f));
+        *(uint4*)(table + (size_t)idx * C + c8 * 8) = o;
+    }
+}
+
 // ---- implicit GEMM on MFMA: out[M,N] = relu(A_gather[M,K] * W[N,K]^T + bias) ---------------------------
 // Row m = (sample b, output position (y,x)); K index = tap * cin + c with tap = ky*tap_w + kx reading the
 // input at position (y+ky, x+kx) of an [in_h][in_w][in_c] channels-last image (the 'same' conv reads a
@@ -134,6 +185,7 @@ struct GemmDesc {
     int K, N;
     int relu;
     unsigned long long* dbg;   // diagnostic builds only (ABLATE == 3): per-block {shader cycles, 100 MHz ticks}
+    const ulonglong2* states;  // k_conv_img2<.., true> only: the batch's canonical bitboards (A is then the conv1 table)
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -613,7 +665,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
 // exposed inside a workgroup and covered by the other one).  Same K order: bit-identical.
 constexpr int HBN2_ = 128;
 
-template <int LAYER>
+// TABLE: the image rows are gathered from the conv1 table (d.A) by pattern index instead of read from act1.
+template <int LAYER, bool TABLE = false>
 __global__ __launch_bounds__(256, 2) void k_conv_img2(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32768];   // img | w[2] (16 KiB each)
     const int n_boards = (int)(*d.n_dev);
@@ -640,7 +693,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_img2(const GemmDesc d) {
         int b = b0 + r / 42;
         b = b < n_boards ? b : n_boards - 1;
         const int p = r % 42, y = p / 7, x = p - y * 7;
-        i_ob[q] = (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8) * 2u;
+        if constexpr (TABLE) {
+            const ulonglong2 st = d.states[b];
+            i_ob[q] = (conv1_pattern(st.x, st.y, y, x) * (uint32_t)C + (uint32_t)chunk * 8u) * 2u;
+        } else {
+            i_ob[q] = (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8) * 2u;
+        }
     }
     const bool i_last_ok = (7 * 4 + wave) * 8 + lrow < IMG_ROWS;          // only piece 7 can run past row 251
     // weight DMA map: piece q (0..3) of wave w = tile rows (q*4 + w)*8 + lrow
@@ -982,14 +1040,28 @@ __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_
 //   conv1 W[3][3][2][C] b[C] bn[4][C] | conv2..4 W[3][3][C][C] b[C] bn[4][C] |
 //   fc1 W[6C][1024] b[1024] bn[4][1024] (input index = (y*3+x)*C + c of conv4's [2][3][C] output) |
 //   fc2 W[1024][512] b[512] bn[4][512] | pi W[512][7] b[7] | v W[512][1] b[1]
-struct ConvNet {
-    int C = 512, max_batch = 0;
+struct ConvNet {                      // the WEIGHTS of one model id (21 MB bf16 + the 20 MB conv1 table at C = 512)
+    int C = 512;
     std::vector<float> params;        // raw f32 parameters as set
     std::vector<void*> dev;           // every device allocation
     float *w1 = nullptr, *b1 = nullptr;              // conv1 folded f32 [18][C], [C]
+    uint16_t* t1 = nullptr;                            // conv1 table [19683][C] bf16 (k_conv1_table)
     uint16_t* wg[5] = {nullptr};                       // conv2,3,4, fc1, fc2 folded bf16 [N][K]
     float* bg[5] = {nullptr};                          // folded bias f32 [N]
     float *wh = nullptr, *bh = nullptr;              // heads f32 [8][512], [8]
+    template <class T> T* dalloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+        dev.push_back(p);
+        return (T*)p;
+    }
+};
+
+// Activation workspace of ONE stream (1.2 GB at 8192 rows, C = 512), shared by every model that runs on that stream:
+// model ids come and go with the Coach loop (src/coach.rs:296-390), the workspace does not grow with them.
+struct NetWorkspace {
+    int C = 512, max_batch = 0;
+    std::vector<void*> dev;
     uint16_t *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *fc1o = nullptr, *fc2o = nullptr;
     // profiling: event quads per forward + pinned copies of the batch size
     struct Rec { hipEvent_t e0, e1, e2, e3; uint32_t* n; };
@@ -1008,16 +1080,15 @@ struct ConvNet {
 
 int64_t convnet_param_count(int channels) { return Layout(channels).total; }
 
-ConvNet* convnet_create(int channels, int max_batch, const char** err) {
+ConvNet* convnet_create(int channels, const char** err) {
     if (channels % 128 != 0 || channels < 128) { if (err) *err = "net_channels must be a multiple of 128"; return nullptr; }
     ConvNet* n = new ConvNet();
     n->C = channels;
-    n->max_batch = max_batch;
     const int C = channels;
-    const size_t B = (size_t)max_batch;
     bool ok = true;
     ok &= (n->w1 = n->dalloc<float>(18 * (size_t)C)) != nullptr;
     ok &= (n->b1 = n->dalloc<float>(C)) != nullptr;
+    ok &= (n->t1 = n->dalloc<uint16_t>((size_t)CONV1_PATTERNS * C)) != nullptr;
     const size_t wk[5] = {9 * (size_t)C, 9 * (size_t)C, 9 * (size_t)C, 6 * (size_t)C, 1024};
     const size_t wn[5] = {(size_t)C, (size_t)C, (size_t)C, 1024, 512};
     for (int l = 0; l < 5; ++l) {
@@ -1026,17 +1097,6 @@ ConvNet* convnet_create(int channels, int max_batch, const char** err) {
     }
     ok &= (n->wh = n->dalloc<float>(8 * 512)) != nullptr;
     ok &= (n->bh = n->dalloc<float>(8)) != nullptr;
-    ok &= (n->act1 = n->dalloc<uint16_t>(B * 72 * C)) != nullptr;
-    ok &= (n->act2 = n->dalloc<uint16_t>(B * 42 * C)) != nullptr;
-    ok &= (n->act3 = n->dalloc<uint16_t>(B * 20 * C)) != nullptr;
-    ok &= (n->act4 = n->dalloc<uint16_t>(B * 6 * C)) != nullptr;
-    ok &= (n->fc1o = n->dalloc<uint16_t>(B * 1024)) != nullptr;
-    ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
-    if (ok) ok = hipMemset(n->act1, 0, B * 72 * C * sizeof(uint16_t)) == hipSuccess;   // the zero halo
-    ok &= (n->dbg = n->dalloc<unsigned long long>(2048)) != nullptr;
-    if (ok) ok = hipMemset(n->dbg, 0, 2048 * 8) == hipSuccess;
-    if (ok) ok = hipHostMalloc((void**)&n->pinned_n, 4096 * sizeof(uint32_t)) == hipSuccess;
-    n->pinned_cap = 4096;
     if (!ok) {
         if (err) *err = "convnet_create: device allocation failed";
         convnet_destroy(n);
@@ -1046,6 +1106,44 @@ ConvNet* convnet_create(int channels, int max_batch, const char** err) {
 }
 
 void convnet_destroy(ConvNet* n) {
+    if (!n) return;
+    for (void* p : n->dev) (void)hipFree(p);
+    delete n;
+}
+
+NetWorkspace* netws_create(int channels, int max_batch, const char** err) {
+    NetWorkspace* n = new NetWorkspace();
+    n->C = channels;
+    n->max_batch = max_batch;
+    const int C = channels;
+    const size_t B = (size_t)max_batch;
+    bool ok = true;
+    ok &= (n->act2 = n->dalloc<uint16_t>(B * 42 * C)) != nullptr;
+    ok &= (n->act3 = n->dalloc<uint16_t>(B * 20 * C)) != nullptr;
+    ok &= (n->act4 = n->dalloc<uint16_t>(B * 6 * C)) != nullptr;
+    ok &= (n->fc1o = n->dalloc<uint16_t>(B * 1024)) != nullptr;
+    ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
+    ok &= (n->dbg = n->dalloc<unsigned long long>(2048)) != nullptr;
+    if (ok) ok = hipMemset(n->dbg, 0, 2048 * 8) == hipSuccess;
+    if (ok) ok = hipHostMalloc((void**)&n->pinned_n, 4096 * sizeof(uint32_t)) == hipSuccess;
+    n->pinned_cap = 4096;
+    if (!ok) {
+        if (err) *err = "netws_create: device allocation failed";
+        netws_destroy(n);
+        return nullptr;
+    }
+    return n;
+}
+
+// act1 (conv1's haloed output image, 604 MB at 8192 rows) is only needed by the kernel sets that run conv1 as a kernel
+static bool netws_need_act1(NetWorkspace* n) {
+    if (n->act1) return true;
+    const size_t bytes = (size_t)n->max_batch * 72 * n->C * sizeof(uint16_t);
+    n->act1 = n->dalloc<uint16_t>(bytes / sizeof(uint16_t));
+    return n->act1 && hipMemset(n->act1, 0, bytes) == hipSuccess;   // the zero halo
+}
+
+void netws_destroy(NetWorkspace* n) {
     if (!n) return;
     for (void* p : n->dev) (void)hipFree(p);
     for (auto& r : n->open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); (void)hipEventDestroy(r.e3); }
@@ -1078,6 +1176,8 @@ bool convnet_set_params(ConvNet* net, const float* p, int64_t count) {
         }
         ok &= hipMemcpy(net->w1, w.data(), w.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
         ok &= hipMemcpy(net->b1, b.data(), b.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        hipLaunchKernelGGL(k_conv1_table, dim3(CONV1_PATTERNS), dim3(64), 0, nullptr, net->w1, net->b1, net->t1, C);
+        ok &= hipDeviceSynchronize() == hipSuccess;
     }
     // conv2..4 and fc1, fc2: bf16 [N][K] (K index = tap*cin + ci = the raw weight's leading index)
     const int64_t w_off[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
@@ -1163,7 +1263,8 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     if ((v == 3 || v == 5) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
         const int t8 = (tiles + 7) / 8 * 8;
-        if (v == 5) hipLaunchKernelGGL((k_conv_img2<LAYER>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+        if (v == 5 && d.states) hipLaunchKernelGGL((k_conv_img2<LAYER, true>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+        else if (v == 5) hipLaunchKernelGGL((k_conv_img2<LAYER>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
@@ -1196,15 +1297,15 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     hipLaunchKernelGGL(k_gemm_mfma<LAYER>, dim3(grid), dim3(256), 0, s, d);
 }
 
-static hipEvent_t net_event(ConvNet* n) {
+static hipEvent_t net_event(NetWorkspace* n) {
     if (!n->ev_pool.empty()) { hipEvent_t e = n->ev_pool.back(); n->ev_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
 }
 
-// Resolve finished profile records (call after the stream is synchronised).
-void convnet_resolve_profile(ConvNet* n, NetProfile* prof) {
+// Resolve finished profile records (call after the workspace's stream is synchronised).
+void netws_resolve_profile(NetWorkspace* n, NetProfile* prof) {
     if (!n) return;
     const int C = n->C;
     const double f_conv = 2.0 * 9.0 * C * C;
@@ -1226,59 +1327,66 @@ void convnet_resolve_profile(ConvNet* n, NetProfile* prof) {
 }
 
 void convnet_set_variant(int v) { g_gemm_variant = v; }
-bool convnet_read_clock_stamps(ConvNet* n, unsigned long long* out2048) {
+bool netws_read_clock_stamps(NetWorkspace* n, unsigned long long* out2048) {
     return n && hipMemcpy(out2048, n->dbg, 2048 * 8, hipMemcpyDeviceToHost) == hipSuccess;
 }
 void convnet_set_conv4_big(int v) { g_conv4_big = v; }
+int g_conv1_table = 1;    // conv2 gathers its image from the conv1 table (default kernel set only); 0 = run k_conv1 into act1
+void convnet_set_conv1_table(int v) { g_conv1_table = v; }
 
-void convnet_forward(ConvNet* n, const EvalBatch& eb, int rows_hint, hipStream_t s, NetProfile* prof) {
+void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows_hint, hipStream_t s, NetProfile* prof) {
     const int C = n->C;
-    if (rows_hint > n->max_batch) rows_hint = n->max_batch;
+    if (rows_hint > ws->max_batch) rows_hint = ws->max_batch;
     if (rows_hint <= 0) return;
-    ConvNet::Rec rec{};
-    const bool timed = prof != nullptr && n->pinned_next < n->pinned_cap;
+    NetWorkspace::Rec rec{};
+    const bool timed = prof != nullptr && ws->pinned_next < ws->pinned_cap;
     if (timed) {
-        rec.e0 = net_event(n); rec.e1 = net_event(n); rec.e2 = net_event(n); rec.e3 = net_event(n);
-        rec.n = n->pinned_n + n->pinned_next++;
+        rec.e0 = net_event(ws); rec.e1 = net_event(ws); rec.e2 = net_event(ws); rec.e3 = net_event(ws);
+        rec.n = ws->pinned_n + ws->pinned_next++;
         (void)hipMemcpyAsync(rec.n, eb.n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         (void)hipEventRecord(rec.e0, s);
     }
-    {
+    // conv1 + conv2: the default kernel set gathers conv2's image from the conv1 table; the others run conv1 into act1
+    const bool table = g_conv1_table && g_gemm_variant == 5 && C % HBN_ == 0;
+    if (!table) {
+        if (!netws_need_act1(ws)) return;
         const size_t waves = (size_t)rows_hint;                                        // one wave per board
         const size_t blocks = std::min<size_t>((waves + 3) / 4, 256 * 4);            // 4 persistent blocks per CU (38 KiB LDS each)
         hipLaunchKernelGGL(k_conv1, dim3((unsigned)blocks), dim3(256), (size_t)(19 * C) * sizeof(float), s, eb, n->w1, n->b1,
-                           n->act1, C);
+                           ws->act1, C);
     }
     GemmDesc d{};
     d.n_dev = eb.n;
     d.relu = 1;
-    d.dbg = n->dbg;
-    // conv2: 3x3 same over the haloed [8][9][C] image -> [6][7][C]
-    d.A = n->act1; d.W = n->wg[0]; d.bias = n->bg[0]; d.out = n->act2;
+    d.dbg = ws->dbg;
+    // conv2: 3x3 same over the haloed [8][9][C] image (or the conv1 table) -> [6][7][C]
+    d.A = table ? n->t1 : ws->act1; d.states = table ? eb.state : nullptr;
+    d.W = n->wg[0]; d.bias = n->bg[0]; d.out = ws->act2;
     d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;
     if (timed) (void)hipEventRecord(rec.e1, s);
     launch_gemm<1>(d, rows_hint, s);
     if (timed) (void)hipEventRecord(rec.e2, s);
+    d.states = nullptr;
     // conv3: 3x3 valid [6][7][C] -> [4][5][C]
-    d.A = n->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = n->act3;
+    d.A = ws->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = ws->act3;
     d.rows_per_sample = 20; d.out_w = 5; d.in_h = 6; d.in_w = 7;
     launch_gemm<2>(d, rows_hint, s);
     // conv4: 3x3 valid [4][5][C] -> [2][3][C]
-    d.A = n->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = n->act4;
+    d.A = ws->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = ws->act4;
     d.rows_per_sample = 6; d.out_w = 3; d.in_h = 4; d.in_w = 5;
     launch_gemm<3>(d, rows_hint, s);
     // fc1: [6C] -> 1024
-    d.A = n->act4; d.W = n->wg[3]; d.bias = n->bg[3]; d.out = n->fc1o;
+    d.A = ws->act4; d.W = n->wg[3]; d.bias = n->bg[3]; d.out = ws->fc1o;
     d.rows_per_sample = 1; d.out_w = 1; d.in_h = 1; d.in_w = 1; d.in_c = 6 * C; d.tap_w = 1; d.cin = 6 * C; d.K = 6 * C; d.N = 1024;
     launch_gemm<4>(d, rows_hint, s);
     // fc2: 1024 -> 512
-    d.A = n->fc1o; d.W = n->wg[4]; d.bias = n->bg[4]; d.out = n->fc2o;
+    d.A = ws->fc1o; d.W = n->wg[4]; d.bias = n->bg[4]; d.out = ws->fc2o;
     d.in_c = 1024; d.cin = 1024; d.K = 1024; d.N = 512;
     launch_gemm<5>(d, rows_hint, s);
-    hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, n->fc2o, n->wh, n->bh);
+    hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, ws->fc2o, n->wh, n->bh);
     if (timed) {
         (void)hipEventRecord(rec.e3, s);
-        n->open.push_back(rec);
+        ws->open.push_back(rec);
     }
 }
 

@@ -68,7 +68,7 @@ class az_arena_params(C.Structure):
 
 # every symbol include/az_engine.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "az_create", "az_destroy", "az_last_error", "az_set_option", "az_get_stats", "az_reset_stats", "az_net_set_kind",
+    "az_create", "az_destroy", "az_last_error", "az_set_option", "az_get_stats", "az_reset_stats", "az_net_set_kind", "az_net_free",
     "az_net_init_random", "az_net_load", "az_net_save", "az_net_param_count", "az_net_set_params",
     "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_net_train_history",
     "az_net_train_begin", "az_net_train_step", "az_net_train_end", "az_tree_create",
@@ -93,6 +93,7 @@ def load_library(path=LIB_PATH):
         "az_reset_stats": (i32, [vp]),
         "az_net_set_kind": (i32, [vp, i32, i32, u64]),
         "az_net_init_random": (i32, [vp, i32, u64]),
+        "az_net_free": (i32, [vp, i32]),
         "az_net_load": (i32, [vp, i32, C.c_char_p]),
         "az_net_save": (i32, [vp, i32, C.c_char_p]),
         "az_net_param_count": (i64, [vp]),
@@ -174,6 +175,10 @@ class Engine:
     # ---- NNet ----
     def net_set_kind(self, model_id, kind, salt=0):
         self._check(_lib.az_net_set_kind(self._h, model_id, kind, salt))
+
+    def net_free(self, model_id):
+        """Drop a model id (weights + conv1 table); the per-stream activation workspace stays."""
+        self._check(_lib.az_net_free(self._h, model_id))
 
     def net_init_random(self, model_id, seed):
         self._check(_lib.az_net_init_random(self._h, model_id, seed))

@@ -102,10 +102,11 @@ const char* az_last_error(const az_engine* e);
 /* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
  * net uses (0 = 128x128 register-staged tiles for every layer, 1 / 2 = 256x256 LDS-DMA tiles, 3 = conv2 image-resident
  * in one 8-wave workgroup per CU, 5 = default, conv2 image-resident in two 4-wave workgroups per CU; 11-17 = timing
- * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto).
+ * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto). "conv1_table" = 1 (default): conv2 of the default kernel set gathers its input image from the
+ * per-model conv1 table (3^9 neighbourhood patterns x C channels) instead of running conv1 as a kernel, 0 = conv1 kernel; bit-identical.
  * Leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
  * src/node.rs:282-289): "eval_dedup" = 0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is
- * evaluated once; "eval_cache_log2" = log2 entries of the engine's evaluation cache shared by all trees (default 24, 0 = none,
+ * evaluated once; "eval_cache_log2" = log2 entries of the engine's evaluation cache shared by all trees (default 26, 0 = none,
  * 40 bytes per entry); "eval_cache_max_stones" = only states with at most that many stones are cached (default 42);
  * "eval_cache_persist" = 0 (default): every az_selfplay / az_arena / az_tree_get_action_prob call starts from an empty cache,
  * 1: entries live until the model's weights change.  Unknown keys or values return AZ_ERR_BAD_ARGUMENT. */
@@ -116,6 +117,10 @@ az_status az_reset_stats(az_engine* e);
 /* ---- NNet trait, src/nnet.rs:35-45 -------------------------------------- */
 /* NNet::new for the stub / hash nets (no weights). salt only matters for AZ_NET_HASH. */
 az_status az_net_set_kind(az_engine* e, int32_t model_id, az_net_kind kind, uint64_t salt);
+/* Drop a model id and its device memory (weights + conv1 table, 41 MB at C = 512).  The reference never frees a model:
+ * its Python side keeps one checkpoint per id on disk (src/nnet.rs:36); a long Coach::learn run (src/coach.rs:296-390: a new
+ * id per accepted iteration) calls this for the superseded id.  The activation workspace is per stream, not per model. */
+az_status az_net_free(az_engine* e, int32_t model_id);
 /* NNet::new with random init: Glorot-uniform kernels, zero bias, BN gamma=1 beta=0 mean=0 var=1 eps=1e-3. */
 az_status az_net_init_random(az_engine* e, int32_t model_id, uint64_t seed);
 /* NNet::new(checkpoint) / save: flat f32 file, layout in DESIGN.md "weights file". */

@@ -116,13 +116,15 @@ def test_net_parity_at_bench_scale(engine, oracle):
         ref_v = np.empty(8192, np.float32)
         for o in range(0, 8192, 256):
             ref_pi[o:o + 256], ref_v[o:o + 256] = engine.predict_states(states[o:o + 256], 20)
-        for variant in (5, 0):
+        for variant, table in ((5, 1), (5, 0), (0, 0)):        # table: conv2 gathers from the conv1 table / reads k_conv1's act1
             for big in (0, 1, 2):
                 engine.set_option("gemm_variant", variant)
+                engine.set_option("conv1_table", table)
                 engine.set_option("conv4_big", big)
                 for n in (8192, 5003):
                     pi, v = engine.predict_states(states[:n], 20)
-                    assert np.array_equal(pi, ref_pi[:n]) and np.array_equal(v, ref_v[:n]), (variant, big, n)
+                    assert np.array_equal(pi, ref_pi[:n]) and np.array_equal(v, ref_v[:n]), (variant, table, big, n)
+        engine.set_option("conv1_table", 1)
         # a different row order through the full-size kernels (rows land in other tiles / XCDs)
         engine.set_option("gemm_variant", 5)
         engine.set_option("conv4_big", 2)
@@ -132,6 +134,7 @@ def test_net_parity_at_bench_scale(engine, oracle):
     finally:
         engine.set_option("gemm_variant", 5)
         engine.set_option("conv4_big", 2)
+        engine.set_option("conv1_table", 1)
     n = 4096
     boards = np.stack([oracle.c4_features(int(m), int(t)) for m, t in states[:n]])
     rpi, rv = forward_ref(engine.net_get_params(20), boards, C, emulate_bf16=True)
@@ -236,3 +239,29 @@ def test_dedup_is_bit_exact_with_the_conv_net(conv_engine, oracle):
     assert sa["leaf_rows_executed"] == sa["leaf_rows_requested"] == sa["leaf_evals"] == sb["leaf_evals"]
     assert sb["leaf_rows_requested"] == sb["leaf_evals"] == sb["leaf_rows_executed"] + sb["eval_cache_hits"] + sb["eval_batch_dups"]
     assert sb["leaf_rows_executed"] < 0.9 * sb["leaf_rows_requested"], sb
+
+
+def test_model_slots_do_not_leak(engine_mod):
+    """A long Coach::learn run trains into a new model id per accepted iteration (src/coach.rs:296-390).  The activation
+    workspace belongs to the stream, not to the model, and az_net_free drops a superseded id: device memory stays flat."""
+    import torch
+    e = engine_mod.Engine(device=0, max_batch=2048, net_channels=C)
+    try:
+        e.net_init_random(0, seed=1)
+        s = np.zeros((64, 2), np.uint64)
+        e.predict_states(s, 0)                              # creates the workspace
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for k in range(1, 13):
+            e.net_init_random(k, seed=k)
+            e.predict_states(s, k)
+            e.net_free(k - 1)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info(0)[0]
+        assert abs(free0 - free1) < 64 << 20, (free0, free1)       # one model is 41 MB; 12 leaked workspaces would be 3.6 GB
+        with pytest.raises(engine_mod.AzError):
+            e.predict_states(s, 3)                          # a freed id is gone
+        pi, v = e.predict_states(s, 12)
+        assert np.isfinite(pi).all()
+    finally:
+        e.close()

@@ -24,7 +24,9 @@ def main():
     fetch, nf = fold(sys.argv[1], "FETCH_SIZE")
     write, nw = fold(sys.argv[2], "WRITE_SIZE")
     line = json.loads([l for l in open(sys.argv[3]).read().splitlines() if l.startswith("{")][-1])
-    leaf_evals = line["leaf_evals_per_sec"] * line["ms_per_step"] * line["steps"] / 1e3
+    # rows the net really ran (leaf de-duplication): every per-leaf figure below is per EXECUTED row
+    per_sec = line["leaf_rows"]["executed_per_sec"] if "leaf_rows" in line else line["leaf_evals_per_sec"]
+    leaf_evals = per_sec * line["ms_per_step"] * line["steps"] / 1e3
     conv = [k for k in fetch if "k_conv_img" in k]   # k_conv_img2<1> (default) or k_conv_img<1>
     launches = nf[conv[0]] if conv else max(nf.values())
     per_launch_leaves = leaf_evals / launches
