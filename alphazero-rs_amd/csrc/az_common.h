@@ -14,16 +14,10 @@
 namespace az {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int ACTIONS = 7;
-constexpr int PATH_CAP = 48;          // a Connect Four line has at most 42 plies
-constexpr int LANES = 8;              // lanes cooperating on one game (7 children + 1)
+constexpr int PATH_CAP = 48;          // node_path entries per simulation (a Connect Four line has at most 42 plies)
 
-// ---- node record (one uint4 per slot) ---------------------------------------
-// x: link  (NONE, or tree-local index of the canonical node: NodeLink.1, src/node.rs:129)
-// y: prior (f32 bits) of the edge parent->this slot: parent.mu.p[a], src/node.rs:354
-// z: meta  bits 0-2 a (src/node.rs:19) | 3-5 nchild | 6 expanded (mu.s is Some)
-//          | 7-8 ecode (e, src/node.rs:20) | 9 has_prior (mu.p is Some)
-// w: child_base (children are contiguous: src/node.rs:313-317)
+// ---- node meta word (the record itself: az_tree.h) ----------------------------
+// bits 0-2 a (src/node.rs:19) | 3-5 nchild | 6 expanded (mu.s is Some) | 7-8 ecode (e, src/node.rs:20) | 9 has_prior (mu.p is Some)
 constexpr uint32_t META_A_MASK = 7u;
 constexpr uint32_t META_NCHILD_SHIFT = 3;
 constexpr uint32_t META_EXPANDED = 1u << 6;
@@ -83,67 +77,6 @@ constexpr uint64_t RNG_BATCH = 4;
 AZ_HD bool dropout_keep(uint64_t mask_seed, uint32_t layer, uint64_t idx, uint32_t keep_thresh24) {
     const uint64_t r = mix64(mix64(mask_seed ^ ((uint64_t)(layer + 1) * 0xD1B54A32D192ED03ull)) ^ idx);
     return (uint32_t)(r >> 40) < keep_thresh24;
-}
-
-// ---- Connect Four on canonical bitboards (connect_four_game.rs:81-238) --------
-// bit(col,row) = col*7 + row, row 0 = bottom; `mine` = side to move.
-constexpr uint64_t C4_FULL = 0x3Full | (0x3Full << 7) | (0x3Full << 14) | (0x3Full << 21) | (0x3Full << 28) |
-                             (0x3Full << 35) | (0x3Full << 42);
-AZ_HD uint64_t c4_top(int c) { return 1ull << (c * 7 + 5); }
-AZ_HD bool c4_has_four(uint64_t b) {
-    uint64_t m;
-    m = b & (b >> 1); if (m & (m >> 2)) return true;
-    m = b & (b >> 7); if (m & (m >> 14)) return true;
-    m = b & (b >> 6); if (m & (m >> 12)) return true;
-    m = b & (b >> 8); if (m & (m >> 16)) return true;
-    return false;
-}
-// valid-move bitmask (bit c set <=> heights[c] < 6), connect_four_game.rs:105-110
-AZ_HD uint32_t c4_valid_mask(uint64_t mine, uint64_t theirs) {
-    uint64_t mask = mine | theirs;
-    uint32_t v = 0;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) v |= (mask & c4_top(c)) ? 0u : (1u << c);
-    return v;
-}
-// get_next_state(1, a) then get_canonical_form(next_player): connect_four_game.rs:90-103, :198-203 (B5)
-AZ_HD void c4_play(uint64_t mine, uint64_t theirs, int a, uint64_t* nmine, uint64_t* ntheirs) {
-    uint64_t mask = mine | theirs;
-    uint64_t nb = (mask + (1ull << (a * 7))) & (0x3Full << (a * 7));
-    *nmine = theirs;
-    *ntheirs = mine | nb;
-}
-// ecode of a canonical state: e = -get_game_ended(1), connect_four_game.rs:112-196 (B6), src/node.rs:293-294
-AZ_HD uint32_t c4_ecode(uint64_t mine, uint64_t theirs) {
-    if (c4_has_four(mine)) return E_MINUS1;        // ended = +1 (unreachable in legal play)
-    if (c4_has_four(theirs)) return E_PLUS1;       // ended = -1: the player who moved in has won
-    if ((mine | theirs) == C4_FULL) return E_DRAW; // ended = DRAW_EPS
-    return E_NONE;
-}
-AZ_HD uint64_t c4_mirror(uint64_t b) {
-    uint64_t r = 0;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) r |= ((b >> (c * 7)) & 0x7Full) << ((6 - c) * 7);
-    return r;
-}
-// feature (plane, row-from-top, col) of a canonical state, connect_four_game.rs:219-237 (S8)
-AZ_HD float c4_feature(uint64_t mine, uint64_t theirs, int plane, int r, int c) {
-    uint64_t bit = 1ull << (c * 7 + (5 - r));
-    return ((plane == 0 ? mine : theirs) & bit) ? 1.0f : 0.0f;
-}
-AZ_HD uint32_t c4_hash(uint64_t mine, uint64_t theirs) { return (uint32_t)mix64(mine ^ mix64(theirs)); }
-// One-word identity of a canonical state (49 bits, never 0): mask + bottom row puts a single 1 above every column's stones,
-// adding `mine` fills in the mover's stones below it.
-constexpr uint64_t C4_BOTTOM = 1ull | (1ull << 7) | (1ull << 14) | (1ull << 21) | (1ull << 28) | (1ull << 35) | (1ull << 42);
-AZ_HD uint64_t c4_key(uint64_t mine, uint64_t theirs) { return mine + (mine | theirs) + C4_BOTTOM; }
-
-// test-fixture net (exact in f32); oracle twin: hashnet_eval in oracle/az_oracle_games.hpp
-AZ_HD void hashnet_eval(uint64_t mine, uint64_t theirs, uint64_t salt, float* pi, float* v) {
-    uint64_t h = mix64(mine ^ mix64(theirs ^ mix64(salt)));
-#pragma unroll
-    for (int a = 0; a < 7; ++a)
-        pi[a] = (float)(uint32_t)((mix64(h + (uint64_t)a) >> 40) + 1) * (1.0f / 16777216.0f);
-    *v = (float)(uint32_t)(mix64(h + 7) >> 40) * (1.0f / 8388608.0f) - 1.0f;
 }
 
 }  // namespace az

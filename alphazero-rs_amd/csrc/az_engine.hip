@@ -90,60 +90,41 @@ struct TreeHost {
     TreeDev d{};
     EvalBatch eb{};         // eval batch of even simulations (and of the root evaluation)
     EvalBatch eb2{};        // eval batch of odd simulations: k_backup_select ping-pongs between the two
-    uint32_t dd_epoch = 0;  // election-table epoch of the last k_dedup launch (both batches share the counter)
-    // unique-row view of a batch: what the net runs on when de-duplication is on
-    static EvalBatch unique_view(const EvalBatch& b) {
-        EvalBatch u{};
-        u.cap = b.cap; u.n = b.un; u.tree = b.tree; u.state = b.ustate; u.pi = b.upi; u.v = b.uv;
-        return u;
-    }
-    void create(int G, uint64_t R, uint32_t H, int log_cap) {
-        d.G = G; d.R = (uint32_t)R; d.H = H;
-        size_t slots = (size_t)G * R;
-        d.rec = mem.alloc<uint4>(slots);
-        d.ctr = mem.alloc<uint64_t>(slots);
-        d.state = mem.alloc<ulonglong2>(slots);
+    uint32_t dd_epoch = 0;  // election-table epoch of the last request launch (both batches share the counter)
+    unsigned long long* d_totals = nullptr;   // [ST_COUNT] k_harvest's sums
+    uint32_t* d_counts = nullptr;             // [G] NodeStore::len per tree (k_harvest)
+    // blocks = child blocks the trees can use (each holds the <= 7 children of one expansion, or a root);
+    // reserve_nodes = reserve_space (src/node.rs:146) clamped to what is reachable
+    void create(int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int log_cap) {
+        d.G = G; d.R = (uint32_t)(blocks * BLOCK_SLOTS); d.H = H; d.reserve_nodes = (uint32_t)reserve_nodes;
+        size_t slots = (size_t)G * d.R;
+        d.node = mem.alloc<uint4>(slots * 2);
         d.hash = mem.alloc<uint32_t>((size_t)G * H);
-        d.len = mem.alloc<uint32_t>(G);
-        d.root = mem.alloc<uint32_t>(G);
-        d.active = mem.alloc<uint8_t>(G);
+        d.head = mem.alloc<TreeHead>(G);
         d.path = mem.alloc<uint32_t>((size_t)G * PATH_CAP);
-        d.path_len = mem.alloc<uint32_t>(G);
-        d.leaf = mem.alloc<uint32_t>(G);
-        d.leaf_kind = mem.alloc<uint32_t>(G);
-        d.leaf_val = mem.alloc<float>(G);
-        d.slot_of = mem.alloc<int32_t>(G);
         d.err = mem.alloc<uint32_t>(ERR_COUNT);
-        d.stat = mem.alloc<uint64_t>((size_t)G * ST_COUNT);
         d.log_cap = log_cap;
-        d.log_len = mem.alloc<uint32_t>(G);
         d.log_state = mem.alloc<ulonglong2>((size_t)G * std::max(log_cap, 0));
         d.log_pi = mem.alloc<float>((size_t)G * std::max(log_cap, 0) * 7);
         d.log_v = mem.alloc<float>((size_t)G * std::max(log_cap, 0));
+        d_totals = mem.alloc<unsigned long long>(ST_COUNT);
+        d_counts = mem.alloc<uint32_t>(G);
         HIPCHK(hipMemset(d.err, 0, ERR_COUNT * sizeof(uint32_t)));
-        HIPCHK(hipMemset(d.stat, 0, (size_t)G * ST_COUNT * sizeof(uint64_t)));
-        HIPCHK(hipMemset(d.log_len, 0, G * sizeof(uint32_t)));
-        HIPCHK(hipMemset(d.active, 1, G));
-        HIPCHK(hipMemset(d.leaf_kind, 0, G * sizeof(uint32_t)));
+        HIPCHK(hipMemset(d_totals, 0, ST_COUNT * sizeof(unsigned long long)));
+        launch_init_heads(d, nullptr);
+        HIPCHK(hipDeviceSynchronize());
         for (EvalBatch* b : {&eb, &eb2}) {
             b->cap = G;
             b->n = mem.alloc<uint32_t>(1);
-            b->tree = mem.alloc<uint32_t>(G);
             b->state = mem.alloc<ulonglong2>(G);
             b->pi = mem.alloc<float>((size_t)G * 8);
             b->v = mem.alloc<float>(G);
             HIPCHK(hipMemset(b->n, 0, sizeof(uint32_t)));
-            // de-duplication arrays (used when the engine's "eval_dedup" applies to the net of a search)
-            b->src = mem.alloc<uint32_t>(G);
-            b->un = mem.alloc<uint32_t>(1);
-            b->ustate = mem.alloc<ulonglong2>(G);
-            b->upi = mem.alloc<float>((size_t)G * 8);
-            b->uv = mem.alloc<float>(G);
+            // election table of the leaf de-duplication (used when the engine's "eval_dedup" applies to a search's net)
             const uint32_t tsize = next_pow2_u32(4ull * (uint64_t)std::max(G, 16));
             b->tkey = mem.alloc<unsigned long long>(tsize);
             b->tuniq = mem.alloc<uint32_t>(tsize);
             b->tmask = tsize - 1;
-            HIPCHK(hipMemset(b->un, 0, sizeof(uint32_t)));
             HIPCHK(hipMemset(b->tkey, 0, (size_t)tsize * 8));
         }
     }
@@ -158,6 +139,11 @@ uint32_t next_pow2(uint64_t x) {
 // per call one fresh root (S10) and num_sims expansions, 7 placeholders each.
 uint64_t reachable_slots(int num_sims, int calls) {
     return 8ull + (uint64_t)calls * ((uint64_t)num_sims * 7ull + 8ull);
+}
+// child blocks the same tree can use: two for the initial root, per call two for a fresh root (S10) and one per expansion;
+// never more than one per pushed node
+uint64_t reachable_blocks(int num_sims, int calls, uint64_t reserve_nodes) {
+    return std::min<uint64_t>(2ull + (uint64_t)calls * ((uint64_t)num_sims + 2ull), std::max<uint64_t>(reserve_nodes, 2ull) + 1ull);
 }
 uint32_t hash_entries(int num_sims, int calls) {
     return next_pow2(2ull * ((uint64_t)calls * ((uint64_t)num_sims + 1) + 2));
@@ -299,21 +285,8 @@ void harvest_dedup(az_engine* e) {
     e->stats.eval_cache_inserts += h[DD_INSERTS];
 }
 
-// NNet::predict for the leaves of one simulation step: with de-duplication the net runs on the batch's unique rows
-void eval_batch(az_engine* e, TreeHost& th, const NetModel& net, const EvalBatch& eb, const EvalCache& ec, bool dedup, int rows_hint,
-                hipStream_t s) {
-    if (!dedup) { net_forward(e, net, eb, rows_hint, s); return; }
-    if (++th.dd_epoch > 0x7FFFu) {          // 15-bit epoch wrapped: stale keys could look current again
-        HIPCHK(hipMemsetAsync(th.eb.tkey, 0, ((size_t)th.eb.tmask + 1) * 8, s));
-        HIPCHK(hipMemsetAsync(th.eb2.tkey, 0, ((size_t)th.eb2.tmask + 1) * 8, s));
-        th.dd_epoch = 1;
-    }
-    launch_dedup(eb, ec, th.dd_epoch, s);
-    net_forward(e, net, TreeHost::unique_view(eb), rows_hint, s);
-}
-
 // get_action_prob body shared by every entry point: S10/S1 prologue, then num_sims x
-// {select+expand, compact, predict, mask+store+backup}  (src/async_mcts.rs:81-82, :191-217).
+// {select+expand (+ leaf request), predict, mask+store+backup}  (src/async_mcts.rs:81-82, :191-217).
 // rows_hint = host-side upper bound on the leaf batch (trees still searching): sizes the net's grids and picks tiles
 void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int num_sims, SearchParams sp,
                 NetModel& net, int rows_hint, hipStream_t s = nullptr) {
@@ -321,25 +294,35 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
     const bool dedup = dedup_applies(e, net);
     const EvalCache ec = cache_for(e, net);
-    // without de-duplication the kernels must take the direct path: hide the batches' src arrays
-    EvalBatch b0 = th.eb, b1 = th.eb2;
-    if (!dedup) { b0.src = nullptr; b0.un = nullptr; b1.src = nullptr; b1.un = nullptr; }
+    // every launch that requests leaves gets its own election-table epoch (15 bits; stale keys could look current again
+    // after a wrap, so the tables are cleared then)
+    auto next_epoch = [&]() -> uint32_t {
+        if (++th.dd_epoch > 0x7FFFu) {
+            HIPCHK(hipMemsetAsync(th.eb.tkey, 0, ((size_t)th.eb.tmask + 1) * 8, s));
+            HIPCHK(hipMemsetAsync(th.eb2.tkey, 0, ((size_t)th.eb2.tmask + 1) * 8, s));
+            th.dd_epoch = 1;
+        }
+        return th.dd_epoch;
+    };
+    EvalBatch B[2] = {th.eb, th.eb2};
+    B[0].dedup = B[1].dedup = dedup ? 1 : 0;
     // root: prepare (its leaf goes to batch 0), predict; then num_sims x {backup of the previous leaf + select of the next
     // (one launch, the new leaf goes to the other batch), predict}; a last backup closes the search.
-    launch_root_prepare(th.d, b0, d_root_states, s);
-    eval_batch(e, th, net, b0, ec, dedup, rows_hint, s);
-    const EvalBatch* B[2] = {&b0, &b1};
+    B[0].epoch = next_epoch();
+    launch_root_prepare(th.d, B[0], ec, d_root_states, s);
+    net_forward(e, net, B[0], rows_hint, s);
     for (int i = 0; i < num_sims; ++i) {
         hipEvent_t t0 = nullptr;
         if (e->prof.on) t0 = e->prof.begin(s);
-        launch_backup_select(th.d, *B[i & 1], *B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
+        B[(i + 1) & 1].epoch = next_epoch();
+        launch_backup_select(th.d, B[i & 1], B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
         if (e->prof.on) { e->prof.end(t0, RG_TREE, s); t0 = e->prof.begin(s); }
-        eval_batch(e, th, net, *B[(i + 1) & 1], ec, dedup, rows_hint, s);
+        net_forward(e, net, B[(i + 1) & 1], rows_hint, s);
         if (e->prof.on) e->prof.end(t0, RG_NET, s);
     }
     hipEvent_t t0 = nullptr;
     if (e->prof.on) t0 = e->prof.begin(s);
-    launch_backup(th.d, *B[num_sims & 1], ec, 0, s);
+    launch_backup(th.d, B[num_sims & 1], ec, 0, s);
     if (e->prof.on) e->prof.end(t0, RG_TREE, s);
 }
 
@@ -351,28 +334,24 @@ void resolve_profile(az_engine* e) {
     for (NetWorkspace* w : e->ws) netws_resolve_profile(w, &e->netprof);
 }
 
-// fold the per-tree counters into the engine stats and clear them
+// fold the per-tree counters into the engine stats and clear them (k_harvest sums on the device)
 void harvest_stats(az_engine* e, TreeHost& th, const NetModel& net) {
     harvest_dedup(e);
     const bool dedup = dedup_applies(e, net);
-    std::vector<uint64_t> h((size_t)th.d.G * ST_COUNT);
-    HIPCHK(hipMemcpy(h.data(), th.d.stat, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(th.d.stat, 0, h.size() * sizeof(uint64_t)));
-    uint64_t sims = 0, depth = 0;
-    for (int g = 0; g < th.d.G; ++g) {
-        const uint64_t* st = &h[(size_t)g * ST_COUNT];
-        sims += st[ST_SIMS];
-        e->stats.expansions += st[ST_EXPANSIONS];
-        e->stats.leaf_evals += st[ST_LEAF_EVALS];
-        if (!dedup) { e->stats.leaf_rows_requested += st[ST_LEAF_EVALS]; e->stats.leaf_rows_executed += st[ST_LEAF_EVALS]; }
-        e->stats.link_hits += st[ST_LINK_HITS];
-        e->stats.terminal_hits += st[ST_TERMINAL_HITS];
-        depth += st[ST_DEPTH_SUM];
-    }
-    e->stats.simulations += sims;
-    e->stats.depth_sum += depth;
+    launch_harvest(th.d, th.d_totals, th.d_counts, e->stream);
+    unsigned long long h[ST_COUNT];
+    HIPCHK(hipMemcpyAsync(h, th.d_totals, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemsetAsync(th.d_totals, 0, sizeof h, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->stats.simulations += h[ST_SIMS];
+    e->stats.expansions += h[ST_EXPANSIONS];
+    e->stats.leaf_evals += h[ST_LEAF_EVALS];
+    if (!dedup) { e->stats.leaf_rows_requested += h[ST_LEAF_EVALS]; e->stats.leaf_rows_executed += h[ST_LEAF_EVALS]; }
+    e->stats.link_hits += h[ST_LINK_HITS];
+    e->stats.terminal_hits += h[ST_TERMINAL_HITS];
+    e->stats.depth_sum += h[ST_DEPTH_SUM];
     // algorithmic tree bytes per simulation, SURVEY.md 8(d): 128 per selection level + 356 per expansion
-    e->stats.tree_bytes += 128.0 * (double)depth + 356.0 * (double)sims;
+    e->stats.tree_bytes += 128.0 * (double)h[ST_DEPTH_SUM] + 356.0 * (double)h[ST_SIMS];
 }
 
 az_status check_tree_errors(az_engine* e, TreeHost& th) {
@@ -626,7 +605,6 @@ az_status az_net_predict_states(az_engine* e, int32_t model_id, const uint64_t* 
         EvalBatch eb{};
         eb.cap = chunk;
         eb.n = mem.alloc<uint32_t>(1);
-        eb.tree = mem.alloc<uint32_t>(chunk);
         eb.state = mem.alloc<ulonglong2>(chunk);
         eb.pi = mem.alloc<float>((size_t)chunk * 8);
         eb.v = mem.alloc<float>(chunk);
@@ -787,8 +765,8 @@ az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_
         std::unique_ptr<az_tree> t(new az_tree());
         t->e = e;
         t->num_sims = num_sims; t->max_depth = max_depth; t->model_id = model_id; t->cpuct = cpuct;
-        uint64_t R = std::min<uint64_t>(reserve, reachable_slots(num_sims, AZ_MAX_PLIES));
-        t->th.create(n_games, R, hash_entries(num_sims, AZ_MAX_PLIES), 0);
+        const uint64_t nodes = std::min<uint64_t>(reserve, reachable_slots(num_sims, AZ_MAX_PLIES));
+        t->th.create(n_games, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(num_sims, AZ_MAX_PLIES), 0);
         t->d_root_states = t->mem.alloc<ulonglong2>(n_games);
         t->d_pi = t->mem.alloc<float>((size_t)n_games * 7);
         t->d_counts = t->mem.alloc<uint16_t>((size_t)n_games * 7);
@@ -818,7 +796,8 @@ az_status az_tree_reset(az_tree* t, const uint64_t* root_states) {
             roots = t->d_root_states;
         }
         launch_reset_trees(t->th.d, nullptr, e->stream, roots);
-        HIPCHK(hipMemsetAsync(t->th.d.stat, 0, (size_t)t->th.d.G * ST_COUNT * sizeof(uint64_t), e->stream));
+        launch_harvest(t->th.d, t->th.d_totals, nullptr, e->stream);          // forget the old trees' counters
+        HIPCHK(hipMemsetAsync(t->th.d_totals, 0, ST_COUNT * sizeof(unsigned long long), e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
@@ -833,7 +812,8 @@ az_status az_tree_record_evals(az_tree* t, int32_t cap) {
         d.log_state = t->mem.alloc<ulonglong2>((size_t)d.G * cap);
         d.log_pi = t->mem.alloc<float>((size_t)d.G * cap * 7);
         d.log_v = t->mem.alloc<float>((size_t)d.G * cap);
-        HIPCHK(hipMemset(d.log_len, 0, d.G * sizeof(uint32_t)));
+        launch_reset_trees(d, nullptr, t->e->stream);      // the log starts with fresh trees (log_len = 0)
+        HIPCHK(hipStreamSynchronize(t->e->stream));
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(t->e, f); }
 }
@@ -844,7 +824,13 @@ az_status az_tree_get_evals(az_tree* t, int32_t* rec_count, uint64_t* states, fl
         HIPCHK(hipSetDevice(t->e->device));
         TreeDev& d = t->th.d;
         size_t n = (size_t)d.G * d.log_cap;
-        if (rec_count) HIPCHK(hipMemcpy(rec_count, d.log_len, d.G * sizeof(uint32_t), hipMemcpyDefault));
+        if (rec_count) {
+            std::vector<TreeHead> heads(d.G);
+            HIPCHK(hipMemcpy(heads.data(), d.head, (size_t)d.G * sizeof(TreeHead), hipMemcpyDeviceToHost));
+            std::vector<int32_t> cnt(d.G);
+            for (int g = 0; g < d.G; ++g) cnt[g] = (int32_t)heads[g].log_len;
+            HIPCHK(hipMemcpy(rec_count, cnt.data(), d.G * sizeof(int32_t), hipMemcpyDefault));
+        }
         if (states) HIPCHK(hipMemcpy(states, d.log_state, n * 16, hipMemcpyDefault));
         if (pis) HIPCHK(hipMemcpy(pis, d.log_pi, n * 7 * sizeof(float), hipMemcpyDefault));
         if (vs) HIPCHK(hipMemcpy(vs, d.log_v, n * sizeof(float), hipMemcpyDefault));
@@ -856,7 +842,11 @@ az_status az_tree_node_counts(az_tree* t, uint32_t* out) {
     if (!t || !out) return AZ_ERR_BAD_ARGUMENT;
     try {
         HIPCHK(hipSetDevice(t->e->device));
-        HIPCHK(hipMemcpy(out, t->th.d.len, t->th.d.G * sizeof(uint32_t), hipMemcpyDefault));
+        std::vector<TreeHead> heads(t->th.d.G);
+        HIPCHK(hipMemcpy(heads.data(), t->th.d.head, heads.size() * sizeof(TreeHead), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> cnt(heads.size());
+        for (size_t g = 0; g < heads.size(); ++g) cnt[g] = heads[g].count;
+        HIPCHK(hipMemcpy(out, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyDefault));
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(t->e, f); }
 }
@@ -876,7 +866,7 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
         TreeDev& d = t->th.d;
         const int G = d.G;
         HIPCHK(hipMemcpyAsync(t->d_root_states, states, (size_t)G * 16, hipMemcpyDefault, e->stream));
-        HIPCHK(hipMemsetAsync(d.active, 1, G, e->stream));
+        launch_set_active(d, 1u, e->stream);
         SearchParams sp{(uint32_t)t->max_depth, (float)t->cpuct};
         if (!e->eval_cache_persist) clear_cache(e, e->stream);
         run_search(e, t->th, t->d_root_states, t->num_sims, sp, *net, G);
@@ -914,8 +904,8 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         HIPCHK(hipSetDevice(e->device));
         hipStream_t s = e->stream;
         TreeHost th;
-        uint64_t R = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
-        th.create(C, R, hash_entries(p->num_sims, AZ_MAX_PLIES), p->record_evals);
+        const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
+        th.create(C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES), p->record_evals);
         DeviceMem mem;
         GamesDev gd{};
         gd.C = C;
@@ -1020,7 +1010,11 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
             e->sp_log_states.resize((size_t)n_games * cap * 2);
             e->sp_log_pi.resize((size_t)n_games * cap * 7);
             e->sp_log_v.resize((size_t)n_games * cap);
-            HIPCHK(hipMemcpy(e->sp_log_count.data(), th.d.log_len, n_games * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            {
+                std::vector<TreeHead> heads(n_games);
+                HIPCHK(hipMemcpy(heads.data(), th.d.head, (size_t)n_games * sizeof(TreeHead), hipMemcpyDeviceToHost));
+                for (int g = 0; g < n_games; ++g) e->sp_log_count[g] = (int32_t)heads[g].log_len;
+            }
             HIPCHK(hipMemcpy(e->sp_log_states.data(), th.d.log_state, e->sp_log_states.size() * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(e->sp_log_pi.data(), th.d.log_pi, e->sp_log_pi.size() * 4, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(e->sp_log_v.data(), th.d.log_v, e->sp_log_v.size() * 4, hipMemcpyDeviceToHost));
@@ -1071,10 +1065,10 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         // one tree PAIR per game (B8 repair): the reference shares one nmcts / one pmcts across all games
         // (src/coach.rs:333-354) and their u16 root counters would wrap at 65536 visits.
         const int calls = AZ_MAX_PLIES / 2 + 1;
-        const uint64_t R = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, calls));
+        const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, calls));
         TreeHost tn, to;
-        tn.create(G, R, hash_entries(p->num_sims, calls), 0);
-        to.create(G, R, hash_entries(p->num_sims, calls), 0);
+        tn.create(G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0);
+        to.create(G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0);
         DeviceMem mem;
         ArenaDev ad{};
         ad.G = G; ad.half = half; ad.first = first;

@@ -19,6 +19,8 @@
 
 namespace az {
 
+constexpr int ACTIONS = ConnectFour::ACTIONS;      // the net is Connect Four's NNet (connect_four_net.py): 7 policy outputs
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

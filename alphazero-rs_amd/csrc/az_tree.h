@@ -1,11 +1,21 @@
 // az_tree.h -- device-side layout of a batch of MCTS trees and the kernel launchers.
 //
-// One TreeDev = G independent NodeStores (src/node.rs:129-375) laid out
-// structure-of-arrays in HBM, G*R slots.  A game's slots are contiguous
-// ([g*R, (g+1)*R)) so the <=7 children of a node (allocated contiguously,
-// src/node.rs:313-317) are one coalesced access by the 8 lanes that serve a game.
+// One TreeDev = G independent NodeStores (src/node.rs:129-375), G*R node slots in HBM, a game's slots contiguous.
+//
+// Node record = 32 bytes (array of structures: everything a selection level needs from a node is one record):
+//     +0  u64 ctr         packed win counter 0xWWWWWWWW_NNNN_VVVV (src/node.rs:17)
+//     +8  u64 key         Game::pack(state) of an expanded node (NodeMutableState.s); 0 on a placeholder
+//     +16 u32 prior       f32 bits of the edge prior parent -> this slot (parent.mu.p[a], src/node.rs:354)
+//     +20 u32 meta        a | nchild << 3 | expanded | ecode << 7 | has_prior   (az_common.h)
+//     +24 u32 link        NONE, or the tree-local slot of the canonical node (NodeLink.1, src/node.rs:129)
+//     +28 u32 child_base  first slot of the child block
+// Children are pushed contiguously at expansion (src/node.rs:313-317) into a CHILD BLOCK of Game::GROUP (8) slots =
+// 256 bytes, 256-byte aligned: lane j of the 8 lanes that serve a game loads child j's record, so a selection level
+// costs one 32-byte record for the parent and exactly two 128-byte lines for its children (the separate rec / ctr /
+// state arrays this replaces cost four to six lines per level).  Per-tree search state is one 64-byte TreeHead.
 #pragma once
 #include "az_common.h"
+#include "az_game.h"
 
 namespace az {
 
@@ -13,71 +23,78 @@ enum StatIdx { ST_SIMS = 0, ST_EXPANSIONS, ST_LEAF_EVALS, ST_LINK_HITS, ST_TERMI
 enum ErrIdx { ERR_CAPACITY = 0, ERR_TERMINAL_ROOT = 1, ERR_PATH = 2, ERR_HASH_FULL = 3, ERR_COUNT = 4 };
 enum LeafKind { LEAF_NONE = 0, LEAF_VALUE = 1, LEAF_EVAL = 2 };
 
+constexpr int BLOCK_SLOTS = 8;         // slots of a child block (== Game::GROUP)
+
+// per-tree search state: one 64-byte line, read at the start and written at the end of every tree kernel
+struct TreeHead {
+    uint32_t len;        // bump pointer in slots (a multiple of BLOCK_SLOTS)
+    uint32_t count;      // NodeStore::len (src/node.rs:134, :372-374): nodes pushed (root + placeholders)
+    uint32_t root;       // root node of the current get_action_prob
+    uint32_t active;     // tree takes part in the current search
+    uint32_t leaf;       // node the simulation stopped on
+    uint32_t leaf_kind;  // LeafKind
+    float leaf_val;      // value when LEAF_VALUE
+    uint32_t src;        // where the leaf's (pi, v) comes from (SRC_*), LEAF_EVAL
+    uint32_t path_len;   // node_path (src/async_mcts.rs:229) entries in TreeDev.path
+    uint32_t log_len;    // eval-log records written
+    uint32_t stat[ST_COUNT];   // counters since the last harvest
+};
+static_assert(sizeof(TreeHead) == 64, "TreeHead is one 64-byte line");
+
 struct TreeDev {
-    int32_t G;           // trees
-    uint32_t R;          // slots per tree (reserve_space, src/node.rs:146)
-    uint32_t H;          // hash entries per tree (power of two)
-    // node store
-    uint4* rec;          // [G*R] {link, prior bits, meta, child_base}
-    uint64_t* ctr;       // [G*R] packed win counters (src/node.rs:17)
-    ulonglong2* state;   // [G*R] canonical state {mine, theirs} (NodeMutableState.s)
-    uint32_t* hash;      // [G*H] `seen`: open-addressing table of node indices (src/node.rs:135)
-    uint32_t* len;       // [G] bump pointer (NodeStore.len, src/node.rs:134)
-    // search state
-    uint32_t* root;      // [G] root node of the current get_action_prob
-    uint8_t* active;     // [G] tree takes part in the current search
-    uint32_t* path;      // [G*PATH_CAP] node_path (src/async_mcts.rs:229)
-    uint32_t* path_len;  // [G]
-    uint32_t* leaf;      // [G] node the simulation stopped on
-    uint32_t* leaf_kind; // [G] LeafKind
-    float* leaf_val;     // [G] value when LEAF_VALUE
-    int32_t* slot_of;    // [G] row of this tree's leaf in the eval batch (LEAF_EVAL)
-    // diagnostics
-    uint32_t* err;       // [ERR_COUNT]
-    uint64_t* stat;      // [G*ST_COUNT]
+    int32_t G;               // trees
+    uint32_t R;              // slots per tree (a multiple of BLOCK_SLOTS)
+    uint32_t H;              // hash entries per tree (power of two)
+    uint32_t reserve_nodes;  // reserve_space (src/node.rs:146): pushes beyond it are the reference's assert (src/node.rs:237)
+    uint4* node;             // [G*R*2] 32-byte records as two uint4: {ctr.lo, ctr.hi, key.lo, key.hi} {prior, meta, link, child_base}
+    uint32_t* hash;          // [G*H] `seen` (src/node.rs:135): open-addressing table of node slots, key = the node's own key word
+    TreeHead* head;          // [G]
+    uint32_t* path;          // [G*PATH_CAP]
+    uint32_t* err;           // [ERR_COUNT]
     // eval log (replay parity): raw (pi, v) of every NNet::predict row, per tree, in order
     int32_t log_cap;
-    uint32_t* log_len;      // [G]
-    ulonglong2* log_state;  // [G*log_cap]
-    float* log_pi;          // [G*log_cap*7]
-    float* log_v;           // [G*log_cap]
+    ulonglong2* log_state;   // [G*log_cap]
+    float* log_pi;           // [G*log_cap*7]
+    float* log_v;            // [G*log_cap]
 };
 
-// Compacted leaf batch handed to the net (src/async_mcts.rs:117-189 restated as lanes).
+// Leaf batch handed to the net (src/async_mcts.rs:117-189 restated as lanes): the DISTINCT states the trees of one
+// simulation step need evaluated.  A tree whose leaf goes to the net either takes the next row (one atomicAdd per wave of 8
+// trees) or -- with de-duplication -- finds that another tree already did, or that the engine's evaluation cache holds
+// the state; its TreeHead.src says where its (pi, v) will be.  The row ORDER of a batch is scheduling-dependent, the results
+// are not: a row's (pi, v) depends on nothing but its state (tests/test_net_gpu.py).
 struct EvalBatch {
     int32_t cap;
     uint32_t* n;          // device: rows in this batch
-    uint32_t* tree;       // [cap] row -> tree index
     ulonglong2* state;    // [cap] canonical state to featurise (to_features, connect_four_game.rs:219-237)
-    float* pi;            // [cap*8] net output: pi[0..6], v repeated in slot 7
+    float* pi;            // [cap*8] net output: pi[0..6], v in slot 7
     float* v;             // [cap]
-    // ---- leaf de-duplication (src == nullptr: off, every requested row is evaluated) -------------------------------
-    // Thousands of games share their openings, and a row's (pi, v) depends on nothing but its state (BatchNorm is folded,
-    // every row's K-sum has one order), so evaluating a state once per batch -- or once per call, through the engine's
-    // evaluation cache -- is bit-exact.  The per-tree analogue in the reference is `seen` (src/node.rs:282-289).
-    // k_dedup gives every requested row r a source src[r]: a row u of the UNIQUE batch (ustate/upi/uv, *un rows: what the
-    // net really runs on), a slot of the batch's election table whose winner holds u, or an entry of the evaluation cache.
-    uint32_t* src;        // [cap] SRC_* tagged
-    uint32_t* un;         // device: unique rows of this batch
-    ulonglong2* ustate;   // [cap]
-    float* upi;           // [cap*8]
-    float* uv;            // [cap]
-    unsigned long long* tkey;   // [tmask+1] election table: (epoch << 49) | state key, stale epochs count as empty
-    uint32_t* tuniq;      // [tmask+1] unique row of the slot's winner
+    // ---- de-duplication (dedup == 0: every requesting tree takes its own row) --------------------------------------
+    // Thousands of games share their openings and a row's (pi, v) depends on its state alone (BatchNorm is folded, every
+    // row's K-sum has one order), so evaluating a state once per batch -- or once per call, through the engine's evaluation
+    // cache -- is bit-exact.  The per-tree analogue in the reference is `seen` (src/node.rs:282-289).
+    // Election table (open addressing, linear probe): the first tree to CAS its state key in takes a row; later trees with
+    // the same key point at the winner's slot.  A slot whose epoch is not this launch's counts as empty, so the table is
+    // never cleared between launches (the host clears it when the 15-bit epoch wraps).
+    int32_t dedup;
+    uint32_t epoch;             // [1, 32767]
+    unsigned long long* tkey;   // [tmask+1] (epoch << 49) | state key
+    uint32_t* tuniq;            // [tmask+1] row of the slot's winner
     uint32_t tmask;
 };
 constexpr uint32_t SRC_TABLE = 0x80000000u, SRC_CACHE = 0x40000000u, SRC_INDEX = 0x3FFFFFFFu;
 
 // Evaluation cache of the engine: state key (49 bits) | model tag (15 bits) -> (pi[7], v), 8-way buckets of one 64-byte key
-// line.  Filled by the trees whose row was evaluated (in the backup kernels), read by k_dedup (a later kernel on the same
-// stream), never evicted; entries of a model die with its tag (a new tag per weight upload).  key == nullptr: off.
+// line.  Filled by the trees whose row was evaluated (in the backup kernels), looked up when a leaf is requested, never
+// evicted; entries of a model die with its tag (a new tag per weight upload).  key == nullptr: off.
+// A key can become visible to a lookup of the SAME launch that publishes it; its payload is read one launch later.
 struct EvalCache {
     unsigned long long* key;   // [(bmask+1)*8], 0 = empty
     float* pv;                 // [(bmask+1)*8][8]
     uint32_t bmask;            // buckets - 1
     uint32_t max_stones;       // only states with at most this many stones are inserted
     unsigned long long tag;    // model tag, already shifted to bits 49..63
-    unsigned long long* stat;  // [DD_COUNT] requested / executed / cache hits / in-batch duplicates / inserts
+    unsigned long long* stat;  // [DD_COUNT]
 };
 enum DedupStat { DD_REQUESTED = 0, DD_EXECUTED, DD_CACHE_HITS, DD_BATCH_DUPS, DD_INSERTS, DD_COUNT };
 
@@ -125,19 +142,20 @@ struct ArenaDev {
     uint32_t* counters;    // [0] games still running, [1] invalid-move flag (src/arena.rs:31-35)
 };
 
-// ---- launchers (all asynchronous on `s`) --------------------------------------
+// ---- launchers (all asynchronous on `s`; instantiated for ConnectFour, the reference's one Game) -------------------
+void launch_init_heads(const TreeDev& t, hipStream_t s);                      // zero every TreeHead, active = 1
+void launch_set_active(const TreeDev& t, uint32_t value, hipStream_t s);
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s,
                         const ulonglong2* roots = nullptr /*[G] root states, nullptr = initial board*/);
-void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const ulonglong2* root_states, hipStream_t s);
-void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipStream_t s);
+void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, const ulonglong2* root_states, hipStream_t s);
 void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s);
-// backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf appended to eb_next) in one launch
+// backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf requested in eb_next) in one launch
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s);
-// rows [0, *eb.n) -> src[] + the unique batch (eb.src != nullptr); epoch in [1, 32767], the caller clears tkey when it wraps
-void launch_dedup(const EvalBatch& eb, const EvalCache& ec, uint32_t epoch, hipStream_t s);
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s);
+// sums the trees' counters into totals[ST_COUNT] (u64, accumulated) and clears them; node_counts [G] may be nullptr
+void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s);
 void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDev& ad, hipStream_t s);

@@ -1,10 +1,9 @@
-// az_tree.hip -- MCTS tree kernels for gfx950 (select / expand / compact / backup /
-// root policy / self-play move).  8 lanes serve one game: lane j evaluates child j
-// of the node being selected, so a node's <=7 contiguous child records are one
-// coalesced 16-byte-per-lane access and the PUCT arg-max is a 7-step in-register
-// fold over lane shuffles.  One simulation is in flight per tree (the reference's
-// deterministic mode, num_sim_threads = 1), so every counter update is a plain
-// read-modify-write by one lane: integer, order-free, bit-reproducible.
+// az_tree.hip -- MCTS tree kernels for gfx950 (select / expand / leaf request / backup / root policy / self-play move),
+// templates over the Game policy of az_game.h.  GROUP (8) lanes serve one game: lane j evaluates child j of the node
+// being selected, so a node's child block (8 x 32-byte records, 256-byte aligned) is two coalesced 128-byte lines and
+// the PUCT arg-max is an in-register fold over lane shuffles.  One simulation is in flight per tree (the reference's
+// deterministic mode, num_sim_threads = 1), so every counter update is a plain read-modify-write by one lane:
+// integer, order-free, bit-reproducible.
 //
 // Reference restated: src/async_mcts.rs:74-115, :219-371; src/node.rs:272-370;
 // src/coach.rs:104-157; with the repairs of SURVEY.md section 0.2 (tagged S#/B#).
@@ -12,18 +11,21 @@
 
 namespace az {
 
-// ---- 8-lane group primitives -----------------------------------------------------
-AZ_D uint32_t gshfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, LANES); }
-AZ_D float gshflf(float v, int src) { return __shfl(v, src, LANES); }
-AZ_D uint32_t gballot(bool p) {
+// ---- lane-group primitives (GW = Game::GROUP lanes per tree) ------------------------------------------------------
+template <int GW> AZ_D uint32_t gshfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, GW); }
+template <int GW> AZ_D float gshflf(float v, int src) { return __shfl(v, src, GW); }
+template <int GW> AZ_D uint64_t gshfl64(uint64_t v, int src) {
+    return ((uint64_t)gshfl<GW>((uint32_t)(v >> 32), src) << 32) | gshfl<GW>((uint32_t)v, src);
+}
+template <int GW> AZ_D uint32_t gballot(bool p) {
     unsigned long long m = __ballot(p);
     int lane = threadIdx.x & 63;
-    return (uint32_t)(m >> (lane & ~(LANES - 1))) & 0xFFu;
+    return (uint32_t)(m >> (lane & ~(GW - 1))) & ((1u << GW) - 1u);
 }
-AZ_D uint32_t nth_set_bit(uint32_t mask, uint32_t n) {
+template <int NA> AZ_D uint32_t nth_set_bit(uint32_t mask, uint32_t n) {
     uint32_t a = 0;
 #pragma unroll
-    for (int c = 0; c < ACTIONS; ++c) {
+    for (int c = 0; c < NA; ++c) {
         bool set = (mask >> c) & 1u;
         if (set && n == 0) a = (uint32_t)c;
         if (set) --n;
@@ -31,27 +33,47 @@ AZ_D uint32_t nth_set_bit(uint32_t mask, uint32_t n) {
     return a;
 }
 
-// `seen.get(&s)` (src/node.rs:282): 8-wide linear probe.  found = node index or NONE;
+// ---- node record access (layout: az_tree.h) ---------------------------------------------------------------------------
+struct NodeRec {
+    uint64_t ctr, key;
+    uint32_t prior, meta, link, child_base;
+};
+AZ_D uint4* node_ptr(const TreeDev& t, size_t base, uint32_t slot) { return t.node + (base + slot) * 2; }
+AZ_D NodeRec node_load(const uint4* p) {
+    const uint4 a = p[0], b = p[1];
+    return NodeRec{((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, b.x, b.y, b.z, b.w};
+}
+AZ_D void node_store(uint4* p, uint64_t ctr, uint64_t key, uint32_t prior, uint32_t meta, uint32_t link, uint32_t child_base) {
+    p[0] = make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)key, (uint32_t)(key >> 32));
+    p[1] = make_uint4(prior, meta, link, child_base);
+}
+AZ_D uint64_t node_ctr(const uint4* p) { return *(const unsigned long long*)p; }
+AZ_D void node_set_ctr(uint4* p, uint64_t v) { *(unsigned long long*)p = v; }
+AZ_D uint64_t node_key(const uint4* p) { return ((const unsigned long long*)p)[1]; }
+AZ_D void node_set_prior(uint4* p, uint32_t bits) { ((uint32_t*)p)[4] = bits; }
+AZ_D void node_set_meta(uint4* p, uint32_t meta) { ((uint32_t*)p)[5] = meta; }
+AZ_D void node_set_link(uint4* p, uint32_t link) { ((uint32_t*)p)[6] = link; }
+
+// `seen.get(&s)` (src/node.rs:282): GW-wide linear probe.  found = node slot or NONE;
 // ins = first empty position (where `seen.insert` will go, src/node.rs:320).
-AZ_D void hash_find(const TreeDev& t, int g, size_t base, uint64_t m, uint64_t th, int sub, uint32_t* found,
-                    uint32_t* ins) {
+template <class G>
+AZ_D void hash_find(const TreeDev& t, int g, size_t base, typename G::State s, int sub, uint32_t* found, uint32_t* ins) {
+    constexpr int GW = G::GROUP;
     const uint32_t mask = t.H - 1;
-    const uint32_t h = c4_hash(m, th) & mask;
+    const uint32_t h = G::hash(s) & mask;
+    const uint64_t key = G::pack(s);
     const uint32_t* tab = t.hash + (size_t)g * t.H;
-    for (uint32_t probe = 0; probe < t.H; probe += LANES) {
+    for (uint32_t probe = 0; probe < t.H; probe += GW) {
         uint32_t pos = (h + probe + (uint32_t)sub) & mask;
         uint32_t idx = tab[pos];
         bool empty = idx == NONE;
         bool match = false;
-        if (!empty) {
-            ulonglong2 s = t.state[base + idx];
-            match = s.x == m && s.y == th;
-        }
-        uint32_t em = gballot(empty), mm = gballot(match);
-        int fe = em ? (__ffs((int)em) - 1) : LANES;
+        if (!empty) match = node_key(node_ptr(t, base, idx)) == key;
+        uint32_t em = gballot<GW>(empty), mm = gballot<GW>(match);
+        int fe = em ? (__ffs((int)em) - 1) : GW;
         uint32_t before = mm & ((1u << fe) - 1u);
         if (before) {
-            *found = gshfl(idx, __ffs((int)before) - 1);
+            *found = gshfl<GW>(idx, __ffs((int)before) - 1);
             *ins = NONE;
             return;
         }
@@ -65,176 +87,258 @@ AZ_D void hash_find(const TreeDev& t, int g, size_t base, uint64_t m, uint64_t t
     *ins = NONE;
 }
 
-// NodeStore::upgrade, `None` arm (src/node.rs:290-323): store s, e = -ended(s), push one
-// placeholder per valid move in ascending action order, insert into `seen`.
-// cbase = current bump pointer (children go to [cbase, cbase+nv)).  Returns false when the
-// arena is exhausted (assert!, src/node.rs:237).
-AZ_D bool node_upgrade(const TreeDev& t, int g, size_t base, uint32_t slot, uint64_t m, uint64_t th,
-                       uint32_t prior_bits, uint32_t a, uint32_t ins_pos, uint64_t ctr_value, uint32_t cbase, int sub,
-                       uint32_t* ecode_out) {
-    uint32_t ec = c4_ecode(m, th);
-    uint32_t vm = ec ? 0u : c4_valid_mask(m, th);
+// NodeStore::upgrade, `None` arm (src/node.rs:290-323): store s, e = -ended(s), push one placeholder per valid move in
+// ascending action order into a fresh child block, insert into `seen`.  extra = nodes pushed besides the placeholders
+// (1 when the upgraded node itself is new: a root).  Returns false when the arena is exhausted (assert!, src/node.rs:237).
+template <class G>
+AZ_D bool node_upgrade(const TreeDev& t, TreeHead& h, int g, size_t base, uint32_t slot, typename G::State s, uint32_t prior_bits,
+                       uint32_t a, uint32_t ins_pos, uint64_t ctr_value, uint32_t cbase, uint32_t extra, int sub, uint32_t* ecode_out) {
+    uint32_t ec = G::ended_code(s);
+    uint32_t vm = ec ? 0u : G::valid_mask(s);
     uint32_t nv = (uint32_t)__popc(vm);
-    if (cbase + nv > t.R || ins_pos == NONE) {
+    if (cbase + BLOCK_SLOTS > t.R || h.count + extra + nv > t.reserve_nodes || ins_pos == NONE) {
         if (sub == 0) atomicOr(&t.err[ins_pos == NONE ? ERR_HASH_FULL : ERR_CAPACITY], 1u);
         return false;
     }
+    h.len = cbase + BLOCK_SLOTS;
+    h.count += extra + nv;
     if (sub == 0) {
-        t.len[g] = cbase + nv;
-        t.state[base + slot] = make_ulonglong2(m, th);
-        t.rec[base + slot] =
-            make_uint4(NONE, prior_bits, a | (nv << META_NCHILD_SHIFT) | META_EXPANDED | (ec << META_ECODE_SHIFT), cbase);
-        t.ctr[base + slot] = ctr_value;
+        node_store(node_ptr(t, base, slot), ctr_value, G::pack(s), prior_bits,
+                   a | (nv << META_NCHILD_SHIFT) | META_EXPANDED | (ec << META_ECODE_SHIFT), NONE, cbase);
         t.hash[(size_t)g * t.H + ins_pos] = slot;
     }
-    if ((uint32_t)sub < nv) {
-        t.rec[base + cbase + sub] = make_uint4(NONE, 0u, nth_set_bit(vm, (uint32_t)sub), 0u);
-        t.ctr[base + cbase + sub] = CTR_INIT;
-    }
+    if ((uint32_t)sub < nv)
+        node_store(node_ptr(t, base, cbase + sub), CTR_INIT, 0ull, 0u, nth_set_bit<G::ACTIONS>(vm, (uint32_t)sub), NONE, 0u);
     *ecode_out = ec;
     return true;
 }
 
+AZ_D TreeHead head_load(const TreeDev& t, int g) {
+    const uint4* p = (const uint4*)(t.head + g);
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    TreeHead h;
+    h.len = a.x; h.count = a.y; h.root = a.z; h.active = a.w;
+    h.leaf = b.x; h.leaf_kind = b.y; h.leaf_val = __uint_as_float(b.z); h.src = b.w;
+    h.path_len = c.x; h.log_len = c.y; h.stat[0] = c.z; h.stat[1] = c.w;
+    h.stat[2] = d.x; h.stat[3] = d.y; h.stat[4] = d.z; h.stat[5] = d.w;
+    return h;
+}
+AZ_D void head_store(const TreeDev& t, int g, const TreeHead& h) {
+    uint4* p = (uint4*)(t.head + g);
+    p[0] = make_uint4(h.len, h.count, h.root, h.active);
+    p[1] = make_uint4(h.leaf, h.leaf_kind, __float_as_uint(h.leaf_val), h.src);
+    p[2] = make_uint4(h.path_len, h.log_len, h.stat[0], h.stat[1]);
+    p[3] = make_uint4(h.stat[2], h.stat[3], h.stat[4], h.stat[5]);
+}
+
+__global__ void k_init_heads(TreeDev t) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= t.G) return;
+    TreeHead h{};
+    h.active = 1;
+    head_store(t, g, h);
+}
+__global__ void k_set_active(TreeDev t, uint32_t value) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < t.G) t.head[g].active = value;
+}
+
 // ---- NodeStore::new (src/node.rs:156-166): clear `seen`, push + upgrade the initial board ----
+template <class G>
 __global__ __launch_bounds__(256) void k_reset_trees(TreeDev t, const uint8_t* flags, uint8_t* clear_flags,
                                                      const ulonglong2* roots /*nullptr = initial board*/) {
+    constexpr int GW = G::GROUP;
     int g = blockIdx.x;
     if (flags && !flags[g]) return;
     uint32_t* tab = t.hash + (size_t)g * t.H;
     for (uint32_t i = threadIdx.x; i < t.H; i += blockDim.x) tab[i] = NONE;
     __syncthreads();
-    if (threadIdx.x < LANES) {
+    if (threadIdx.x < GW) {
         int sub = threadIdx.x;
         size_t base = (size_t)g * t.R;
+        TreeHead h = head_load(t, g);
+        h.len = 0;
+        h.count = 0;
         uint32_t ec;
-        const ulonglong2 rs = roots ? roots[g] : make_ulonglong2(0ull, 0ull);     // NodeStore::from_root, src/node.rs:168-177
-        uint32_t ins = c4_hash(rs.x, rs.y) & (t.H - 1);
-        node_upgrade(t, g, base, 0u, rs.x, rs.y, 0u, 0u, ins, CTR_INIT, 1u, sub, &ec);
+        const typename G::State rs = roots ? roots[g] : G::init();          // NodeStore::from_root, src/node.rs:168-177
+        uint32_t ins = G::hash(rs) & (t.H - 1);
+        // the root takes slot 0 of block 0, its children block 1
+        node_upgrade<G>(t, h, g, base, 0u, rs, 0u, 0u, ins, CTR_INIT, BLOCK_SLOTS, 1u, sub, &ec);
+        h.root = 0;
+        h.log_len = 0;
+        h.leaf_kind = LEAF_NONE;
         if (sub == 0) {
-            t.root[g] = 0;
-            t.log_len[g] = 0;
+            head_store(t, g, h);
             if (clear_flags) clear_flags[g] = 0;
         }
     }
 }
 
-// ---- inference batch assembly (src/async_mcts.rs:137-151 restated) -------------------------------------------------
-// A tree whose leaf goes to the net takes the next row of the eval batch: one atomicAdd per wave (8 trees), rows in lane
-// order inside the wave.  The row ORDER of a batch therefore depends on which wave's atomic lands first; the results do
-// not, because a row's (pi, v) is independent of its position and of the batch's composition (tests/test_net_gpu.py,
-// test_net_rows_are_batch_independent) and every tree finds its own row through slot_of.  k_backup resets the counter.
-// (A separate single-block compaction kernel with rows in tree order cost 15.6 us per simulation step: 25 % of the
-// tree-only time, 1.3 % with the conv net.)
-AZ_D void batch_append(const TreeDev& t, const EvalBatch& eb, int g, bool want, uint64_t m_, uint64_t t_) {
+// ---- leaf request: inference batch assembly (src/async_mcts.rs:137-151 restated) + de-duplication ---------------------
+// A tree whose leaf goes to the net (want) gets a SOURCE for its (pi, v):
+//   1. the evaluation cache: the state's bucket is one 64-byte line of 8 keys, lane j checks way j;
+//   2. the batch's election table: the first tree to CAS its key in wins a row, later ones point at the winner's slot;
+//   3. a row of the batch: one atomicAdd per wave (8 trees), rows in lane order inside the wave.
+// Without de-duplication every requesting tree goes straight to 3.  All lanes of the wave that are still alive call
+// this together (the ballots are wave-wide); lanes of trees with nothing to evaluate pass want = false.
+template <class G>
+AZ_D uint32_t leaf_request(const EvalBatch& eb, const EvalCache& ec, bool want, typename G::State s, int sub) {
+    constexpr int GW = G::GROUP;
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long mask = __ballot(want);
-    if (!mask) return;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(eb.n, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (want) {
-        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        t.slot_of[g] = (int32_t)slot;
-        eb.tree[slot] = (uint32_t)g;
-        eb.state[slot] = make_ulonglong2(m_, t_);
+    uint32_t src = 0;
+    bool hit = false, dup = false, take = want;
+    uint32_t tpos = 0;
+    if (eb.dedup) {
+        const unsigned long long key = (unsigned long long)G::pack(s);
+        if (ec.key) {
+            const unsigned long long ck = key | ec.tag;
+            const uint32_t bucket = (uint32_t)(mix64(ck) >> 20) & ec.bmask;
+            const uint32_t ways = gballot<GW>(want && ec.key[(size_t)bucket * 8 + sub] == ck);
+            if (want && ways) { hit = true; take = false; src = SRC_CACHE | (bucket * 8u + (uint32_t)__ffs((int)ways) - 1u); }
+        }
+        if (take && sub == 0) {
+            const unsigned long long mine = key | ((unsigned long long)eb.epoch << 49);
+            uint32_t pos = (uint32_t)(mix64(key) >> 24) & eb.tmask;
+            for (;;) {
+                unsigned long long cur = eb.tkey[pos];
+                if ((cur >> 49) != (unsigned long long)eb.epoch) {          // empty or stale: try to take it
+                    const unsigned long long prev = atomicCAS(&eb.tkey[pos], cur, mine);
+                    if (prev == cur) break;                                // won the slot
+                    cur = prev;                                            // somebody else took it first
+                    if ((cur >> 49) != (unsigned long long)eb.epoch) continue;
+                }
+                if (cur == mine) { dup = true; break; }
+                pos = (pos + 1u) & eb.tmask;
+            }
+            tpos = pos;
+        }
+        dup = gshfl<GW>(dup ? 1u : 0u, 0) != 0u;
+        tpos = gshfl<GW>(tpos, 0);
+        if (take && dup) { take = false; src = SRC_TABLE | tpos; }
     }
+    // rows of the batch: one atomicAdd per wave
+    const unsigned long long wm = __ballot(take && sub == 0);
+    if (wm) {
+        const int leader = __ffsll((long long)wm) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(eb.n, (uint32_t)__popcll(wm));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (take) {
+            const int lane0 = lane & ~(GW - 1);
+            const uint32_t row = base + (uint32_t)__popcll(wm & ((1ull << lane0) - 1ull));
+            if (sub == 0) {
+                eb.state[row] = s;
+                if (eb.dedup) eb.tuniq[tpos] = row;
+            }
+            src = row;
+        }
+    }
+    if (ec.stat && eb.dedup) {
+        const unsigned long long am = __ballot(want && sub == 0), hm = __ballot(hit && sub == 0), dm = __ballot(dup && want && sub == 0);
+        if (am && lane == __ffsll((long long)am) - 1) {
+            atomicAdd(&ec.stat[DD_REQUESTED], (unsigned long long)__popcll(am));
+            if (wm) atomicAdd(&ec.stat[DD_EXECUTED], (unsigned long long)__popcll(wm));
+            if (hm) atomicAdd(&ec.stat[DD_CACHE_HITS], (unsigned long long)__popcll(hm));
+            if (dm) atomicAdd(&ec.stat[DD_BATCH_DUPS], (unsigned long long)__popcll(dm));
+        }
+    }
+    return src;
 }
 
 // ---- get_action_prob prologue: root lookup (src/async_mcts.rs:81) + S10 + S1 -------------
-__global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, const ulonglong2* root_states) {
+template <class G>
+__global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, EvalCache ec, const ulonglong2* root_states) {
+    constexpr int GW = G::GROUP;
     int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid >> 3, sub = tid & 7;
+    int g = tid / GW, sub = tid % GW;
     if (g >= t.G) return;
-    if (!t.active[g]) {
-        if (sub == 0) t.leaf_kind[g] = LEAF_NONE;
-        return;
-    }
+    TreeHead h = head_load(t, g);
+    const bool act = h.active != 0;
     size_t base = (size_t)g * t.R;
-    ulonglong2 s = root_states[g];
-    uint32_t found, ins;
-    hash_find(t, g, base, s.x, s.y, sub, &found, &ins);
+    typename G::State s = act ? root_states[g] : G::init();
     uint32_t kind = LEAF_NONE;
-    uint32_t root = found;
-    uint32_t n_exp = 0;
-    if (found == NONE) {
-        // S10 (A11): unseen root -> push + upgrade a fresh node, as NodeStore::from_root (src/node.rs:168-177)
-        uint32_t idx = t.len[g];
-        uint32_t ec;
-        if (idx + 1 > t.R) {
-            if (sub == 0) atomicOr(&t.err[ERR_CAPACITY], 1u);
-        } else if (node_upgrade(t, g, base, idx, s.x, s.y, 0u, 0u, ins, CTR_INIT, idx + 1, sub, &ec)) {
-            root = idx;
-            n_exp = 1;
+    if (act) {
+        uint32_t found, ins;
+        hash_find<G>(t, g, base, s, sub, &found, &ins);
+        uint32_t root = found;
+        uint32_t n_exp = 0;
+        if (found == NONE) {
+            // S10 (A11): unseen root -> push + upgrade a fresh node, as NodeStore::from_root (src/node.rs:168-177):
+            // the root takes slot 0 of a new block, its children the next block
+            uint32_t idx = h.len;
+            uint32_t ec_;
+            if (idx + BLOCK_SLOTS > t.R) {
+                if (sub == 0) atomicOr(&t.err[ERR_CAPACITY], 1u);
+            } else if (node_upgrade<G>(t, h, g, base, idx, s, 0u, 0u, ins, CTR_INIT, idx + BLOCK_SLOTS, 1u, sub, &ec_)) {
+                root = idx;
+                n_exp = 1;
+            }
         }
-    }
-    if (root != NONE) {
-        uint32_t meta = (found == NONE) ? 0u : t.rec[base + root].z;
-        uint32_t ec = (found == NONE) ? c4_ecode(s.x, s.y) : ((meta >> META_ECODE_SHIFT) & 3u);
-        if (ec != E_NONE) {
-            // terminal root: the reference panics at root.mu.p.unwrap() (src/async_mcts.rs:85)
-            if (sub == 0) atomicOr(&t.err[ERR_TERMINAL_ROOT], 1u);
-        } else if (!(meta & META_HAS_PRIOR)) {
-            kind = LEAF_EVAL;  // S1 (A1): evaluate the root once so best_child has a prior
+        if (root != NONE) {
+            uint32_t meta = (found == NONE) ? 0u : node_load(node_ptr(t, base, root)).meta;
+            uint32_t ec_ = (found == NONE) ? G::ended_code(s) : ((meta >> META_ECODE_SHIFT) & 3u);
+            if (ec_ != E_NONE) {
+                // terminal root: the reference panics at root.mu.p.unwrap() (src/async_mcts.rs:85)
+                if (sub == 0) atomicOr(&t.err[ERR_TERMINAL_ROOT], 1u);
+            } else if (!(meta & META_HAS_PRIOR)) {
+                kind = LEAF_EVAL;  // S1 (A1): evaluate the root once so best_child has a prior
+            }
         }
+        h.root = (root == NONE) ? 0u : root;
+        h.leaf = h.root;
+        h.path_len = 0;
+        if (root == NONE) h.active = 0;       // a failed root deactivates the tree for this search
+        h.stat[ST_EXPANSIONS] += n_exp;
     }
-    if (sub == 0) {
-        t.root[g] = (root == NONE) ? 0u : root;
-        t.leaf[g] = (root == NONE) ? 0u : root;
-        t.leaf_kind[g] = kind;
-        t.path_len[g] = 0;
-        if (root == NONE || kind == LEAF_NONE) {
-            // nothing to evaluate; a failed root also deactivates the tree for this search
-            if (root == NONE) t.active[g] = 0;
-        }
-        t.stat[(size_t)g * ST_COUNT + ST_EXPANSIONS] += n_exp;
-    }
-    batch_append(t, eb, g, sub == 0 && kind == LEAF_EVAL, s.x, s.y);
+    h.leaf_kind = kind;
+    const uint32_t src = leaf_request<G>(eb, ec, kind == LEAF_EVAL, s, sub);
+    if (kind == LEAF_EVAL) h.src = src;
+    if (sub == 0) head_store(t, g, h);
 }
 
 // ---- search_iteration: select + expand (src/async_mcts.rs:226-299, Appendix A of SURVEY.md) ----
-AZ_D void select_body(const TreeDev& t, const EvalBatch& eb, const SearchParams& sp, int g, int sub) {
-    if (!t.active[g]) {
-        if (sub == 0) t.leaf_kind[g] = LEAF_NONE;
-        return;
-    }
+template <class G>
+AZ_D void select_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const EvalCache& ec, const SearchParams& sp, int g, int sub) {
+    constexpr int GW = G::GROUP;
+    constexpr int NA = G::ACTIONS;
+    const bool act = h.active != 0;
     const size_t base = (size_t)g * t.R;
     uint32_t* path = t.path + (size_t)g * PATH_CAP;
-    const uint32_t len_g = t.len[g];
-    uint32_t cur = t.root[g];
+    uint32_t cur = h.root;
     uint32_t depth = 0, plen = 0, kind = LEAF_NONE;
     float val = 0.0f;
     uint32_t n_exp = 0, n_link = 0, n_term = 0, n_depth = 0;
-    uint64_t leaf_m = 0, leaf_t = 0;
-    for (;;) {
-        uint4 pr = t.rec[base + cur];
-        uint64_t pc = t.ctr[base + cur] + CTR_VISIT;            // visit(), src/node.rs:77-80; S5: before the checks
-        if (sub == 0) t.ctr[base + cur] = pc;
-        uint32_t ec = (pr.z >> META_ECODE_SHIFT) & 3u;
+    typename G::State leaf_s = G::init();
+    while (act) {
+        uint4* pp = node_ptr(t, base, cur);
+        const NodeRec pr = node_load(pp);
+        const uint64_t pc = pr.ctr + CTR_VISIT;                 // visit(), src/node.rs:77-80; S5: before the checks
+        if (sub == 0) node_set_ctr(pp, pc);
+        const uint32_t ecd = (pr.meta >> META_ECODE_SHIFT) & 3u;
         if (depth > sp.max_depth) { val = 0.0f; kind = LEAF_VALUE; break; }   // src/async_mcts.rs:241-244 (B10)
-        if (ec != E_NONE) { val = ecode_value(ec); kind = LEAF_VALUE; ++n_term; break; }  // :246-249
+        if (ecd != E_NONE) { val = ecode_value(ecd); kind = LEAF_VALUE; ++n_term; break; }  // :246-249
         // best_child, src/node.rs:343-370
-        const uint32_t nchild = (pr.z >> META_NCHILD_SHIFT) & 7u, cb = pr.w;
+        const uint32_t nchild = (pr.meta >> META_NCHILD_SHIFT) & 7u, cb = pr.child_base;
         const float sq = puct_sqrt_parent(ctr_n(pc));
-        uint4 cr = make_uint4(NONE, 0u, 0u, 0u);
+        NodeRec cr{0ull, 0ull, 0u, 0u, NONE, 0u};
         float u = 0.0f;
         if ((uint32_t)sub < nchild) {
-            // the child's record and (speculatively) its own counter are fetched together; only a link slot needs
-            // the second, dependent fetch of the canonical node's counter (resolve(), src/node.rs:179-193)
-            cr = t.rec[base + cb + sub];
-            uint64_t cc = t.ctr[base + cb + sub];
-            if (cr.x != NONE) cc = t.ctr[base + cr.x];
-            u = puct(cc, __uint_as_float(cr.y), sq, sp.cpuct_f);
+            // the child's record carries its own counter; only a link slot needs the second, dependent fetch of the
+            // canonical node's counter (resolve(), src/node.rs:179-193)
+            cr = node_load(node_ptr(t, base, cb + sub));
+            uint64_t cc = cr.ctr;
+            if (cr.link != NONE) cc = node_ctr(node_ptr(t, base, cr.link));
+            u = puct(cc, __uint_as_float(cr.prior), sq, sp.cpuct_f);
         }
         uint32_t best = 0;
-        float bu = gshflf(u, 0);
+        float bu = gshflf<GW>(u, 0);
 #pragma unroll
-        for (int j = 1; j < ACTIONS; ++j) {                     // max_by: later element wins unless earlier is Greater (C7)
-            float uj = gshflf(u, j);
+        for (int j = 1; j < NA; ++j) {                          // max_by: later element wins unless earlier is Greater (C7)
+            float uj = gshflf<GW>(u, j);
             if ((uint32_t)j < nchild && !(bu > uj)) { best = (uint32_t)j; bu = uj; }
         }
         ++n_depth;
-        const uint32_t clink = gshfl(cr.x, (int)best), cmeta = gshfl(cr.z, (int)best), cprior = gshfl(cr.y, (int)best);
+        const uint32_t clink = gshfl<GW>(cr.link, (int)best), cmeta = gshfl<GW>(cr.meta, (int)best), cprior = gshfl<GW>(cr.prior, (int)best);
         const uint32_t cslot = cb + best;
         if (plen >= (uint32_t)PATH_CAP) {
             if (sub == 0) atomicOr(&t.err[ERR_PATH], 1u);
@@ -246,21 +350,18 @@ AZ_D void select_body(const TreeDev& t, const EvalBatch& eb, const SearchParams&
         if (clink != NONE) { cur = clink; ++depth; continue; }  // Exists(false): follow the link (S2: one level per iteration)
         if (cmeta & META_EXPANDED) { cur = cslot; ++depth; continue; }   // Exists(true)
         // PlaceHolder (:261-268, S3): expand it.  B1: play the child's own action.
-        ulonglong2 ps = t.state[base + cur];
-        uint64_t m2, t2;
-        c4_play(ps.x, ps.y, (int)(cmeta & META_A_MASK), &m2, &t2);       // :284-287 (B5)
+        const typename G::State s2 = G::play(G::unpack(pr.key), (int)(cmeta & META_A_MASK));       // :284-287 (B5)
         uint32_t found, ins;
-        hash_find(t, g, base, m2, t2, sub, &found, &ins);
+        hash_find<G>(t, g, base, s2, sub, &found, &ins);
         if (found != NONE) {                                    // upgrade -> Some(false): become a link (src/node.rs:285-289)
-            if (sub == 0) t.rec[base + cslot].x = found;
+            if (sub == 0) node_set_link(node_ptr(t, base, cslot), found);
             cur = found;
             ++n_link;
             continue;                                           // :297-298
         }
         uint32_t ec2;
         // the placeholder is visited right after the upgrade (:309): its counter becomes INIT + VISIT
-        if (!node_upgrade(t, g, base, cslot, m2, t2, cprior, cmeta & META_A_MASK, ins, CTR_INIT + CTR_VISIT, len_g, sub,
-                          &ec2)) {
+        if (!node_upgrade<G>(t, h, g, base, cslot, s2, cprior, cmeta & META_A_MASK, ins, CTR_INIT + CTR_VISIT, h.len, 0u, sub, &ec2)) {
             kind = LEAF_NONE;
             break;
         }
@@ -268,312 +369,285 @@ AZ_D void select_body(const TreeDev& t, const EvalBatch& eb, const SearchParams&
         cur = cslot;
         if (ec2 != E_NONE) { val = ecode_value(ec2); kind = LEAF_VALUE; break; }   // S4 (A5)
         kind = LEAF_EVAL;                                       // :303-315: goes to the net
-        leaf_m = m2;
-        leaf_t = t2;
+        leaf_s = s2;
         break;
     }
-    if (sub == 0) {
-        t.leaf[g] = cur;
-        t.leaf_kind[g] = kind;
-        t.leaf_val[g] = val;
-        t.path_len[g] = plen;
-        uint64_t* st = t.stat + (size_t)g * ST_COUNT;
-        st[ST_SIMS] += 1;
-        st[ST_EXPANSIONS] += n_exp;
-        st[ST_LINK_HITS] += n_link;
-        st[ST_TERMINAL_HITS] += n_term;
-        st[ST_DEPTH_SUM] += n_depth;
+    if (act) {
+        h.leaf = cur;
+        h.leaf_val = val;
+        h.path_len = plen;
+        h.stat[ST_SIMS] += 1;
+        h.stat[ST_EXPANSIONS] += n_exp;
+        h.stat[ST_LINK_HITS] += n_link;
+        h.stat[ST_TERMINAL_HITS] += n_term;
+        h.stat[ST_DEPTH_SUM] += n_depth;
     }
-    batch_append(t, eb, g, sub == 0 && kind == LEAF_EVAL, leaf_m, leaf_t);
+    h.leaf_kind = kind;
+    const uint32_t src = leaf_request<G>(eb, ec, kind == LEAF_EVAL, leaf_s, sub);
+    if (kind == LEAF_EVAL) h.src = src;
+}
+
+// `seen`-style sharing of evaluations across trees: a tree whose row was really evaluated publishes (pi, v) under its
+// state's key.  Bucket = one 64-byte line of 8 keys; lane j looks at way j, lane 0 claims the first empty way with a CAS
+// (another inserter may have taken it: try the next empty one), then lanes 0..7 write the 32-byte payload.
+template <class G>
+AZ_D void cache_insert(const EvalCache& ec, typename G::State s, float pv, int sub) {
+    constexpr int GW = G::GROUP;
+    bool inserted = false;
+    if (G::stones(s) <= ec.max_stones) {
+        const unsigned long long key = (unsigned long long)G::pack(s) | ec.tag;
+        const uint32_t bucket = (uint32_t)(mix64(key) >> 20) & ec.bmask;
+        unsigned long long* keys = ec.key + (size_t)bucket * 8;
+        uint32_t empties = gballot<GW>(keys[sub] == 0ull);
+        uint32_t way = NONE;
+        while (empties) {
+            const uint32_t w = (uint32_t)__ffs((int)empties) - 1u;
+            unsigned long long prev = 0ull;
+            if (sub == 0) prev = atomicCAS(&keys[w], 0ull, key);
+            prev = gshfl64<GW>(prev, 0);
+            if (prev == 0ull) { way = w; break; }
+            if (prev == key) break;                       // already published
+            empties &= empties - 1u;
+        }
+        if (way != NONE) {                                // (bucket full: not cached)
+            ec.pv[((size_t)bucket * 8 + way) * 8 + sub] = pv;
+            inserted = true;
+        }
+    }
+    const unsigned long long im = __ballot(inserted && sub == 0);
+    if (im && (int)(threadIdx.x & 63) == __ffsll((long long)im) - 1) atomicAdd(&ec.stat[DD_INSERTS], (unsigned long long)__popcll(im));
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
-// `seen`-style sharing of evaluations across trees: a tree whose row was really evaluated publishes (pi, v) under its
-// state's key.  Bucket = one 64-byte line of 8 keys; lane j looks at way j, lane 0 claims the first empty way with a CAS
-// (another inserter may have taken it: try the next empty one), then lanes 0..7 write the 32-byte payload.  Readers are
-// k_dedup launches LATER on the same stream, so a claimed key always has its payload by the time it can be matched.
-AZ_D void cache_insert(const EvalCache& ec, uint64_t m, uint64_t th, float pv, int sub) {
-    if ((uint32_t)__popcll(m | th) > ec.max_stones) return;
-    const unsigned long long key = c4_key(m, th) | ec.tag;
-    const uint32_t bucket = (uint32_t)(mix64(key) >> 20) & ec.bmask;
-    unsigned long long* keys = ec.key + (size_t)bucket * 8;
-    uint32_t empties = gballot(keys[sub] == 0ull);
-    uint32_t way = NONE;
-    while (empties) {
-        const uint32_t w = (uint32_t)__ffs((int)empties) - 1u;
-        unsigned long long prev = 0ull;
-        if (sub == 0) prev = atomicCAS(&keys[w], 0ull, key);
-        prev = ((unsigned long long)gshfl((uint32_t)(prev >> 32), 0) << 32) | gshfl((uint32_t)prev, 0);
-        if (prev == 0ull) { way = w; break; }
-        if (prev == key) return;                     // already published
-        empties &= empties - 1u;
-    }
-    if (way == NONE) return;                         // bucket full: not cached
-    ec.pv[((size_t)bucket * 8 + way) * 8 + sub] = pv;
-    if (sub == 0) atomicAdd(&ec.stat[DD_INSERTS], 1ull);
-}
-
-AZ_D void backup_body(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g, int sub) {
-    const uint32_t kind = t.leaf_kind[g];
+template <class G>
+AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g, int sub) {
+    constexpr int GW = G::GROUP;
+    constexpr int NA = G::ACTIONS;
+    const uint32_t kind = h.leaf_kind;
     if (kind == LEAF_NONE) return;
     const size_t base = (size_t)g * t.R;
-    const uint32_t leaf = t.leaf[g];
+    const uint32_t leaf = h.leaf;
     float val;
     if (kind == LEAF_EVAL) {
-        const int slot = t.slot_of[g];
-        const ulonglong2 s = t.state[base + leaf];
-        float pv;                                   // lanes 0..6: pi[sub], lane 7: v
-        if (eb.src) {
-            const uint32_t src = eb.src[slot];
-            if (src & SRC_CACHE) {
-                pv = ec.pv[(size_t)(src & SRC_INDEX) * 8 + sub];
-            } else {
-                const uint32_t u = (src & SRC_TABLE) ? eb.tuniq[src & SRC_INDEX] : src;
-                pv = eb.upi[(size_t)u * 8 + sub];
-                if (!(src & SRC_TABLE) && ec.key) cache_insert(ec, s.x, s.y, pv, sub);
-            }
+        uint4* lp = node_ptr(t, base, leaf);
+        const NodeRec lr = node_load(lp);
+        const typename G::State s = G::unpack(lr.key);
+        const uint32_t src = h.src;
+        float pv;                                   // lanes 0..NA-1: pi[sub], lane NA: v
+        if (src & SRC_CACHE) {
+            pv = ec.pv[(size_t)(src & SRC_INDEX) * 8 + sub];
         } else {
-            pv = eb.pi[(size_t)slot * 8 + sub];
+            const uint32_t row = (src & SRC_TABLE) ? eb.tuniq[src & SRC_INDEX] : src;
+            pv = eb.pi[(size_t)row * 8 + sub];
+            if (!(src & SRC_TABLE) && eb.dedup && ec.key) cache_insert<G>(ec, s, pv, sub);
         }
-        float p = sub < ACTIONS ? pv : 0.0f;
-        const float v = gshflf(pv, 7);
+        float p = sub < NA ? pv : 0.0f;
+        const float v = gshflf<GW>(pv, NA);
         if (t.log_cap > 0) {
-            uint32_t n = t.log_len[g];
+            uint32_t n = h.log_len;
             if (n < (uint32_t)t.log_cap) {
                 size_t li = (size_t)g * t.log_cap + n;
-                if (sub < ACTIONS) t.log_pi[li * 7 + sub] = p;
+                if (sub < NA) t.log_pi[li * NA + sub] = p;
                 if (sub == 0) { t.log_v[li] = v; t.log_state[li] = s; }
             }
-            if (sub == 0) t.log_len[g] = n + 1;
+            h.log_len = n + 1;
         }
-        const uint32_t vm = c4_valid_mask(s.x, s.y);
-        const bool valid = sub < ACTIONS && ((vm >> sub) & 1u);
+        const uint32_t vm = G::valid_mask(s);
+        const bool valid = sub < NA && ((vm >> sub) & 1u);
         if (!valid) p = 0.0f;                                       // :322-326
         float sum = 0.0f;
 #pragma unroll
-        for (int a = 0; a < ACTIONS; ++a) sum = __fadd_rn(sum, gshflf(p, a));   // :328 (sequential, C10)
+        for (int a = 0; a < NA; ++a) sum = __fadd_rn(sum, gshflf<GW>(p, a));   // :328 (sequential, C10)
         if (sum > 0.0f) {
             p = __fdiv_rn(p, sum);                                  // :331
         } else {
             p = __fadd_rn(p, valid ? 1.0f : 0.0f);                  // :340-342
             float s2 = 0.0f;
 #pragma unroll
-            for (int a = 0; a < ACTIONS; ++a) s2 = __fadd_rn(s2, gshflf(p, a));
+            for (int a = 0; a < NA; ++a) s2 = __fadd_rn(s2, gshflf<GW>(p, a));
             p = __fdiv_rn(p, s2);                                   // :344
         }
-        const uint4 lr = t.rec[base + leaf];
-        const uint32_t nchild = (lr.z >> META_NCHILD_SHIFT) & 7u, cb = lr.w;
-        const uint32_t myact = (uint32_t)sub < nchild ? nth_set_bit(vm, (uint32_t)sub) : 0u;
-        const float pa = gshflf(p, (int)myact);
-        if ((uint32_t)sub < nchild) t.rec[base + cb + sub].y = __float_as_uint(pa);   // set_policy, :348
-        if (sub == 0) {
-            t.rec[base + leaf].z = lr.z | META_HAS_PRIOR;
-            t.stat[(size_t)g * ST_COUNT + ST_LEAF_EVALS] += 1;
-        }
+        const uint32_t nchild = (lr.meta >> META_NCHILD_SHIFT) & 7u, cb = lr.child_base;
+        const uint32_t myact = (uint32_t)sub < nchild ? nth_set_bit<NA>(vm, (uint32_t)sub) : 0u;
+        const float pa = gshflf<GW>(p, (int)myact);
+        if ((uint32_t)sub < nchild) node_set_prior(node_ptr(t, base, cb + sub), __float_as_uint(pa));   // set_policy, :348
+        if (sub == 0) node_set_meta(lp, lr.meta | META_HAS_PRIOR);
+        h.stat[ST_LEAF_EVALS] += 1;
         val = -v;                                                   // :353 (C9)
     } else {
-        val = t.leaf_val[g];
+        val = h.leaf_val;
     }
     if (apply_only) return;
     // unvisit() leaf -> root along node_path; B2: the sign alternates toward the root.
     // A Connect Four line never repeats a node, so the lanes update distinct counters.
-    const uint32_t plen = t.path_len[g];
+    const uint32_t plen = h.path_len;
     const uint32_t* path = t.path + (size_t)g * PATH_CAP;
-    for (uint32_t i = (uint32_t)sub; i <= plen; i += LANES) {
+    for (uint32_t i = (uint32_t)sub; i <= plen; i += GW) {
         uint32_t node = i == 0 ? leaf : path[plen - i];
         float x = (i & 1u) ? -val : val;
-        t.ctr[base + node] -= ctr_unvisit_delta(x);                 // src/node.rs:83-92
+        uint4* np = node_ptr(t, base, node);
+        node_set_ctr(np, node_ctr(np) - ctr_unvisit_delta(x));      // src/node.rs:83-92
     }
 }
 
 // ---- get_action_prob epilogue (src/async_mcts.rs:84-114): counts -> pi ----------------------
 struct RootPolicy {
-    float pi;        // this lane's action (sub < 7)
+    float pi;        // this lane's action (sub < ACTIONS)
     uint32_t count;
     float q;
 };
-AZ_D RootPolicy root_policy(const TreeDev& t, int g, int sub, float temp, uint64_t seed, uint64_t game_id, uint64_t ply) {
+template <class G>
+AZ_D RootPolicy root_policy(const TreeDev& t, uint32_t root, int g, int sub, float temp, uint64_t seed, uint64_t game_id, uint64_t ply) {
+    constexpr int GW = G::GROUP;
+    constexpr int NA = G::ACTIONS;
     const size_t base = (size_t)g * t.R;
-    const uint4 pr = t.rec[base + t.root[g]];
-    const uint32_t nchild = (pr.z >> META_NCHILD_SHIFT) & 7u, cb = pr.w;
+    const NodeRec pr = node_load(node_ptr(t, base, root));
+    const uint32_t nchild = (pr.meta >> META_NCHILD_SHIFT) & 7u, cb = pr.child_base;
     uint32_t ca = 0, cn = 0;
     float cq = 0.0f;
     if ((uint32_t)sub < nchild) {
-        uint4 cr = t.rec[base + cb + sub];
-        uint32_t r = cr.x != NONE ? cr.x : cb + (uint32_t)sub;
-        uint64_t cc = t.ctr[base + r];
-        ca = cr.z & META_A_MASK;                                    // B3: the slot's own action
+        const NodeRec cr = node_load(node_ptr(t, base, cb + sub));
+        const uint64_t cc = cr.link != NONE ? node_ctr(node_ptr(t, base, cr.link)) : cr.ctr;
+        ca = cr.meta & META_A_MASK;                                 // B3: the slot's own action
         cn = ctr_n(cc);
         cq = ctr_q(cc);
     }
     RootPolicy out{0.0f, 0u, 0.0f};
 #pragma unroll
-    for (int j = 0; j < ACTIONS; ++j) {                             // counts[a] = n, :88-94
-        uint32_t aj = gshfl(ca, j), nj = gshfl(cn, j);
-        float qj = gshflf(cq, j);
+    for (int j = 0; j < NA; ++j) {                                  // counts[a] = n, :88-94
+        uint32_t aj = gshfl<GW>(ca, j), nj = gshfl<GW>(cn, j);
+        float qj = gshflf<GW>(cq, j);
         if ((uint32_t)j < nchild && aj == (uint32_t)sub) { out.count = nj; out.q = qj; }
     }
     if (temp == 0.0f) {                                             // :97-107
         uint32_t mx = 0;
 #pragma unroll
-        for (int a = 0; a < ACTIONS; ++a) { uint32_t ca2 = gshfl(out.count, a); mx = ca2 > mx ? ca2 : mx; }
-        uint32_t ties = gballot(sub < ACTIONS && out.count == mx) & 0x7Fu;
+        for (int a = 0; a < NA; ++a) { uint32_t ca2 = gshfl<GW>(out.count, a); mx = ca2 > mx ? ca2 : mx; }
+        uint32_t ties = gballot<GW>(sub < NA && out.count == mx) & ((1u << NA) - 1u);
         uint64_t r = rng_draw(seed, game_id, ply, RNG_TIEBREAK);
-        uint32_t pick = nth_set_bit(ties, rng_choose(r, (uint32_t)__popc(ties)));
+        uint32_t pick = nth_set_bit<NA>(ties, rng_choose(r, (uint32_t)__popc(ties)));
         out.pi = ((uint32_t)sub == pick) ? 1.0f : 0.0f;
     } else {                                                        // S6 (A7): counts^(1/temp) / sum
         float inv_t = __fdiv_rn(1.0f, temp);
         float x = (inv_t == 1.0f) ? (float)out.count : powf((float)out.count, inv_t);   // :109
-        if (sub >= ACTIONS) x = 0.0f;
+        if (sub >= NA) x = 0.0f;
         float sum = 0.0f;
 #pragma unroll
-        for (int a = 0; a < ACTIONS; ++a) sum = __fadd_rn(sum, gshflf(x, a));           // :110
+        for (int a = 0; a < NA; ++a) sum = __fadd_rn(sum, gshflf<GW>(x, a));           // :110
         out.pi = __fdiv_rn(x, sum);
     }
     return out;
 }
 
-__global__ __launch_bounds__(64) void k_select(TreeDev t, EvalBatch eb, SearchParams sp) {
-    const int tid = blockIdx.x * 64 + threadIdx.x;
-    const int g = tid >> 3, sub = tid & 7;
-    if (g >= t.G) return;
-    select_body(t, eb, sp, g, sub);
-}
-
+template <class G>
 __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCache ec, int apply_only) {
+    constexpr int GW = G::GROUP;
     const int tid = blockIdx.x * 64 + threadIdx.x;
-    const int g = tid >> 3, sub = tid & 7;
-    if (tid == 0) { *eb.n = 0; if (eb.un) *eb.un = 0; }   // the batch has been consumed (nothing in this kernel reads the counts)
+    const int g = tid / GW, sub = tid % GW;
+    if (tid == 0) *eb.n = 0;            // the batch has been consumed (nothing in this kernel reads the count)
     if (g >= t.G) return;
-    backup_body(t, eb, ec, apply_only, g, sub);
+    TreeHead h = head_load(t, g);
+    backup_body<G>(t, h, eb, ec, apply_only, g, sub);
+    h.leaf_kind = LEAF_NONE;
+    if (sub == 0) head_store(t, g, h);
 }
 
 // backup of simulation i and select of simulation i+1 in one launch: both belong to the same 8 lanes of the same tree and
 // nothing else touches that tree in between.  The leaf of i+1 goes into the OTHER eval batch (eb_next; its count was
 // zeroed by the previous launch, this one zeroes eb_prev's), so the two ping-pong.
+template <class G>
 __global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec,
                                                       SearchParams sp, int apply_only) {
+    constexpr int GW = G::GROUP;
     const int tid = blockIdx.x * 64 + threadIdx.x;
-    const int g = tid >> 3, sub = tid & 7;
-    if (tid == 0) { *eb_prev.n = 0; if (eb_prev.un) *eb_prev.un = 0; }
+    const int g = tid / GW, sub = tid % GW;
+    if (tid == 0) *eb_prev.n = 0;
     if (g >= t.G) return;
-    backup_body(t, eb_prev, ec, apply_only, g, sub);
+    TreeHead h = head_load(t, g);
+    backup_body<G>(t, h, eb_prev, ec, apply_only, g, sub);
     // the counters this tree's other lanes just wrote are read by the selection below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    select_body(t, eb_next, sp, g, sub);
+    select_body<G>(t, h, eb_next, ec, sp, g, sub);
+    if (sub == 0) head_store(t, g, h);
 }
 
-// ---- leaf de-duplication: one thread per requested row ------------------------------------------------------------------
-// 1. evaluation cache: the row's bucket is one 64-byte line of 8 keys; a match ends the row (src = cache entry).
-// 2. election table (open addressing, linear probe): the first row to CAS its key in wins and takes the next row of the
-//    unique batch (one atomicAdd per wave); later rows with the same key point at the winner's slot.  A slot whose epoch
-//    is not this launch's counts as empty, so the table is never cleared between launches (the caller clears it when the
-//    15-bit epoch wraps).
-__global__ __launch_bounds__(256) void k_dedup(EvalBatch eb, EvalCache ec, uint32_t epoch) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t n = *eb.n;
-    const int lane = (int)(threadIdx.x & 63);
-    bool winner = false, hit = false, dup = false;
-    ulonglong2 s = make_ulonglong2(0ull, 0ull);
-    if (r < n) {
-        s = eb.state[r];
-        const unsigned long long key = c4_key(s.x, s.y);
-        if (ec.key) {
-            const unsigned long long ck = key | ec.tag;
-            const uint32_t bucket = (uint32_t)(mix64(ck) >> 20) & ec.bmask;
-            const ulonglong4* kp = (const ulonglong4*)(ec.key + (size_t)bucket * 8);
-            const ulonglong4 k0 = kp[0], k1 = kp[1];
-            const int way = k0.x == ck ? 0 : k0.y == ck ? 1 : k0.z == ck ? 2 : k0.w == ck ? 3 :
-                            k1.x == ck ? 4 : k1.y == ck ? 5 : k1.z == ck ? 6 : k1.w == ck ? 7 : -1;
-            if (way >= 0) { hit = true; eb.src[r] = SRC_CACHE | (bucket * 8u + (uint32_t)way); }
-        }
-        if (!hit) {
-            const unsigned long long mine = key | ((unsigned long long)epoch << 49);
-            uint32_t pos = (uint32_t)(mix64(key) >> 24) & eb.tmask;
-            for (;;) {
-                unsigned long long cur = eb.tkey[pos];
-                if ((cur >> 49) != (unsigned long long)epoch) {          // empty or stale: try to take it
-                    const unsigned long long prev = atomicCAS(&eb.tkey[pos], cur, mine);
-                    if (prev == cur) { winner = true; break; }
-                    cur = prev;                                          // somebody else took it first
-                    if ((cur >> 49) != (unsigned long long)epoch) continue;   // (a stale value replaced by another stale one cannot happen; retry anyway)
-                }
-                if (cur == mine) { dup = true; eb.src[r] = SRC_TABLE | pos; break; }
-                pos = (pos + 1u) & eb.tmask;
-            }
-            if (winner) eb.src[r] = pos;            // provisional: replaced by the unique row below
-        }
-    }
-    // unique rows: one atomicAdd per wave
-    const unsigned long long wm = __ballot(winner);
-    if (wm) {
-        const int leader = __ffsll((long long)wm) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(eb.un, (uint32_t)__popcll(wm));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (winner) {
-            const uint32_t u = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
-            eb.tuniq[eb.src[r]] = u;
-            eb.src[r] = u;
-            eb.ustate[u] = s;
-        }
-    }
-    if (ec.stat) {
-        const unsigned long long hm = __ballot(hit), dm = __ballot(dup), am = __ballot(r < n);
-        if (am && lane == __ffsll((long long)am) - 1) {
-            atomicAdd(&ec.stat[DD_REQUESTED], (unsigned long long)__popcll(am));
-            if (wm) atomicAdd(&ec.stat[DD_EXECUTED], (unsigned long long)__popcll(wm));
-            if (hm) atomicAdd(&ec.stat[DD_CACHE_HITS], (unsigned long long)__popcll(hm));
-            if (dm) atomicAdd(&ec.stat[DD_BATCH_DUPS], (unsigned long long)__popcll(dm));
-        }
-    }
-}
-
+template <class G>
 __global__ __launch_bounds__(64) void k_root_policy(TreeDev t, float temp, uint64_t seed, uint64_t first_game_id,
                                                     float* pi, uint16_t* counts, float* q) {
+    constexpr int GW = G::GROUP;
+    constexpr int NA = G::ACTIONS;
     int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid >> 3, sub = tid & 7;
-    if (g >= t.G || !t.active[g]) return;
-    const ulonglong2 s = t.state[(size_t)g * t.R + t.root[g]];
-    RootPolicy rp = root_policy(t, g, sub, temp, seed, first_game_id + (uint64_t)g, (uint64_t)__popcll(s.x | s.y));
-    if (sub < ACTIONS) {
-        pi[(size_t)g * 7 + sub] = rp.pi;
-        if (counts) counts[(size_t)g * 7 + sub] = (uint16_t)rp.count;
-        if (q) q[(size_t)g * 7 + sub] = rp.q;
+    int g = tid / GW, sub = tid % GW;
+    if (g >= t.G) return;
+    const TreeHead h = head_load(t, g);
+    if (!h.active) return;
+    const typename G::State s = G::unpack(node_key(node_ptr(t, (size_t)g * t.R, h.root)));
+    RootPolicy rp = root_policy<G>(t, h.root, g, sub, temp, seed, first_game_id + (uint64_t)g, (uint64_t)G::stones(s));
+    if (sub < NA) {
+        pi[(size_t)g * NA + sub] = rp.pi;
+        if (counts) counts[(size_t)g * NA + sub] = (uint16_t)rp.count;
+        if (q) q[(size_t)g * NA + sub] = rp.q;
+    }
+}
+
+// sums the per-tree counters into totals (one atomicAdd per counter per wave) and clears them
+__global__ __launch_bounds__(256) void k_harvest(TreeDev t, unsigned long long* totals, uint32_t* node_counts) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t st[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+    if (g < t.G) {
+        TreeHead* hp = t.head + g;
+#pragma unroll
+        for (int k = 0; k < ST_COUNT; ++k) { st[k] = hp->stat[k]; hp->stat[k] = 0; }
+        if (node_counts) node_counts[g] = hp->count;
+    }
+#pragma unroll
+    for (int k = 0; k < ST_COUNT; ++k) {
+        unsigned long long v = st[k];                 // 64 lanes x < 2^32 each: the sum fits 38 bits
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64), lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
+            v += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0 && v) atomicAdd(&totals[k], v);
     }
 }
 
 // ---- Coach::execute_episode, one ply for every slot (src/coach.rs:118-156) -------------------
+template <class G>
 __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, SelfplayMoveParams mp) {
+    constexpr int GW = G::GROUP;
+    constexpr int NA = G::ACTIONS;
     int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid >> 3, sub = tid & 7;
+    int g = tid / GW, sub = tid % GW;
     if (g >= t.G) return;
     const int gi = gd.gid[g];
-    if (gi < 0 || !t.active[g]) return;
+    const TreeHead h = head_load(t, g);
+    if (gi < 0 || !h.active) return;
     const int ply = gd.ply[g];
     const int8_t player = gd.player[g];
-    const ulonglong2 s = gd.state[g];
+    const typename G::State s = gd.state[g];
     const uint64_t game_id = mp.first_game_id + (uint64_t)gi;
     const float temp = (ply + 1 < mp.temp_threshold) ? 1.0f : 0.0f;         // :122-126 (episode_step = ply + 1)
-    RootPolicy rp = root_policy(t, g, sub, temp, mp.seed, game_id, (uint64_t)ply);   // :128
-    const size_t so = (size_t)gi * 42 + ply;
-    if (sub < ACTIONS) gd.smp_pi[so * 7 + sub] = rp.pi;                     // :130-135 (symmetries regenerated at emit)
+    RootPolicy rp = root_policy<G>(t, h.root, g, sub, temp, mp.seed, game_id, (uint64_t)ply);   // :128
+    const size_t so = (size_t)gi * G::MAX_PLIES + ply;
+    if (sub < NA) gd.smp_pi[so * NA + sub] = rp.pi;                         // :130-135 (symmetries regenerated at emit)
     // choose_weighted, :137-138
-    float w[ACTIONS];
+    float w[NA];
 #pragma unroll
-    for (int a = 0; a < ACTIONS; ++a) w[a] = gshflf(rp.pi, a);
+    for (int a = 0; a < NA; ++a) w[a] = gshflf<GW>(rp.pi, a);
     float total = 0.0f;
 #pragma unroll
-    for (int a = 0; a < ACTIONS; ++a) total = __fadd_rn(total, w[a]);
+    for (int a = 0; a < NA; ++a) total = __fadd_rn(total, w[a]);
     const uint64_t r = rng_draw(mp.seed, game_id, (uint64_t)ply, RNG_MOVE);
     const float uu = (float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f);
     const float target = __fmul_rn(uu, total);
     float acc = 0.0f;
     int action = -1, last = -1;
 #pragma unroll
-    for (int a = 0; a < ACTIONS; ++a) {
+    for (int a = 0; a < NA; ++a) {
         if (w[a] > 0.0f) {
             acc = __fadd_rn(acc, w[a]);
             last = a;
@@ -582,9 +656,8 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
     }
     if (action < 0) action = last;
     if (action < 0) action = 0;
-    uint64_t m2, t2;
-    c4_play(s.x, s.y, action, &m2, &t2);                                    // :140-142
-    const uint32_t ec = c4_ecode(m2, t2);                                   // r = get_game_ended(cur_player), :144
+    const typename G::State s2 = G::play(s, action);                        // :140-142
+    const uint32_t ec = G::ended_code(s2);                                  // r = get_game_ended(cur_player), :144
     if (sub == 0) {
         gd.smp_state[so] = s;
         gd.smp_player[so] = player;
@@ -602,16 +675,16 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
             }
             gd.gid[g] = next;
             if (next >= 0) {
-                gd.state[g] = make_ulonglong2(0ull, 0ull);
+                gd.state[g] = G::init();
                 gd.player[g] = 1;
                 gd.ply[g] = 0;
                 gd.need_reset[g] = 1;
             } else {
-                t.active[g] = 0;
+                t.head[g].active = 0;
                 atomicSub(&gd.counters[2], 1u);
             }
         } else {
-            gd.state[g] = make_ulonglong2(m2, t2);
+            gd.state[g] = s2;
             gd.player[g] = (int8_t)-player;
             gd.ply[g] = ply + 1;
         }
@@ -619,25 +692,29 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
 }
 
 // ---- training tuples (TrainingSample, src/nnet.rs:22-27; z per B4, src/coach.rs:146-154) -----
+template <class G>
 __global__ __launch_bounds__(256) void k_emit_samples(GamesDev gd, const int64_t* offsets, int symmetries,
                                                       ulonglong2* out_states, float* out_boards, float* out_pis,
                                                       float* out_zs) {
+    constexpr int NA = G::ACTIONS;
+    constexpr int NF = G::FEATURES;
+    static_assert(NF > NA + 1, "the item loop below spreads pi / z / state stores over the first feature indices");
     const int gi = blockIdx.x;
     const int len = gd.g_len[gi];
     const int nsym = symmetries ? 2 : 1;
     const float r = gd.g_result[gi];
     const int8_t fin = gd.g_final_player[gi];
-    for (int item = threadIdx.x; item < len * nsym * 84; item += blockDim.x) {
-        const int f = item % 84, rest = item / 84;
+    for (int item = threadIdx.x; item < len * nsym * NF; item += blockDim.x) {
+        const int f = item % NF, rest = item / NF;
         const int sym = rest % nsym, ply = rest / nsym;
-        const size_t so = (size_t)gi * 42 + ply;
+        const size_t so = (size_t)gi * G::MAX_PLIES + ply;
         const int64_t o = (offsets[gi] + ply) * nsym + sym;
-        ulonglong2 s = gd.smp_state[so];
-        if (sym) s = make_ulonglong2(c4_mirror(s.x), c4_mirror(s.y));          // get_symmetries, connect_four_game.rs:205-211
-        if (out_boards) out_boards[o * 84 + f] = c4_feature(s.x, s.y, f / 42, (f % 42) / 7, f % 7);
-        if (f < 7) out_pis[o * 7 + f] = gd.smp_pi[so * 7 + (sym ? 6 - f : f)];
-        if (f == 7) out_zs[o] = __fmul_rn(r, gd.smp_player[so] == fin ? 1.0f : -1.0f);   // B4
-        if (f == 8 && out_states) out_states[o] = s;
+        typename G::State s = gd.smp_state[so];
+        if (sym) s = G::mirror(s);                                             // get_symmetries, connect_four_game.rs:205-211
+        if (out_boards) out_boards[o * NF + f] = G::feature(s, f);
+        if (f < NA) out_pis[o * NA + f] = gd.smp_pi[so * NA + (sym ? G::mirror_action(f) : f)];
+        if (f == NA) out_zs[o] = __fmul_rn(r, gd.smp_player[so] == fin ? 1.0f : -1.0f);   // B4
+        if (f == NA + 1 && out_states) out_states[o] = s;
     }
 }
 
@@ -649,25 +726,29 @@ __global__ void k_arena_sync(TreeDev tn, TreeDev to, ArenaDev ad) {
     const bool alive = ad.alive[g] != 0;
     const int first_model = ad.first + g < ad.half ? 0 : 1;            // 0 = new, 1 = old (global game index)
     const int mover = ad.player[g] == 1 ? first_model : 1 - first_model;
-    tn.active[g] = alive && mover == 0;
-    to.active[g] = alive && mover == 1;
+    tn.head[g].active = (alive && mover == 0) ? 1u : 0u;
+    to.head[g].active = (alive && mover == 1) ? 1u : 0u;
 }
 
 // The searching tree's owner plays argmax(get_action_prob(s, temp = 0)) (src/coach.rs:356-372).
+template <class G>
 __global__ __launch_bounds__(64) void k_arena_move(TreeDev t, ArenaDev ad, uint64_t seed) {
+    constexpr int GW = G::GROUP;
+    constexpr int NA = G::ACTIONS;
     int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid >> 3, sub = tid & 7;
-    if (g >= t.G || !t.active[g]) return;
-    const ulonglong2 s = ad.state[g];
+    int g = tid / GW, sub = tid % GW;
+    if (g >= t.G) return;
+    const TreeHead h = head_load(t, g);
+    if (!h.active) return;
+    const typename G::State s = ad.state[g];
     const int8_t player = ad.player[g];
-    RootPolicy rp = root_policy(t, g, sub, 0.0f, seed, (uint64_t)(ad.first + g), (uint64_t)__popcll(s.x | s.y));
+    RootPolicy rp = root_policy<G>(t, h.root, g, sub, 0.0f, seed, (uint64_t)(ad.first + g), (uint64_t)G::stones(s));
     // argmax with max_by (last max) over the one-hot pi = the index of the 1
-    const uint32_t hot = gballot(sub < ACTIONS && rp.pi == 1.0f) & 0x7Fu;
+    const uint32_t hot = gballot<GW>(sub < NA && rp.pi == 1.0f) & ((1u << NA) - 1u);
     const int action = hot ? (31 - __clz((int)hot)) : 0;
-    const bool valid = (c4_valid_mask(s.x, s.y) >> action) & 1u;      // src/arena.rs:29-35
-    uint64_t m2, t2;
-    c4_play(s.x, s.y, action, &m2, &t2);
-    const uint32_t ec = c4_ecode(m2, t2);
+    const bool valid = (G::valid_mask(s) >> action) & 1u;             // src/arena.rs:29-35
+    const typename G::State s2 = G::play(s, action);
+    const uint32_t ec = G::ended_code(s2);
     if (sub == 0) {
         if (!valid || !hot) {
             atomicOr(&ad.counters[1], 1u);
@@ -680,7 +761,7 @@ __global__ __launch_bounds__(64) void k_arena_move(TreeDev t, ArenaDev ad, uint6
             ad.alive[g] = 0;
             atomicSub(&ad.counters[0], 1u);
         } else {
-            ad.state[g] = make_ulonglong2(m2, t2);
+            ad.state[g] = s2;
             ad.player[g] = (int8_t)-player;
         }
     }
@@ -688,37 +769,44 @@ __global__ __launch_bounds__(64) void k_arena_move(TreeDev t, ArenaDev ad, uint6
 
 __global__ void k_sync_active(TreeDev t, GamesDev gd) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < t.G) t.active[g] = gd.gid[g] >= 0 ? 1 : 0;
+    if (g < t.G) t.head[g].active = gd.gid[g] >= 0 ? 1u : 0u;
 }
 
-// ---- launchers --------------------------------------------------------------------------------
-static inline int group_blocks(int G) { return (G * LANES + 63) / 64; }
+// ---- launchers: the reference's one Game (ConnectFour) --------------------------------------------------------------
+using TheGame = ConnectFour;
+static_assert(TheGame::GROUP == BLOCK_SLOTS && TheGame::GROUP > TheGame::ACTIONS && (TheGame::GROUP & (TheGame::GROUP - 1)) == 0,
+              "one lane per child plus one, power of two, one child block per group");
+static_assert(sizeof(TheGame::State) == 16 && sizeof(TheGame::Packed) == 8, "16-byte states, 8-byte node-resident identity");
+static inline int group_blocks(int G) { return (G * TheGame::GROUP + 63) / 64; }
 
+void launch_init_heads(const TreeDev& t, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_heads, dim3((t.G + 255) / 256), dim3(256), 0, s, t);
+}
+void launch_set_active(const TreeDev& t, uint32_t value, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_active, dim3((t.G + 255) / 256), dim3(256), 0, s, t, value);
+}
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags, hipStream_t s, const ulonglong2* roots) {
-    hipLaunchKernelGGL(k_reset_trees, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags), roots);
+    hipLaunchKernelGGL(k_reset_trees<TheGame>, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags), roots);
 }
-void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const ulonglong2* root_states, hipStream_t s) {
-    hipLaunchKernelGGL(k_root_prepare, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, root_states);
-}
-void launch_select(const TreeDev& t, const EvalBatch& eb, SearchParams sp, hipStream_t s) {
-    hipLaunchKernelGGL(k_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, sp);
+void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, const ulonglong2* root_states, hipStream_t s) {
+    hipLaunchKernelGGL(k_root_prepare<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, root_states);
 }
 void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s) {
-    hipLaunchKernelGGL(k_backup, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, apply_only);
+    hipLaunchKernelGGL(k_backup<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, apply_only);
 }
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s) {
-    hipLaunchKernelGGL(k_backup_select, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, apply_only);
-}
-void launch_dedup(const EvalBatch& eb, const EvalCache& ec, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL(k_dedup, dim3((eb.cap + 255) / 256), dim3(256), 0, s, eb, ec, epoch);
+    hipLaunchKernelGGL(k_backup_select<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, apply_only);
 }
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s) {
-    hipLaunchKernelGGL(k_root_policy, dim3(group_blocks(t.G)), dim3(64), 0, s, t, temp, seed, first_game_id, pi, counts, q);
+    hipLaunchKernelGGL(k_root_policy<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, temp, seed, first_game_id, pi, counts, q);
+}
+void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_harvest, dim3((t.G + 255) / 256), dim3(256), 0, s, t, totals, node_counts);
 }
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s) {
-    hipLaunchKernelGGL(k_selfplay_move, dim3(group_blocks(t.G)), dim3(64), 0, s, t, gd, mp);
+    hipLaunchKernelGGL(k_selfplay_move<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, gd, mp);
 }
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s) {
     hipLaunchKernelGGL(k_sync_active, dim3((t.G + 255) / 256), dim3(256), 0, s, t, gd);
@@ -727,11 +815,11 @@ void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDe
     hipLaunchKernelGGL(k_arena_sync, dim3((ad.G + 255) / 256), dim3(256), 0, s, t_new, t_old, ad);
 }
 void launch_arena_move(const TreeDev& t, const ArenaDev& ad, uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(k_arena_move, dim3(group_blocks(t.G)), dim3(64), 0, s, t, ad, seed);
+    hipLaunchKernelGGL(k_arena_move<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, ad, seed);
 }
 void launch_emit_samples(const GamesDev& gd, const int64_t* offsets, int symmetries, ulonglong2* out_states,
                          float* out_boards, float* out_pis, float* out_zs, hipStream_t s) {
-    hipLaunchKernelGGL(k_emit_samples, dim3(gd.n_games), dim3(256), 0, s, gd, offsets, symmetries, out_states,
+    hipLaunchKernelGGL(k_emit_samples<TheGame>, dim3(gd.n_games), dim3(256), 0, s, gd, offsets, symmetries, out_states,
                        out_boards, out_pis, out_zs);
 }
 
