@@ -95,7 +95,21 @@ struct TreeHost {
     uint32_t* d_counts = nullptr;             // [G] NodeStore::len per tree (k_harvest)
     // blocks = child blocks the trees can use (each holds the <= 7 children of one expansion, or a root);
     // reserve_nodes = reserve_space (src/node.rs:146) clamped to what is reachable
+    // allocation key (the engine keeps finished calls' arenas for the next call of the same shape)
+    int k_G = 0, k_log = 0; uint64_t k_blocks = 0; uint32_t k_H = 0;
+    bool in_use = false;
+    bool fits(int G, uint64_t blocks, uint32_t H, int log_cap) const { return G == k_G && blocks == k_blocks && H == k_H && log_cap == k_log; }
+    // make a kept arena look freshly created (the trees themselves are rebuilt by launch_reset_trees)
+    void recycle(uint64_t reserve_nodes, hipStream_t s) {
+        d.reserve_nodes = (uint32_t)reserve_nodes;
+        HIPCHK(hipMemsetAsync(d.err, 0, ERR_COUNT * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(d_totals, 0, ST_COUNT * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(eb.n, 0, sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(eb2.n, 0, sizeof(uint32_t), s));
+        launch_init_heads(d, s);
+    }
     void create(int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int log_cap) {
+        k_G = G; k_blocks = blocks; k_H = H; k_log = log_cap;
         d.G = G; d.R = (uint32_t)(blocks * BLOCK_SLOTS); d.H = H; d.reserve_nodes = (uint32_t)reserve_nodes;
         size_t slots = (size_t)G * d.R;
         d.node = mem.alloc<uint4>(slots * 2);
@@ -186,6 +200,10 @@ struct az_engine {
     EvalCache cache{};              // key == nullptr until first use
     int cache_alloc_log2 = -1;
     uint64_t next_cache_tag = 1;    // 15 bits; wrapping clears the cache
+    // tree arenas of finished az_selfplay / az_arena calls, reused by the next call of the same shape (9.7 GB at 8192 x 100:
+    // no hipMalloc / hipFree per call); at most three are kept (self-play + the arena's pair)
+    std::vector<std::unique_ptr<TreeHost>> tree_pool;
+    uint64_t tree_pool_allocs = 0;  // arenas created (a second call of the same shape must not add to it)
 };
 
 struct az_tree {
@@ -272,6 +290,38 @@ EvalCache cache_for(az_engine* e, NetModel& net) {
     c.tag = (unsigned long long)net.cache_tag << 49;
     return c;
 }
+// A tree arena for one call: a kept one of the same shape, or a new one (the oldest idle one makes room).
+struct TreeLease {
+    TreeHost* th = nullptr;
+    ~TreeLease() { if (th) th->in_use = false; }
+    TreeHost* operator->() const { return th; }
+    TreeHost& operator*() const { return *th; }
+};
+void acquire_trees(az_engine* e, TreeLease& lease, int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int log_cap, hipStream_t s) {
+    for (auto& p : e->tree_pool)
+        if (!p->in_use && p->fits(G, blocks, H, log_cap)) {
+            p->in_use = true;
+            lease.th = p.get();
+            p->recycle(reserve_nodes, s);
+            return;
+        }
+    // drop idle arenas of other shapes before allocating (two shapes of 10 GB each should not pile up)
+    for (size_t i = 0; i < e->tree_pool.size();) {
+        if (!e->tree_pool[i]->in_use && (e->tree_pool.size() >= 3 || !e->tree_pool[i]->fits(G, blocks, H, log_cap))) {
+            HIPCHK(hipStreamSynchronize(s));
+            e->tree_pool.erase(e->tree_pool.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+    std::unique_ptr<TreeHost> th(new TreeHost());
+    th->create(G, blocks, reserve_nodes, H, log_cap);
+    th->in_use = true;
+    lease.th = th.get();
+    e->tree_pool.push_back(std::move(th));
+    e->tree_pool_allocs += 1;
+}
+
 // fold the device-side de-duplication counters into the engine stats (after a stream sync)
 void harvest_dedup(az_engine* e) {
     if (!e->cache.stat) return;
@@ -420,6 +470,7 @@ void az_destroy(az_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->nets) if (kv.second.conv) convnet_destroy(kv.second.conv);
     for (NetWorkspace* w : e->ws) netws_destroy(w);
+    e->tree_pool.clear();
     trainer_destroy(e->trainer);
     { double ms[RG_COUNT] = {0, 0}; e->prof.resolve(ms); }
     (void)hipStreamDestroy(e->stream);
@@ -477,6 +528,7 @@ az_status az_get_stats(az_engine* e, az_stats* out) {
     out->net_conv2_flops = e->netprof.conv2_flops;
     out->net_total_ms = e->netprof.total_ms;
     out->net_total_flops = e->netprof.total_flops;
+    out->tree_arena_allocs = e->tree_pool_allocs;
     return AZ_OK;
 }
 az_status az_reset_stats(az_engine* e) {
@@ -903,9 +955,11 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
     try {
         HIPCHK(hipSetDevice(e->device));
         hipStream_t s = e->stream;
-        TreeHost th;
         const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
-        th.create(C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES), p->record_evals);
+        TreeLease lease;
+        acquire_trees(e, lease, C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES),
+                      p->record_evals, s);
+        TreeHost& th = *lease;
         DeviceMem mem;
         GamesDev gd{};
         gd.C = C;
@@ -1066,9 +1120,10 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         // (src/coach.rs:333-354) and their u16 root counters would wrap at 65536 visits.
         const int calls = AZ_MAX_PLIES / 2 + 1;
         const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, calls));
-        TreeHost tn, to;
-        tn.create(G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0);
-        to.create(G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0);
+        TreeLease lease_n, lease_o;
+        acquire_trees(e, lease_n, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0, s);
+        acquire_trees(e, lease_o, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0, s);
+        TreeHost &tn = *lease_n, &to = *lease_o;
         DeviceMem mem;
         ArenaDev ad{};
         ad.G = G; ad.half = half; ad.first = first;

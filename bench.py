@@ -100,6 +100,19 @@ def cpu_baseline(params, channels, sims, mean_plies=None, budget_s=20.0, seed=1)
     }
 
 
+def committed_pmc():
+    """The newest committed PMC fold (tools/collect_profiles.sh -> profiles/r<NN><x>_pmc_traffic.json): bench.py cannot
+    collect hardware counters itself, so per-kernel HBM bytes come from the rocprofv3 --pmc passes of this same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def self_launch(n):
     """`python3 bench.py --gpus N` without torchrun: start N ranks (one per GPU) under torch.distributed.run as a CHILD
     process -- never an exec, and before anything in this process has initialised the GPU -- and pass its output through.
@@ -169,6 +182,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary no-dedup and arena (config 3) measurements")
     ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
     ap.add_argument("--dedup", type=int, default=1, choices=[0, 1], help="leaf de-duplication + per-call evaluation cache (bit-exact); 0 = every requested row runs")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and run the gather even at world size 1 (rehearsal)")
@@ -288,16 +302,18 @@ def main():
             # HBM traffic of the same kernel from the committed PMC passes (profiles/r01k_pmc_traffic.json: separate
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command -- tools/collect_profiles.sh, gfx950 correction
             # applied), scaled by this run's mean leaves per launch.  bench.py cannot collect PMC counters itself.
-            traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")))
-                per_leaf = pmc["kernels"]["void az::k_conv_img2<1>"]["hbm_bytes_per_leaf"]
-                traffic = per_leaf * (st["net_conv2_flops"] / st["net_launches"]) / (2.0 * 42 * 512 * 4608)
-            except Exception:
-                pass
-            roof = {"bound": "mfma", "kernel": "k_conv_img2<1> (conv2: 3x3 same, 512->512, image-resident implicit GEMM on MFMA, two 4-wave workgroups per CU)",
+            traffic, traffic_src = None, None
+            pmc, pmc_name = committed_pmc()
+            if pmc:
+                for k, v in pmc["kernels"].items():
+                    if "k_conv_img2<1" in k:
+                        traffic = v["hbm_bytes_per_leaf"] * (st["net_conv2_flops"] / st["net_launches"]) / (2.0 * 42 * 512 * 4608)
+                        traffic_src = pmc_name
+            roof = {"bound": "mfma", "kernel": "k_conv_img2<1, true> (conv2: 3x3 same, 512->512, image-resident implicit GEMM on MFMA, two 4-wave "
+                                               "workgroups per CU, input image gathered from the conv1 pattern table)",
                     "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, offline pass)",
+                    "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{traffic_src}: "
+                                                        "bytes per executed row x this run's mean rows per launch)",
                     "launches": st["net_launches"],
                     "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"],
                     "avg_flop_per_launch": st["net_conv2_flops"] / st["net_launches"],
@@ -308,7 +324,19 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
         line["roofline"] = roof
         if not args.no_profile and st["tree_ms"] > 0:
+            tree_counter = None
+            pmc, pmc_name = committed_pmc()
+            if pmc:
+                for k, v in pmc["kernels"].items():
+                    if "k_backup_select" in k:
+                        # counter bytes per launch of the committed PMC pass over this run's mean launch time
+                        launch_s = st["tree_ms"] * 1e-3 / max(1, st["net_launches"])      # one tree launch per net launch
+                        tree_counter = {"hbm_bytes_per_launch_pmc": v["hbm_bytes_per_launch"], "source": f"profiles/{pmc_name}",
+                                        "mean_launch_us_this_run": launch_s * 1e6,
+                                        "counter_GBps": v["hbm_bytes_per_launch"] / launch_s / 1e9,
+                                        "counter_over_algorithmic": v["hbm_bytes_per_launch"] / max(1.0, st["tree_bytes"] / max(1, st["net_launches"]))}
             line["tree_hbm"] = {"achieved_GBps": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                                "counter": tree_counter,
                                 "frac": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "frac_of_measured_copy_bw": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9 / 6290.0,
                                 "algorithmic_bytes_per_sim": st["tree_bytes"] / max(1, st["simulations"]),
@@ -340,6 +368,41 @@ def main():
                                       "note": "az_net_train wall time incl. upload of the samples; ~3x forward FLOPs per sample"}
             except Exception as ex:
                 line["nnet_train"] = {"error": repr(ex)}
+        if world == 1 and args.net == "conv" and not args.no_aux:
+            # auxiliary, outside the timed region, not part of `value`
+            # (a) the same workload with every requested row executed (de-duplication off): what round 1 measured
+            try:
+                e.set_option("eval_dedup", 0)
+                e.reset_stats()
+                t1 = time.perf_counter()
+                r = e.selfplay(n_games=args.games, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
+                               first_game_id=10**9, symmetries=False, want_boards=False, out=out)
+                torch.cuda.synchronize()
+                dta = time.perf_counter() - t1
+                sa = e.stats()
+                line["no_dedup"] = {"games_per_sec": args.games / dta, "episodes": args.games, "leaf_evals_per_sec": sa["leaf_evals"] / dta,
+                                    "mfma_fraction_end_to_end": sa["leaf_rows_executed"] / dta * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12),
+                                    "conv2_tflops": sa["net_conv2_flops"] / (sa["net_conv2_ms"] * 1e-3) / 1e12 if sa["net_conv2_ms"] else None,
+                                    "note": "one episode batch of --games episodes (no refill), eval_dedup = 0"}
+            except Exception as ex:
+                line["no_dedup"] = {"error": repr(ex)}
+            finally:
+                e.set_option("eval_dedup", args.dedup)
+            # (b) BASELINE config 3: arena.rs head-to-head, 4096 paired games new-vs-old net, 400 sims/move, two seeded bf16 nets
+            try:
+                e.net_init_random(2, seed=args.seed + 1)
+                e.reset_stats()
+                t1 = time.perf_counter()
+                wld, _res = e.arena(num_games=4096, num_sims=400, new_model_id=2, old_model_id=0, seed=args.seed)
+                dta = time.perf_counter() - t1
+                sa = e.stats()
+                line["arena"] = {"games_per_sec": 4096 / dta, "seconds": dta, "games": 4096, "sims_per_move": 400, "wld_new_model": [int(x) for x in wld],
+                                 "simulations_per_sec": sa["simulations"] / dta,
+                                 "leaf_rows_executed_over_requested": sa["leaf_rows_executed"] / max(1, sa["leaf_rows_requested"]),
+                                 "note": "temp 0 from the first move (src/coach.rs:356-372): games of one seating differ only where the "
+                                         "tie-break RNG does, so most leaf rows are duplicates the evaluation cache answers"}
+            except Exception as ex:
+                line["arena"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
     e.close()
     if use_dist:

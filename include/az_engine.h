@@ -92,6 +92,8 @@ typedef struct az_stats {
     uint64_t eval_cache_hits;
     uint64_t eval_batch_dups;
     uint64_t eval_cache_inserts;
+    uint64_t tree_arena_allocs;  /* tree arenas hipMalloc'ed by az_selfplay / az_arena since az_create (kept and reused across
+                                  * calls of the same shape; not cleared by az_reset_stats) */
 } az_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */

@@ -458,3 +458,20 @@ def test_dedup_counters_and_cache_corner_cases(engine, oracle, dedup_mode):
         engine.set_option("eval_cache_log2", 24)
         engine.set_option("eval_cache_max_stones", 42)
         engine.set_option("eval_cache_persist", 0)
+
+
+def test_tree_arena_is_kept_across_calls(engine, oracle, dedup_mode):
+    """az_selfplay / az_arena keep their tree arenas for the next call of the same shape (no hipMalloc / hipFree per call) and
+    a recycled arena plays exactly what a fresh one does."""
+    n, sims = 40, 25
+    ref = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=31, threads=8)
+    _compare_selfplay(engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=31, concurrent=16), ref)
+    a0 = engine.stats()["tree_arena_allocs"]
+    for _ in range(3):
+        _compare_selfplay(engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=31, concurrent=16), ref)
+    assert engine.stats()["tree_arena_allocs"] == a0
+    w1, r1 = engine.arena(num_games=24, num_sims=25, new_model_id=10, old_model_id=11, seed=3)
+    a1 = engine.stats()["tree_arena_allocs"]
+    w2, r2 = engine.arena(num_games=24, num_sims=25, new_model_id=10, old_model_id=11, seed=3)
+    assert engine.stats()["tree_arena_allocs"] == a1 and np.array_equal(w1, w2) and np.array_equal(r1, r2)
+    _compare_selfplay(engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=31, concurrent=16), ref)

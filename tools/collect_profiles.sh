@@ -7,7 +7,7 @@ O="$R/gpurun_out/prof_g"
 mkdir -p "$O"
 cd /tmp
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --episodes 8192 --no-cpu-baseline --no-train-probe"
+ARGS="--steps 1 --warmup 0 --episodes 16384 --no-cpu-baseline --no-train-probe --no-aux"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o bench -- python3 "$R/bench.py" $ARGS > "$O/bench_under_rocprof.json" 2> "$O/err1.log"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O" -o fetch -- python3 "$R/bench.py" $ARGS --no-profile > "$O/bench_fetch.json" 2> "$O/err2.log"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O" -o write -- python3 "$R/bench.py" $ARGS --no-profile > "$O/bench_write.json" 2> "$O/err3.log"

@@ -30,8 +30,8 @@ def main():
     conv = [k for k in fetch if "k_conv_img" in k]   # k_conv_img2<1> (default) or k_conv_img<1>
     launches = nf[conv[0]] if conv else max(nf.values())
     per_launch_leaves = leaf_evals / launches
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --episodes 8192 "
-                      "--no-cpu-baseline --no-profile --no-train-probe (two separate passes; tools/collect_profiles.sh)",
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --episodes 16384 "
+                      "--no-cpu-baseline --no-profile --no-train-probe --no-aux (two separate passes; tools/collect_profiles.sh)",
            "units": "FETCH_SIZE / WRITE_SIZE in KB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports "
                     "half the bytes of 16-B-per-lane streaming reads, MI355X_MICROARCH.md HBM section; WRITE_SIZE of the 8-B-per-lane "
                     "epilogue stores is uncalibrated)",
