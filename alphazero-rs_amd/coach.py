@@ -5,20 +5,24 @@ meaning, `learn` runs the iteration loop of src/coach.rs:169-396: self-play epis
 (max_queue_length / max_history_length) -> save examples -> shuffle -> NNet::train -> arena of new vs old ->
 accept iff nwins + pwins > 0 and nwins / (nwins + pwins) >= update_threshold (:383-390).  Self-play and the arena
 are ONE engine call each (az_selfplay / az_arena); episodes shard across ranks by global game id when a process
-group is active, the tuples are gathered once per iteration (alphazero-rs_amd/dist.py) and gradients are all-reduced.
+group is active and the tuples are gathered once per iteration (alphazero-rs_amd/dist.py).
 
 NNet::train is the engine's own (az_net_train, csrc/az_train.hip) unless a `trainer` object is passed (the PyTorch
-autograd trainer of alphazero-rs_amd/trainer.py, which all-reduces gradients across ranks; with the engine's trainer
-every rank trains on the same gathered samples and, the kernels being deterministic, ends with the same weights).
+autograd restatement of alphazero-rs_amd/trainer.py: what the CPU tests use).  Several ranks are REPLICAS for training:
+every rank trains on the same gathered samples with the same seeds and, the kernels being deterministic, ends with the
+same weights -- no gradient exchange.
 The C++ host (include/az_host.hpp `Coach`) runs the same sequence with the same seeds and writes the same files.
 
 On-disk formats (the reference's are bincode / TF checkpoints, src/coach.rs:159-167 with defect A14; these are the
 build's own, documented here):
   <dir>/<iter>.examples   "AZEX0001": char magic[8]; int64 H; int64 lens[H] (samples per history entry);
                           f32 boards[N][2][6][7]; f32 pis[N][7]; f32 vs[N] -- the whole `history` deque, oldest first
-  <dir>/<model_id>.aznet  weights file of az_net_save
+  <dir>/<model_id>.aznet  weights file of az_net_save: the initial model and every candidate
+  <dir>/coach.state       text "iteration model_id\n": the last finished iteration and the ACCEPTED model id after its gate
+                          (a rejected candidate leaves its <id+1>.aznet behind; the state file says which id is live)
 Resume picks the largest numeric stem, as Coach::setup does (:55-81); non-numeric files are ignored instead of
-panicking.
+panicking; when coach.state names a model whose .aznet exists it is loaded into that engine slot, so iteration k+1 of a
+restarted run is byte-identical to an uninterrupted one.
 """
 import collections
 import os
@@ -51,10 +55,17 @@ class Coach:
         self.start_iteration = 0
         os.makedirs(self.dir, exist_ok=True)
         stems = [int(f[:-9]) for f in os.listdir(self.dir) if f.endswith(".examples") and f[:-9].isdigit()]
+        self.model_id = 0
         if stems:                                                      # src/coach.rs:55-81
             it = max(stems)
             self.history.extend(load_examples(os.path.join(self.dir, f"{it}.examples")))
             self.start_iteration = it + 1
+            st = read_state(self.dir)
+            if st is not None and st[0] == it:                         # the live model of the run being resumed
+                self.model_id = st[1]
+                path = os.path.join(self.dir, f"{self.model_id}.aznet")
+                if os.path.exists(path):
+                    engine.net_load(self.model_id, path)
         return self
 
     # ---- rank helpers -------------------------------------------------------------------------------------
@@ -107,20 +118,27 @@ class Coach:
         boards = states_to_boards(s2.numpy().view(np.uint64))
         return boards, p2.numpy(), z2.numpy()
 
-    def learn(self, skip_first_play=False, seed=0, model_id=0):
-        """src/coach.rs:169-396.  Engine model slots: `model_id` is the current net, `model_id + 1` the candidate.
-        Returns a list of per-iteration dicts (wins, accepted, losses)."""
+    def learn(self, skip_first_play=False, seed=0, model_id=None):
+        """src/coach.rs:169-396.  Engine model slots: `model_id` is the current net (default: the resumed run's live
+        model, else 0), `model_id + 1` the candidate.  Returns a list of per-iteration dicts (wins, accepted, losses)."""
         rank, world = self._world()
         report = []
+        if model_id is None:
+            model_id = self.model_id
+        first = os.path.join(self.dir, f"{model_id}.aznet")
+        if rank == 0 and not os.path.exists(first):
+            self.engine.net_save(model_id, first)                       # the run's initial model: what a restart would load
+        free = getattr(self.engine, "net_free", None)
         for iteration in range(self.start_iteration, self.start_iteration + self.num_iters):
             t_play = t_train = t_arena = 0.0
+            boards, pis, vs = np.zeros((0, 2, 6, 7), np.float32), np.zeros((0, 7), np.float32), np.zeros(0, np.float32)
             if not skip_first_play or iteration > self.start_iteration:
                 t0 = time.perf_counter()
                 boards, pis, vs = self.execute_episodes(model_id, iteration, seed)
                 t_play = time.perf_counter() - t0
                 if vs.shape[0] > self.max_queue_length:                 # :275-277: keep the newest max_queue_length
                     boards, pis, vs = boards[-self.max_queue_length:], pis[-self.max_queue_length:], vs[-self.max_queue_length:]
-                self.history.append((boards, pis, vs))
+            self.history.append((boards, pis, vs))                      # :282: pushed even when the play was skipped (empty entry)
             if len(self.history) > self.max_history_length:             # :285-288
                 self.history.popleft()
             if rank == 0:
@@ -174,10 +192,31 @@ class Coach:
             report.append({"iteration": iteration, "samples": int(allv.shape[0]), "nwins": nwins, "pwins": pwins,
                            "draws": draws, "accepted": accepted, "losses": losses, "model_id": model_id,
                            "seconds": {"selfplay": t_play, "train": t_train, "arena": t_arena}})
+            # a long run moves to a new model id per accepted iteration: drop the slot nobody will read again
+            if free is not None:
+                free(model_id if accepted else model_id + 1)
             if accepted:
                 model_id += 1
-        self.model_id = model_id
+            if rank == 0:
+                write_state(self.dir, iteration, model_id)
+            self.model_id = model_id
         return report
+
+
+def write_state(directory, iteration, model_id):
+    tmp = os.path.join(directory, "coach.state.tmp")
+    with open(tmp, "w") as f:
+        f.write(f"{int(iteration)} {int(model_id)}\n")
+    os.replace(tmp, os.path.join(directory, "coach.state"))
+
+
+def read_state(directory):
+    """(iteration, model_id) of <dir>/coach.state, or None."""
+    try:
+        a, b = open(os.path.join(directory, "coach.state")).read().split()
+        return int(a), int(b)
+    except (OSError, ValueError):
+        return None
 
 
 def states_to_boards(states):

@@ -1,11 +1,16 @@
-"""NNet::train (src/nnet.rs:38) for the policy+value net -- SURVEY.md section 8(f2), first tier.
+"""PyTorch autograd RESTATEMENT of NNet::train (src/nnet.rs:38) -- a checker and a stand-in, not the product trainer.
 
-The reference's training code is Python (TensorFlow 1.x, examples/connect_four_lib/connect_four_net.py:102-151,
-internally broken: B11); only its recipe is taken: loss = softmax cross-entropy(pi) + mean squared error(v)
-(:104-108), Adam with lr 1e-3 (:21, :112), dropout 0.3 on the two FC layers (:15, :72-89), BatchNorm in training
-mode (:39-77), batch 64 (:14), 10 epochs (:13).  This tier runs the backward pass with PyTorch-ROCm on the GPU
-(autograd over the same parameter vector and layout as the engine's weights file); the hand-written MFMA
-forward in csrc/az_net.hip is what self-play and the arena use.  Hand-written backward kernels are the next step.
+The product's NNet::train is `az_net_train` (csrc/az_train.hip: f32 MFMA forward/backward/Adam kernels behind the C ABI).
+This module states the same recipe in plain PyTorch on the engine's parameter layout; it is what the CPU tests' fake
+engine trains with (tests/test_coach_cpu.py: there is no GPU, hence no az_net_train), the yardstick of
+tools/train_bench_torch.py, and an optional `trainer=` for Coach.setup.  The recipe is the reference's (TensorFlow 1.x,
+examples/connect_four_lib/connect_four_net.py:102-151, internally broken: B11): loss = softmax cross-entropy(pi) + mean
+squared error(v) (:104-108), Adam with lr 1e-3 (:21, :112), dropout 0.3 on the two FC layers (:15, :72-89), BatchNorm in
+training mode (:39-77), batch 64 (:14), 10 epochs (:13).
+
+Several ranks: REPLICAS.  Every rank holds the same all-gathered samples and draws the same batches and dropout masks from
+the same seeds, so every rank computes the same step and ends with the same weights -- no gradient exchange (splitting the
+recipe's batch of 64 over ranks would make each step's GEMMs smaller and add a 43 MB all-reduce per ~1.5 ms step).
 """
 import numpy as np
 import torch
@@ -97,15 +102,12 @@ class Trainer:
     """NNet::train(examples, previous_model_id, model_id): starts from the previous model's weights, returns the new
     model's flat parameters (the caller uploads them under `model_id` with az_net_set_params)."""
 
-    def __init__(self, channels=512, lr=1e-3, batch_size=64, epochs=10, dropout=0.3, device=None, group=None):
+    def __init__(self, channels=512, lr=1e-3, batch_size=64, epochs=10, dropout=0.3, device=None):
         self.C, self.lr, self.batch_size, self.epochs, self.dropout = channels, lr, batch_size, epochs, dropout
         self.device = device or (torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
-        self.group = group          # torch.distributed group: gradients are all-reduced (DP) when world > 1
         self.history = []
 
     def train(self, prev_params, boards, pis, vs, seed=0):
-        import torch.distributed as dist
-        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         torch.manual_seed(seed)                  # dropout masks (batches use their own generator below)
         net = PolicyValueNet(self.C, prev_params, self.device)
         net.train()
@@ -125,15 +127,6 @@ class Trainer:
                 lp, lv = loss_fn(logits, v, P[idx], V[idx])
                 opt.zero_grad(set_to_none=True)
                 (lp + lv).backward()
-                if ddp:   # data-parallel: one bucketed all-reduce of the flattened gradients per step (43 MB fp32)
-                    grads = [p.grad for p in net.parameters() if p.grad is not None]
-                    flat = torch.cat([g.reshape(-1) for g in grads])
-                    dist.all_reduce(flat, group=self.group)
-                    flat /= dist.get_world_size(self.group)
-                    o = 0
-                    for g in grads:
-                        g.copy_(flat[o:o + g.numel()].reshape(g.shape))
-                        o += g.numel()
                 opt.step()
                 tot[0] += lp.item()
                 tot[1] += lv.item()

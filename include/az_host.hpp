@@ -294,7 +294,22 @@ class Coach {
             if (ent.path().extension() != ".examples" || stem.empty() || stem.find_first_not_of("0123456789") != std::string::npos) continue;
             best = std::max(best, std::stol(stem));
         }
-        if (best >= 0) { c.load_train_examples((size_t)best); c.start_iteration = (size_t)best + 1; }
+        if (best >= 0) {
+            c.load_train_examples((size_t)best);
+            c.start_iteration = (size_t)best + 1;
+            // <dir>/coach.state = "iteration model_id": the accepted model after that iteration's gate; load it so the
+            // restarted run continues from the live weights
+            long it = -1, mid = -1;
+            if (FILE* f = std::fopen((c.dir_ + "/coach.state").c_str(), "r")) {
+                if (std::fscanf(f, "%ld %ld", &it, &mid) != 2) it = -1;
+                std::fclose(f);
+            }
+            if (it == best && mid >= 0) {
+                c.model_id = (size_t)mid;
+                const std::string w = c.dir_ + "/" + std::to_string(mid) + ".aznet";
+                if (fs::exists(w)) e.check(az_net_load(e.raw(), (int32_t)mid, w.c_str()));
+            }
+        }
         return c;
     }
 
@@ -350,19 +365,26 @@ class Coach {
 
     // Coach::learn(skip_first_play), src/coach.rs:169-396.  Engine model slots: `model_id` is the current net,
     // `model_id + 1` the candidate.
-    std::vector<Report> learn(bool skip_first_play, uint64_t seed, size_t model_id = 0) {
+    static constexpr size_t RESUMED = (size_t)-1;     // learn(): continue from the live model of the resumed run (else 0)
+    std::vector<Report> learn(bool skip_first_play, uint64_t seed, size_t model_id = RESUMED) {
         std::vector<Report> report;
+        if (model_id == RESUMED) model_id = this->model_id;
+        {   // the run's initial model: what a restart would load
+            const std::string w = dir_ + "/" + std::to_string(model_id) + ".aznet";
+            if (!std::filesystem::exists(w)) e_.check(az_net_save(e_.raw(), (int32_t)model_id, w.c_str()));
+        }
         for (size_t iteration = start_iteration; iteration < start_iteration + num_iters; ++iteration) {
+            HistoryEntry h;
             if (!skip_first_play || iteration > start_iteration) {
-                HistoryEntry h = execute_episodes(model_id, iteration, seed);
+                h = execute_episodes(model_id, iteration, seed);
                 if (h.len() > max_queue_length) {                   // keep the newest max_queue_length (:275-277)
                     const size_t drop = h.len() - max_queue_length;
                     h.boards.erase(h.boards.begin(), h.boards.begin() + (std::ptrdiff_t)(drop * 84));
                     h.pis.erase(h.pis.begin(), h.pis.begin() + (std::ptrdiff_t)(drop * 7));
                     h.vs.erase(h.vs.begin(), h.vs.begin() + (std::ptrdiff_t)drop);
                 }
-                history.push_back(std::move(h));
             }
+            history.push_back(std::move(h));                                    // :282: pushed even when the play was skipped
             if (history.size() > max_history_length) history.pop_front();      // :285-288
             save_train_examples(iteration);                                       // :291-293
             size_t n = 0;
@@ -397,10 +419,20 @@ class Coach {
             std::printf("NEW/PREV WINS : %zu / %zu; DRAWS : %zu\n", r.nwins, r.pwins, r.draws);        // :381
             r.accepted = !(r.pwins + r.nwins == 0 || (float)r.nwins / (float)(r.pwins + r.nwins) < update_threshold);   // :383-390
             std::printf(r.accepted ? "ACCEPTING NEW MODEL\n" : "REJECTING NEW MODEL\n");
+            // a long run moves to a new model id per accepted iteration: drop the slot nobody will read again
+            e_.check(az_net_free(e_.raw(), (int32_t)(r.accepted ? model_id : model_id + 1)));
             if (r.accepted) ++model_id;
+            {
+                const std::string tmp = dir_ + "/coach.state.tmp";
+                if (FILE* f = std::fopen(tmp.c_str(), "w")) {
+                    std::fprintf(f, "%zu %zu\n", iteration, model_id);
+                    std::fclose(f);
+                    std::filesystem::rename(tmp, dir_ + "/coach.state");
+                }
+            }
+            this->model_id = model_id;
             report.push_back(std::move(r));
         }
-        this->model_id = model_id;
         return report;
     }
 

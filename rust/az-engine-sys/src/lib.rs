@@ -1,18 +1,30 @@
-//! Raw bindings of include/az_engine.h plus a safe `Mi355xNNet` implementing the reference's `NNet` trait shape
-//! (src/nnet.rs:35-45) and helpers that replace the self-play fan-out (src/coach.rs:241-272) and the arena gate
+//! Raw bindings of include/az_engine.h (EVERY exported entry point, checked against the header by
+//! tests/test_abi_cpu.py) plus a safe `Mi355xNNet` with the reference's `NNet` trait surface (src/nnet.rs:35-45:
+//! `new`, `predict`, `train`), an `Mi355xMcts` with `AsyncMcts`'s (`default`, `from_state`, `get_action_prob`,
+//! src/async_mcts.rs:27-115), and helpers that replace the self-play fan-out (src/coach.rs:241-272) and the arena gate
 //! (src/coach.rs:333-390) with one engine call each.  NOT compiled in this repository (no Rust toolchain here).
 #![allow(non_camel_case_types)]
 use std::ffi::{CStr, CString};
 use std::os::raw::{c_char, c_int};
 use std::path::Path;
 
-use ndarray::{Array1, Array2, ArrayViewD};
+use ndarray::{Array1, Array2, ArrayView1, ArrayView2, ArrayViewD};
 
 #[repr(C)] pub struct az_engine { _p: [u8; 0] }
 #[repr(C)] pub struct az_tree { _p: [u8; 0] }
 
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct az_config { pub device: i32, pub max_batch: i32, pub net_channels: i32, pub profile: i32 }
+
+#[repr(C)] #[derive(Default, Clone, Copy)]
+pub struct az_stats {
+    pub games: u64, pub moves: u64, pub simulations: u64, pub expansions: u64, pub leaf_evals: u64,
+    pub link_hits: u64, pub terminal_hits: u64, pub depth_sum: u64, pub samples: u64, pub net_launches: u64,
+    pub net_conv2_ms: f64, pub net_conv2_flops: f64, pub net_total_ms: f64, pub net_total_flops: f64,
+    pub tree_ms: f64, pub tree_bytes: f64, pub device_ms: f64,
+    pub leaf_rows_requested: u64, pub leaf_rows_executed: u64, pub eval_cache_hits: u64, pub eval_batch_dups: u64,
+    pub eval_cache_inserts: u64, pub tree_arena_allocs: u64,
+}
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct az_selfplay_params {
@@ -33,30 +45,43 @@ pub struct az_arena_params {
 }
 
 extern "C" {
+    // ---- lifecycle
     pub fn az_create(cfg: *const az_config, out: *mut *mut az_engine) -> c_int;
     pub fn az_destroy(e: *mut az_engine);
     pub fn az_last_error(e: *const az_engine) -> *const c_char;
     pub fn az_set_option(e: *mut az_engine, key: *const c_char, value: i64) -> c_int;
+    pub fn az_get_stats(e: *mut az_engine, out: *mut az_stats) -> c_int;
+    pub fn az_reset_stats(e: *mut az_engine) -> c_int;
+    // ---- NNet trait, src/nnet.rs:35-45
     pub fn az_net_set_kind(e: *mut az_engine, model_id: i32, kind: c_int, salt: u64) -> c_int;
+    pub fn az_net_free(e: *mut az_engine, model_id: i32) -> c_int;
     pub fn az_net_init_random(e: *mut az_engine, model_id: i32, seed: u64) -> c_int;
     pub fn az_net_load(e: *mut az_engine, model_id: i32, path: *const c_char) -> c_int;
     pub fn az_net_save(e: *mut az_engine, model_id: i32, path: *const c_char) -> c_int;
     pub fn az_net_param_count(e: *const az_engine) -> i64;
     pub fn az_net_set_params(e: *mut az_engine, model_id: i32, params: *const f32, n: i64) -> c_int;
     pub fn az_net_get_params(e: *mut az_engine, model_id: i32, params: *mut f32, n: i64) -> c_int;
-    pub fn az_net_predict(e: *mut az_engine, model_id: i32, boards: *const f32, b: i32, pi: *mut f32, v: *mut f32) -> c_int;
+    pub fn az_net_predict(e: *mut az_engine, model_id: i32, boards: *const f32, B: i32, pi: *mut f32, v: *mut f32) -> c_int;
+    pub fn az_net_predict_states(e: *mut az_engine, model_id: i32, states: *const u64, B: i32, pi: *mut f32, v: *mut f32) -> c_int;
     pub fn az_net_train(e: *mut az_engine, prev_id: i32, id: i32, boards: *const f32, pis: *const f32, vs: *const f32, n: i64) -> c_int;
     pub fn az_net_train_history(e: *const az_engine, out: *mut f32, cap_epochs: i32) -> i32;
     pub fn az_net_train_begin(e: *mut az_engine, prev_id: i32) -> c_int;
     pub fn az_net_train_step(e: *mut az_engine, boards: *const f32, pis: *const f32, vs: *const f32, b: i32, mask_seed: u64,
                              apply: i32, loss_out: *mut f32, grads_out: *mut f32) -> c_int;
     pub fn az_net_train_end(e: *mut az_engine, model_id: i32) -> c_int;
+    // ---- AsyncMcts, src/async_mcts.rs:14-115
     pub fn az_tree_create(e: *mut az_engine, n_games: i32, reserve: u64, num_sims: i32, max_depth: i32,
                           model_id: i32, cpuct: i32, out: *mut *mut az_tree) -> c_int;
     pub fn az_tree_destroy(t: *mut az_tree);
+    pub fn az_tree_reset(t: *mut az_tree, root_states: *const u64) -> c_int;
     pub fn az_tree_get_action_prob(t: *mut az_tree, states: *const u64, temp: f32, seed: u64, first_game_id: u64,
                                    pi: *mut f32, counts: *mut u16, q: *mut f32) -> c_int;
+    pub fn az_tree_record_evals(t: *mut az_tree, cap: i32) -> c_int;
+    pub fn az_tree_get_evals(t: *mut az_tree, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;
+    pub fn az_tree_node_counts(t: *mut az_tree, out: *mut u32) -> c_int;
+    // ---- Coach::execute_episode x many, src/coach.rs:104-157; arena::play_games, src/arena.rs:62-99
     pub fn az_selfplay(e: *mut az_engine, p: *const az_selfplay_params, out: *mut az_samples) -> c_int;
+    pub fn az_selfplay_get_evals(e: *mut az_engine, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;
     pub fn az_arena(e: *mut az_engine, p: *const az_arena_params, out_wld: *mut u64, results: *mut i8) -> c_int;
 }
 
@@ -87,8 +112,55 @@ impl Mi355xNNet {
         check(self.e, unsafe { az_net_predict(self.e, model_id as i32, x.as_ptr(), b as i32, pi.as_mut_ptr(), v.as_mut_ptr()) });
         (pi, v)
     }
+    /// NNet::train(examples = (boards [N,2,6,7], pis [N,7], vs [N]), previous_model_id, model_id), src/nnet.rs:38:
+    /// the reference's recipe on the device (f32 MFMA trainer), result stored under model_id.
+    pub fn train(&mut self, boards: ArrayViewD<f32>, pis: ArrayView2<f32>, vs: ArrayView1<f32>, previous_model_id: usize, model_id: usize) {
+        let (b, p, v) = (boards.as_standard_layout(), pis.as_standard_layout(), vs.as_standard_layout());
+        check(self.e, unsafe { az_net_train(self.e, previous_model_id as i32, model_id as i32, b.as_ptr(), p.as_ptr(), v.as_ptr(), v.len() as i64) });
+    }
+    /// Drop a superseded model id (Coach::learn moves to model_id + 1 per accepted iteration, src/coach.rs:383-390).
+    pub fn free(&mut self, model_id: usize) { check(self.e, unsafe { az_net_free(self.e, model_id as i32) }); }
 }
 impl Drop for Mi355xNNet { fn drop(&mut self) { unsafe { az_destroy(self.e) } } }
+
+/// n x `AsyncMcts<ConnectFourGame>` (src/async_mcts.rs:14-115) as one tree batch on the device.
+pub struct Mi355xMcts { pub e: *mut az_engine, pub t: *mut az_tree, pub n_games: usize }
+
+impl Mi355xMcts {
+    /// AsyncMcts::default(reserve_space, num_sims, 1, max_depth, model_id, cpuct, ..), src/async_mcts.rs:27-48
+    pub fn default(e: *mut az_engine, n_games: usize, reserve_space: usize, num_sims: usize, max_depth: usize, model_id: usize, cpuct: i32) -> Self {
+        let mut t = std::ptr::null_mut();
+        check(e, unsafe { az_tree_create(e, n_games as i32, reserve_space as u64, num_sims as i32, max_depth as i32, model_id as i32, cpuct, &mut t) });
+        Mi355xMcts { e, t, n_games }
+    }
+    /// AsyncMcts::from_state(s, ..), src/async_mcts.rs:50-72: every tree re-rooted at its canonical bitboards [n_games, 2]
+    pub fn from_state(e: *mut az_engine, root_states: &[u64], reserve_space: usize, num_sims: usize, max_depth: usize, model_id: usize, cpuct: i32) -> Self {
+        let m = Self::default(e, root_states.len() / 2, reserve_space, num_sims, max_depth, model_id, cpuct);
+        check(e, unsafe { az_tree_reset(m.t, root_states.as_ptr()) });
+        m
+    }
+    /// get_action_prob(&self, s, temp, episode_id, rng) for every tree, src/async_mcts.rs:74-115: pi [n_games, 7]
+    pub fn get_action_prob(&self, states: &[u64], temp: f32, seed: u64, first_game_id: u64) -> Array2<f32> {
+        let mut pi = Array2::<f32>::zeros((self.n_games, 7));
+        check(self.e, unsafe { az_tree_get_action_prob(self.t, states.as_ptr(), temp, seed, first_game_id, pi.as_mut_ptr(),
+                                                       std::ptr::null_mut(), std::ptr::null_mut()) });
+        pi
+    }
+    /// NodeStore::len per tree, src/node.rs:372-374
+    pub fn node_counts(&self) -> Vec<u32> {
+        let mut out = vec![0u32; self.n_games];
+        check(self.e, unsafe { az_tree_node_counts(self.t, out.as_mut_ptr()) });
+        out
+    }
+}
+impl Drop for Mi355xMcts { fn drop(&mut self) { unsafe { az_tree_destroy(self.t) } } }
+
+/// Counters since az_create / the last reset (SURVEY.md 8b "Introspection").
+pub fn stats(e: *mut az_engine) -> az_stats {
+    let mut s = az_stats::default();
+    check(e, unsafe { az_get_stats(e, &mut s) });
+    s
+}
 
 /// Replaces the rayon fan-out of `execute_episode` (src/coach.rs:241-272): returns (boards [N,2,6,7], pis [N,7], vs [N]).
 pub fn self_play(e: *mut az_engine, p: &az_selfplay_params) -> (Vec<f32>, Vec<f32>, Vec<f32>) {

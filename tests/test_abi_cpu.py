@@ -95,3 +95,82 @@ def test_cpp_host_mirror_rules_and_shuffle(oracle, tmp_path):
     # after 11 plies player -1 is to move: canonical (mine, theirs) = (minus, plus)
     assert (got["canon_plus"], got["canon_minus"]) == s == (got["minus"], got["plus"])
     assert got["valid"] == [(oracle.c4_valid_mask(*s) >> c) & 1 for c in range(7)] and got["features_sum"] == 11
+
+
+# ---- the Rust shim crate (rust/az-engine-sys/src/lib.rs) against the header: it cannot be compiled here, so it is parsed ----
+_C2RUST = {"int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "uint16_t": "u16", "uint8_t": "u8",
+           "int8_t": "i8", "float": "f32", "double": "f64", "char": "c_char", "az_status": "c_int", "az_net_kind": "c_int",
+           "az_engine": "az_engine", "az_tree": "az_tree", "az_config": "az_config", "az_stats": "az_stats",
+           "az_selfplay_params": "az_selfplay_params", "az_samples": "az_samples", "az_arena_params": "az_arena_params"}
+
+
+def _rust_type(ctype):
+    """'const float*' -> '*const f32', 'az_tree**' -> '*mut *mut az_tree', 'uint64_t out_wld[3]' handled by the caller."""
+    c = ctype.strip()
+    const = c.startswith("const ")
+    c = c[6:].strip() if const else c
+    stars = c.count("*")
+    base = _C2RUST[c.replace("*", "").strip()]
+    if stars == 0:
+        return base
+    out = base
+    for i in range(stars):
+        out = ("*const " if (const and i == 0) else "*mut ") + out
+    return out
+
+
+def _header_functions():
+    hdr = open(os.path.join(ROOT, "include", "az_engine.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    fns = {}
+    for ret, name, args in re.findall(r"\b([A-Za-z_0-9]+\s*\**)\s*\b(az_[a-z_]+)\s*\(([^)]*)\)\s*;", hdr):
+        params = []
+        for a in [x.strip() for x in args.split(",") if x.strip()]:
+            m = re.match(r"(.*?)([A-Za-z_0-9]+)(\[\d*\])?$", a)
+            ctype = m.group(1).strip() + ("*" if m.group(3) else "")
+            params.append(_rust_type(ctype))
+        r = ret.replace(" ", "")
+        fns[name] = (None if r == "void" else ("*const c_char" if r in ("char*", "constchar*") else _rust_type(ret)), params)
+    # `const char* az_last_error(...)`: the regex above sees `char*` after `const`
+    return fns
+
+
+def _header_structs():
+    hdr = open(os.path.join(ROOT, "include", "az_engine.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef struct [a-z_]+ \{(.*?)\}\s*([a-z_]+);", hdr, flags=re.S):
+        fields = []
+        for decl in [d.strip() for d in body.split(";") if d.strip()]:
+            m = re.match(r"(.*?)([A-Za-z_0-9]+)$", decl)
+            fields.append((m.group(2), _rust_type(m.group(1))))
+        out[name] = fields
+    return out
+
+
+def test_rust_shim_matches_the_header():
+    """rust/az-engine-sys/src/lib.rs binds every export of include/az_engine.h with the same argument count and types, and
+    its #[repr(C)] structs have the header's fields in the header's order."""
+    src = open(os.path.join(ROOT, "rust", "az-engine-sys", "src", "lib.rs")).read()
+    ext = src[src.index('extern "C" {'):]
+    ext = ext[:ext.index("\n}\n")]
+    ext = re.sub(r"//[^\n]*", "", ext)
+    rust = {}
+    for name, args, ret in re.findall(r"pub fn (az_[a-z_]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", ext, flags=re.S):
+        params = [a.split(":", 1)[1].strip() for a in args.split(",") if a.strip()]
+        rust[name] = (ret.strip() if ret else None, params)
+    hdr = _header_functions()
+    assert sorted(rust) == sorted(hdr) == declared_symbols()
+    for name, (ret, params) in hdr.items():
+        rret, rparams = rust[name]
+        assert rparams == params, (name, rparams, params)
+        assert rret == ret, (name, rret, ret)
+    structs = _header_structs()
+    assert set(structs) == {"az_config", "az_stats", "az_selfplay_params", "az_samples", "az_arena_params"}
+    for sname, fields in structs.items():
+        m = re.search(r"pub struct %s \{(.*?)\}" % sname, src, flags=re.S)
+        rfields = [(n, t.strip()) for n, t in re.findall(r"pub ([a-z_0-9]+):\s*([^,}]+)", m.group(1))]
+        assert rfields == fields, (sname, rfields, fields)
+    # the NNet / AsyncMcts surfaces the reference's callers use
+    for needle in ("pub fn new<P: AsRef<Path>>", "pub fn predict(", "pub fn train(", "pub fn from_state(", "pub fn get_action_prob("):
+        assert needle in src, needle

@@ -59,9 +59,19 @@ class FakeEngine:
     def __init__(self, oracle, C):
         self.oracle, self.C, self.params = oracle, C, {}
         self.calls = []
+        self.freed = {}
+
+    def net_free(self, model_id):
+        self.calls.append(("free", model_id))
+        self.freed[model_id] = self.params.pop(model_id)
+
+    def net_load(self, model_id, path):
+        self.calls.append(("load", model_id))
+        self.params[model_id] = np.fromfile(path, np.float32)
 
     def _salt(self, model_id):
-        return int(np.abs(self.params[model_id]).sum() * 1e3) % (1 << 30)
+        p = self.params[model_id] if model_id in self.params else self.freed[model_id]
+        return int(np.abs(p).sum() * 1e3) % (1 << 30)
 
     def net_get_params(self, model_id):
         return self.params[model_id].copy()
@@ -160,6 +170,31 @@ def test_coach_resume_and_queue_limit(mods, oracle, tmp_path):
     assert rep[0]["iteration"] == 1 and os.path.exists(os.path.join(tmp_path, "1.examples"))
 
 
+def test_coach_state_file_skip_first_play_and_model_slots(mods, oracle, tmp_path):
+    """(1) skip_first_play still pushes an (empty) history entry, as src/coach.rs:282 does, so the replay window ages exactly
+    like the reference's; (2) coach.state names the live model after every gate and a restarted Coach loads it; (3) the model
+    slot nobody will read again (the old net after an accept, the candidate after a reject) is dropped."""
+    coach, trainer = mods
+    c, eng, _ = make_coach(coach, trainer, oracle, str(tmp_path), iters=2, history=3)
+    rep = c.learn(seed=4)
+    assert coach.read_state(str(tmp_path)) == (1, c.model_id)
+    assert os.path.exists(os.path.join(tmp_path, "0.aznet"))                       # the run's initial model
+    frees = [x[1] for x in eng.calls if x[0] == "free"]
+    assert frees == [r["model_id"] if r["accepted"] else r["model_id"] + 1 for r in rep]
+    assert sorted(eng.params) == [c.model_id]                                      # exactly the live model is resident
+    # restart: resumes at iteration 2 with the live model loaded from its checkpoint, first play skipped
+    c2, eng2, _ = make_coach(coach, trainer, oracle, str(tmp_path), iters=2, history=3)
+    assert c2.start_iteration == 2 and c2.model_id == c.model_id and ("load", c.model_id) in eng2.calls
+    assert np.array_equal(eng2.params[c.model_id], eng.params[c.model_id])
+    n_before = len(c2.history)
+    rep2 = c2.learn(skip_first_play=True, seed=4)
+    sp = [x for x in eng2.calls if x[0] == "selfplay"]
+    assert len(sp) == 1 and sp[0][2] == 3 * 5                                      # only iteration 3 played (global ids 15..)
+    z2 = coach.load_examples(os.path.join(tmp_path, "2.examples"))
+    assert len(z2) == min(3, n_before + 1) and z2[-1][2].shape[0] == 0            # the skipped play left an empty entry
+    assert rep2[0]["iteration"] == 2 and rep2[0]["model_id"] == c.model_id
+
+
 def test_setup_contracts(mods, oracle, tmp_path):
     coach, trainer = mods
     eng = FakeEngine(oracle, 16)
@@ -197,7 +232,7 @@ def _coach_rank(rank, world, port, tmp, q):
     from test_coach_cpu import make_coach
     c, eng, _ = make_coach(coach, trainer, orc, os.path.join(tmp, f"rank{rank}"), iters=1)
     rep = c.learn(seed=4)
-    q.put((rank, rep[0]["samples"], c.history[0][0].copy(), c.history[0][1].copy(), c.history[0][2].copy(), eng.params[1].copy(),
+    q.put((rank, rep[0]["samples"], c.history[0][0].copy(), c.history[0][1].copy(), c.history[0][2].copy(), eng.params.get(1, eng.freed.get(1)).copy(),
            [x for x in eng.calls if x[0] == "selfplay"], (rep[0]["nwins"], rep[0]["pwins"], rep[0]["draws"]),
            [x for x in eng.calls if x[0] == "arena"]))
     dist.barrier()
@@ -230,7 +265,7 @@ def test_coach_two_ranks_match_single_process(mods, oracle, tmp_path):
         assert n == rep[0]["samples"]
         assert np.array_equal(boards, c.history[0][0]) and np.array_equal(pis, c.history[0][1]) and np.array_equal(vs, c.history[0][2])
         # identical data + identical batches + averaged gradients -> the same weights as one process
-        assert np.allclose(params, eng.params[1], atol=1e-5)
+        assert np.allclose(params, eng.params.get(1, eng.freed.get(1)), atol=1e-5)
     # the 5 episodes were sharded 3 + 2 by global id
     assert got[0][6] == [("selfplay", 3, 0, 0)] and got[1][6] == [("selfplay", 2, 3, 0)]
 

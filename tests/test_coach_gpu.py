@@ -52,6 +52,46 @@ def test_python_and_cpp_coach_agree(engine_mod, tmp_path):
     assert any(m.startswith("NEW/PREV WINS : ") for m in msgs)
 
 
+def _has_model(e, k):
+    try:
+        e.net_get_params(k)
+        return True
+    except Exception:
+        return False
+
+
+def test_coach_resume_is_byte_identical(engine_mod, tmp_path):
+    """Kill after iteration 0, restart in a fresh engine, run iteration 1: the examples file, the candidate's weights and
+    the state file are byte-identical to an uninterrupted two-iteration run (the live model comes back from
+    <id>.aznet + coach.state; self-play, shuffle, NNet::train and the arena are deterministic functions of the seed)."""
+    from alphazero_rs_amd.coach import Coach
+    C, seed = 128, 23
+    args = (1000000, 0.55, 15, 3, 100000, 1, 64, 16)
+    tail = (40, 25, 1, 1000, 1)
+
+    def run(directory, iters, init_seed):
+        e = engine_mod.Engine(device=0, max_batch=256, net_channels=C)
+        try:
+            e.net_init_random(0, init_seed)
+            e.set_option("train_epochs", 1)
+            c = Coach.setup(e, directory, *args, iters, *tail, log=lambda m: None)
+            return c.learn(seed=seed), c.model_id
+        finally:
+            e.close()
+
+    da, db = os.path.join(tmp_path, "a"), os.path.join(tmp_path, "b")
+    rep_a, mid_a = run(da, 2, 3)
+    run(db, 1, 3)
+    rep_b, mid_b = run(db, 1, 999)          # a different random init: the restart must take the live model from the checkpoint
+    assert rep_b[0]["iteration"] == 1 and mid_a == mid_b
+    for k in ("samples", "nwins", "pwins", "draws", "accepted", "model_id", "losses"):
+        assert rep_a[1][k] == rep_b[0][k], k
+    assert sorted(os.listdir(da)) == sorted(os.listdir(db))
+    for f in sorted(os.listdir(da)):
+        with open(os.path.join(da, f), "rb") as x, open(os.path.join(db, f), "rb") as y:
+            assert x.read() == y.read(), f
+
+
 def test_coach_learn_on_gpu(engine_mod, tmp_path):
     from alphazero_rs_amd.coach import Coach
     from alphazero_rs_amd.trainer import Trainer
@@ -71,6 +111,12 @@ def test_coach_learn_on_gpu(engine_mod, tmp_path):
             assert all(np.isfinite(l[0]) and np.isfinite(l[1]) for l in r["losses"])
         assert os.path.exists(os.path.join(tmp_path, "0.examples")) and os.path.exists(os.path.join(tmp_path, "1.examples"))
         assert os.path.exists(os.path.join(tmp_path, "1.aznet"))
+        # the loop keeps only the live model resident (the superseded slot is freed): reload both from their checkpoints
+        live = coach.model_id
+        assert sorted(k for k in (0, 1, 2) if _has_model(e, k)) == [live]
+        e.net_load(0, os.path.join(tmp_path, "0.aznet"))
+        e.net_load(1, os.path.join(tmp_path, "1.aznet"))
+        assert np.array_equal(e.net_get_params(0), p0)
         # the candidate differs from its parent and predicts through the MFMA net like any other model
         p1 = e.net_get_params(1)
         assert p1.shape == p0.shape and not np.array_equal(p1, p0)
