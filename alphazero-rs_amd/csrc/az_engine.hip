@@ -192,6 +192,7 @@ struct az_engine {
     std::vector<float> train_history;              // (loss_pi, loss_v) mean per epoch of the last az_net_train
     // leaf de-duplication + evaluation cache (az_set_option "eval_dedup", "eval_cache_log2", "eval_cache_max_stones",
     // "eval_cache_persist")
+    int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
     int eval_cache_log2 = 26;       // entries = 2^log2 (40 B each: 2.7 GB); 0 = no cache, in-batch de-duplication only
     int eval_cache_max_stones = 42;
@@ -343,6 +344,14 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
     if (!s) s = e->stream;
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
     const bool dedup = dedup_applies(e, net);
+    if (net.kind != AZ_NET_CONV && !dedup && e->fused_search) {
+        // stub / hash nets are device functions of the state: the whole search is one launch
+        hipEvent_t t0 = nullptr;
+        if (e->prof.on) t0 = e->prof.begin(s);
+        launch_search_fixture(th.d, d_root_states, sp, num_sims, net.kind, net.salt, s);
+        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
+        return;
+    }
     const EvalCache ec = cache_for(e, net);
     // every launch that requests leaves gets its own election-table epoch (15 bits; stale keys could look current again
     // after a wrap, so the tables are cleared then)
@@ -366,9 +375,8 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
         if (e->prof.on) t0 = e->prof.begin(s);
         B[(i + 1) & 1].epoch = next_epoch();
         launch_backup_select(th.d, B[i & 1], B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
-        if (e->prof.on) { e->prof.end(t0, RG_TREE, s); t0 = e->prof.begin(s); }
+        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
         net_forward(e, net, B[(i + 1) & 1], rows_hint, s);
-        if (e->prof.on) e->prof.end(t0, RG_NET, s);
     }
     hipEvent_t t0 = nullptr;
     if (e->prof.on) t0 = e->prof.begin(s);
@@ -501,10 +509,13 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = buf;       // returned through az_last_error
         return AZ_OK;
     }
+    if (std::strcmp(key, "fused_search") == 0 && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_dedup") == 0 && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_log2") == 0 && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_max_stones") == 0 && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_persist") == 0 && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "fc_ring") == 0 && value >= 0 && value <= 2) { convnet_set_fc_ring((int)value); return AZ_OK; }
+    if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv1_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv1_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {
         convnet_set_conv4_big((int)value);

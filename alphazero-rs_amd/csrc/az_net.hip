@@ -298,6 +298,115 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
     }
 }
 
+// ---- 128x128 tile, LDS-DMA RING: the small-grid layers (fc1, fc2; conv4 on small batches) ---------------------------
+// fc1 (M = leaves, N = 1024, K = 3072) has 176 tiles at 2700 leaves and fc2 88: fewer workgroups than CUs, so k_gemm_mfma
+// runs one 4-wave workgroup per CU and every K-step exposes a full L2 / HBM round trip between its global loads and the
+// barrier that publishes them (~1 us per step, 48 steps: the kernel is latency-bound at 19 % of the MFMA peak).  Same tile,
+// same per-row K order (bit-identical), but the operands go global -> LDS with global_load_lds into a ring of NS stages
+// (32 KiB each, 128 KiB at NS = 4: the LDS an under-filled CU has to spare), NS-1 stages in flight, retired with a COUNTED
+// s_waitcnt (never 0 inside the loop) and one raw barrier per step.
+template <int LAYER, int NS>
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * 32768];      // [stage][A 128 x 128 B | W 128 x 128 B]
+    const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int ntaps = d.K / d.cin;
+    const int NT = d.N / GBN;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int m0 = mtile * GBM, n0 = ntile * GBN;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // DMA map: piece q (0..3) of wave w fills tile rows (q*4 + w)*8 .. +7 of both operands; lane -> row lane>>3, slot lane&7
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    uint32_t a_ob[4], b_ob[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int m = m0 + (q * 4 + wave) * 8 + lrow;
+        m = m < M ? m : M - 1;
+        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
+        const int y = r / d.out_w, x = r - y * d.out_w;
+        a_ob[q] = (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8) * 2u;
+        b_ob[q] = (uint32_t)((n0 + (q * 4 + wave) * 8 + lrow) * d.K + chunk * 8) * 2u;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    // K-step walker (channel block outer, tap inner), scalars only
+    int ks_tap = 0, ks_kx = 0;
+    uint32_t ks_c0 = 0, ks_toff = 0, ks_kk = 0;
+#define AZ_RDMA(buf_)                                                                                   \
+    {                                                                                                   \
+        const char* abase = (const char*)(d.A + ks_toff);                                               \
+        const char* wbase = (const char*)(d.W + ks_kk);                                                 \
+        unsigned char* la = smem + (buf_) * 32768 + wave * 1024;                                        \
+        unsigned char* lb = la + 16384;                                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob[q_]), (lds_ptr)(lb + q_ * 4096), 16, 0, 0); \
+        ++ks_tap; ++ks_kx; ks_toff += (uint32_t)d.in_c; ks_kk += (uint32_t)d.cin;                       \
+        if (ks_kx == d.tap_w) { ks_kx = 0; ks_toff += (uint32_t)((d.in_w - d.tap_w) * d.in_c); }        \
+        if (ks_tap == ntaps) { ks_tap = 0; ks_kx = 0; ks_c0 += GBK; ks_toff = ks_c0; ks_kk = ks_c0; }   \
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = d.K / GBK;
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) AZ_RDMA(st);
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt must have landed; up to NS-2 younger stages (8 DMA instructions each) may stay in flight
+        const int younger = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // raw: every wave is also done with stage kt-1's buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NS - 1 < nk) AZ_RDMA((kt + NS - 1) % NS);
+        const unsigned char* sA = smem + (kt % NS) * 32768;
+        const unsigned char* sB = sA + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ fsw) << 4;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * 64 + mt * 16 + frow) * 128 + coff);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+#undef AZ_RDMA
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wr * 64 + mt * 16 + frow;
+            if (m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
 // ---- 256x256 tile variant for the big layers (conv2, conv3): LDS-DMA staging ------------------------------
 // 8 waves (2 x 4), each wave a 128(m) x 64(n) sub-tile = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16.
 // Both operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write): one wave-instruction
@@ -999,8 +1108,10 @@ constexpr int C3_NB = 12;     // (conv4 as <L, 19, 4, 5, 4> is bit-identical too
 // ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
 // one wave per sample; lane holds 8 of the 512 inputs.
 __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_t* __restrict__ x /*[n][512] bf16*/,
-                                               const float* __restrict__ w /*[8][512]*/, const float* __restrict__ bias /*[8]*/) {
+                                               const float* __restrict__ w /*[8][512]*/, const float* __restrict__ bias /*[8]*/,
+                                               uint32_t* __restrict__ n_log /*profile mode: this forward's row count, else nullptr*/) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (n_log && blockIdx.x == 0 && threadIdx.x == 0) *n_log = *eb.n;
     if ((uint32_t)wave >= *eb.n) return;
     const uint4 xv = *(const uint4*)(x + (size_t)wave * 512 + lane * 8);
     float xf[8];
@@ -1069,7 +1180,8 @@ struct NetWorkspace {
     struct Rec { hipEvent_t e0, e1, e2, e3; uint32_t* n; };
     std::vector<Rec> open;
     std::vector<hipEvent_t> ev_pool;
-    uint32_t* pinned_n = nullptr;
+    uint32_t* pinned_n = nullptr;          // host copy of d_nlog (one copy per resolve, not one per forward)
+    uint32_t* d_nlog = nullptr;            // [pinned_cap] row count of every timed forward, written by its k_heads
     int pinned_cap = 0, pinned_next = 0;
     unsigned long long* dbg = nullptr;     // [2048] clock stamps of the diagnostic variant
     template <class T> T* dalloc(size_t n) {
@@ -1128,6 +1240,7 @@ NetWorkspace* netws_create(int channels, int max_batch, const char** err) {
     ok &= (n->dbg = n->dalloc<unsigned long long>(2048)) != nullptr;
     if (ok) ok = hipMemset(n->dbg, 0, 2048 * 8) == hipSuccess;
     if (ok) ok = hipHostMalloc((void**)&n->pinned_n, 4096 * sizeof(uint32_t)) == hipSuccess;
+    ok &= (n->d_nlog = n->dalloc<uint32_t>(4096)) != nullptr;
     n->pinned_cap = 4096;
     if (!ok) {
         if (err) *err = "netws_create: device allocation failed";
@@ -1257,6 +1370,8 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants
                           // git history): 4-stage ring, XCD column remap, third weight buffer, late / spread DMA issue, mid
                           // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
                           // split, cross-step fragment prefetch, weights straight into registers.
+int g_fc_ring = 1;        // 128x128 LDS-DMA ring kernel for under-filled grids (az_set_option "fc_ring"); bit-identical
+int g_ring_max_tiles = 256;   // ... when the layer has at most this many tiles ("ring_max_tiles")
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
 
 template <int LAYER>
@@ -1296,6 +1411,14 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
     const int mt8 = (mt + 7) / 8 * 8;
     const int grid = mt8 * (d.N / GBN);
+    // under-filled grids (fewer tiles than ~2 per CU) are latency-bound: the LDS-DMA ring hides the round trips
+    // LDS-DMA ring instead of register staging (bit-identical).  A grid that fits one round of one workgroup per CU is
+    // latency / fetch bound: 4 stages (128 KiB) in flight; otherwise 2 stages (64 KiB) so that two workgroups share a CU.
+    if (v == 5 && g_fc_ring) {
+        if (mt * (d.N / GBN) <= g_ring_max_tiles && (LAYER >= 4 || g_fc_ring == 2)) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(grid), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);
+        return;
+    }
     hipLaunchKernelGGL(k_gemm_mfma<LAYER>, dim3(grid), dim3(256), 0, s, d);
 }
 
@@ -1312,6 +1435,8 @@ void netws_resolve_profile(NetWorkspace* n, NetProfile* prof) {
     const int C = n->C;
     const double f_conv = 2.0 * 9.0 * C * C;
     const double per_sample = 2.0 * (42.0 * 18 * C) + f_conv * (42 + 20 + 6) + 2.0 * (6.0 * C * 1024 + 1024.0 * 512 + 512.0 * 8);
+    if (!n->open.empty() && hipMemcpy(n->pinned_n, n->d_nlog, (size_t)n->pinned_next * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        prof = nullptr;
     for (auto& r : n->open) {
         float conv2 = 0, total = 0;
         if (hipEventElapsedTime(&conv2, r.e1, r.e2) == hipSuccess && hipEventElapsedTime(&total, r.e0, r.e3) == hipSuccess && prof) {
@@ -1333,6 +1458,8 @@ bool netws_read_clock_stamps(NetWorkspace* n, unsigned long long* out2048) {
     return n && hipMemcpy(out2048, n->dbg, 2048 * 8, hipMemcpyDeviceToHost) == hipSuccess;
 }
 void convnet_set_conv4_big(int v) { g_conv4_big = v; }
+void convnet_set_fc_ring(int v) { g_fc_ring = v; }
+void convnet_set_ring_max_tiles(int v) { g_ring_max_tiles = v; }
 int g_conv1_table = 1;    // conv2 gathers its image from the conv1 table (default kernel set only); 0 = run k_conv1 into act1
 void convnet_set_conv1_table(int v) { g_conv1_table = v; }
 
@@ -1341,11 +1468,12 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     if (rows_hint > ws->max_batch) rows_hint = ws->max_batch;
     if (rows_hint <= 0) return;
     NetWorkspace::Rec rec{};
+    uint32_t* n_log = nullptr;
     const bool timed = prof != nullptr && ws->pinned_next < ws->pinned_cap;
     if (timed) {
         rec.e0 = net_event(ws); rec.e1 = net_event(ws); rec.e2 = net_event(ws); rec.e3 = net_event(ws);
-        rec.n = ws->pinned_n + ws->pinned_next++;
-        (void)hipMemcpyAsync(rec.n, eb.n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        rec.n = ws->pinned_n + ws->pinned_next;
+        n_log = ws->d_nlog + ws->pinned_next++;
         (void)hipEventRecord(rec.e0, s);
     }
     // conv1 + conv2: the default kernel set gathers conv2's image from the conv1 table; the others run conv1 into act1
@@ -1385,7 +1513,7 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.A = ws->fc1o; d.W = n->wg[4]; d.bias = n->bg[4]; d.out = ws->fc2o;
     d.in_c = 1024; d.cin = 1024; d.K = 1024; d.N = 512;
     launch_gemm<5>(d, rows_hint, s);
-    hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, ws->fc2o, n->wh, n->bh);
+    hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, ws->fc2o, n->wh, n->bh, n_log);
     if (timed) {
         (void)hipEventRecord(rec.e3, s);
         ws->open.push_back(rec);

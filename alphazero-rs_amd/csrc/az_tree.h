@@ -152,6 +152,10 @@ void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, i
 // backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf requested in eb_next) in one launch
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s);
+// the whole search (root prepare + num_sims simulations + backups) in one launch for the device-function nets
+// (kind 0 = stub, 1 = hash fixture): no leaf batch, no kernel boundary per simulation
+void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind, uint64_t salt,
+                           hipStream_t s);
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s);
 // sums the trees' counters into totals[ST_COUNT] (u64, accumulated) and clears them; node_counts [G] may be nullptr

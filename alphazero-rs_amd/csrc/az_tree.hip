@@ -190,6 +190,10 @@ AZ_D uint32_t leaf_request(const EvalBatch& eb, const EvalCache& ec, bool want, 
     uint32_t tpos = 0;
     if (eb.dedup) {
         const unsigned long long key = (unsigned long long)G::pack(s);
+        // the election table's first probe is fetched together with the cache's key line (one round trip, not two)
+        const uint32_t pos0 = (uint32_t)(mix64(key) >> 24) & eb.tmask;
+        unsigned long long cur0 = 0ull;
+        if (want && sub == 0) cur0 = eb.tkey[pos0];
         if (ec.key) {
             const unsigned long long ck = key | ec.tag;
             const uint32_t bucket = (uint32_t)(mix64(ck) >> 20) & ec.bmask;
@@ -198,14 +202,13 @@ AZ_D uint32_t leaf_request(const EvalBatch& eb, const EvalCache& ec, bool want, 
         }
         if (take && sub == 0) {
             const unsigned long long mine = key | ((unsigned long long)eb.epoch << 49);
-            uint32_t pos = (uint32_t)(mix64(key) >> 24) & eb.tmask;
-            for (;;) {
-                unsigned long long cur = eb.tkey[pos];
+            uint32_t pos = pos0;
+            unsigned long long cur = cur0;
+            for (;; cur = eb.tkey[pos]) {
                 if ((cur >> 49) != (unsigned long long)eb.epoch) {          // empty or stale: try to take it
                     const unsigned long long prev = atomicCAS(&eb.tkey[pos], cur, mine);
                     if (prev == cur) break;                                // won the slot
-                    cur = prev;                                            // somebody else took it first
-                    if ((cur >> 49) != (unsigned long long)eb.epoch) continue;
+                    cur = prev;                                            // somebody else took it first (in this launch: epoch is current)
                 }
                 if (cur == mine) { dup = true; break; }
                 pos = (pos + 1u) & eb.tmask;
@@ -247,12 +250,7 @@ AZ_D uint32_t leaf_request(const EvalBatch& eb, const EvalCache& ec, bool want, 
 
 // ---- get_action_prob prologue: root lookup (src/async_mcts.rs:81) + S10 + S1 -------------
 template <class G>
-__global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, EvalCache ec, const ulonglong2* root_states) {
-    constexpr int GW = G::GROUP;
-    int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid / GW, sub = tid % GW;
-    if (g >= t.G) return;
-    TreeHead h = head_load(t, g);
+AZ_D typename G::State root_prepare_body(const TreeDev& t, TreeHead& h, const ulonglong2* root_states, int g, int sub) {
     const bool act = h.active != 0;
     size_t base = (size_t)g * t.R;
     typename G::State s = act ? root_states[g] : G::init();
@@ -291,14 +289,25 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, Ev
         h.stat[ST_EXPANSIONS] += n_exp;
     }
     h.leaf_kind = kind;
-    const uint32_t src = leaf_request<G>(eb, ec, kind == LEAF_EVAL, s, sub);
-    if (kind == LEAF_EVAL) h.src = src;
+    return s;
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, EvalCache ec, const ulonglong2* root_states) {
+    constexpr int GW = G::GROUP;
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid / GW, sub = tid % GW;
+    if (g >= t.G) return;
+    TreeHead h = head_load(t, g);
+    const typename G::State s = root_prepare_body<G>(t, h, root_states, g, sub);
+    const uint32_t src = leaf_request<G>(eb, ec, h.leaf_kind == LEAF_EVAL, s, sub);
+    if (h.leaf_kind == LEAF_EVAL) h.src = src;
     if (sub == 0) head_store(t, g, h);
 }
 
 // ---- search_iteration: select + expand (src/async_mcts.rs:226-299, Appendix A of SURVEY.md) ----
 template <class G>
-AZ_D void select_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const EvalCache& ec, const SearchParams& sp, int g, int sub) {
+AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, const SearchParams& sp, int g, int sub) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
     const bool act = h.active != 0;
@@ -383,8 +392,7 @@ AZ_D void select_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const 
         h.stat[ST_DEPTH_SUM] += n_depth;
     }
     h.leaf_kind = kind;
-    const uint32_t src = leaf_request<G>(eb, ec, kind == LEAF_EVAL, leaf_s, sub);
-    if (kind == LEAF_EVAL) h.src = src;
+    return leaf_s;
 }
 
 // `seen`-style sharing of evaluations across trees: a tree whose row was really evaluated publishes (pi, v) under its
@@ -419,8 +427,11 @@ AZ_D void cache_insert(const EvalCache& ec, typename G::State s, float pv, int s
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
-template <class G>
-AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g, int sub) {
+// INLINE_PV: the leaf's (pi, v) row is handed over in a register (pv_in: lane a < ACTIONS holds pi[a], lane ACTIONS holds v)
+// instead of being read through TreeHead.src -- the fused search of the fixture nets.
+template <class G, bool INLINE_PV = false>
+AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g, int sub,
+                      float pv_in = 0.0f) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
     const uint32_t kind = h.leaf_kind;
@@ -434,7 +445,9 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const 
         const typename G::State s = G::unpack(lr.key);
         const uint32_t src = h.src;
         float pv;                                   // lanes 0..NA-1: pi[sub], lane NA: v
-        if (src & SRC_CACHE) {
+        if constexpr (INLINE_PV) {
+            pv = pv_in;
+        } else if (src & SRC_CACHE) {
             pv = ec.pv[(size_t)(src & SRC_INDEX) * 8 + sub];
         } else {
             const uint32_t row = (src & SRC_TABLE) ? eb.tuniq[src & SRC_INDEX] : src;
@@ -569,7 +582,58 @@ __global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_pr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    select_body<G>(t, h, eb_next, ec, sp, g, sub);
+    const typename G::State leaf_s = select_body<G>(t, h, sp, g, sub);
+    const uint32_t src = leaf_request<G>(eb_next, ec, h.leaf_kind == LEAF_EVAL, leaf_s, sub);
+    if (h.leaf_kind == LEAF_EVAL) h.src = src;
+    if (sub == 0) head_store(t, g, h);
+}
+
+// ---- the whole get_action_prob search in ONE launch, for nets that are a pure function of the state on the device ----
+// (DumbConnectFourNnet, examples/connect_four.rs:12-43, and the hash fixture): root prepare, then num_sims x {select,
+// evaluate in registers, backup} per tree with no kernel boundary and no leaf batch -- the trees never wait for each other.
+// Same operations per tree in the same order as the launch-per-step path: bit-identical.
+AZ_D void group_memory_sync() {
+    // what one lane of the group stored (node records, node_path, counters) is read by its other lanes next
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class G>
+AZ_D float fixture_row(typename G::State s, int kind, uint64_t salt, int sub) {
+    float pi[G::ACTIONS], v;
+    if (kind == 0) {
+#pragma unroll
+        for (int a = 0; a < G::ACTIONS; ++a) pi[a] = __fdiv_rn(1.0f, (float)G::ACTIONS);   // examples/connect_four.rs:34-41 (S9)
+        v = 1.0f;
+    } else {
+        hashnet_eval(s.x, s.y, salt, pi, &v);
+    }
+    float out = v;
+#pragma unroll
+    for (int a = 0; a < G::ACTIONS; ++a) out = sub == a ? pi[a] : out;
+    return out;
+}
+template <class G>
+__global__ __launch_bounds__(64) void k_search_fixture(TreeDev t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind,
+                                                       uint64_t salt) {
+    constexpr int GW = G::GROUP;
+    const int tid = blockIdx.x * 64 + threadIdx.x;
+    const int g = tid / GW, sub = tid % GW;
+    if (g >= t.G) return;
+    const EvalBatch no_eb{};
+    const EvalCache no_ec{};
+    TreeHead h = head_load(t, g);
+    typename G::State ls = root_prepare_body<G>(t, h, root_states, g, sub);
+    for (int i = 0; i <= num_sims; ++i) {
+        group_memory_sync();
+        // backup of the previous leaf (i == 0: the root's priors only, S1), then the next selection
+        const float pv = h.leaf_kind == LEAF_EVAL ? fixture_row<G>(ls, kind, salt, sub) : 0.0f;
+        backup_body<G, true>(t, h, no_eb, no_ec, i == 0 ? 1 : 0, g, sub, pv);
+        if (i == num_sims) break;
+        group_memory_sync();
+        ls = select_body<G>(t, h, sp, g, sub);
+    }
+    h.leaf_kind = LEAF_NONE;
     if (sub == 0) head_store(t, g, h);
 }
 
@@ -797,6 +861,10 @@ void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, i
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s) {
     hipLaunchKernelGGL(k_backup_select<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, apply_only);
+}
+void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind, uint64_t salt,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_search_fixture<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, root_states, sp, num_sims, kind, salt);
 }
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s) {

@@ -19,14 +19,17 @@ def oracle_salt(model_id):
     return HASH_SALT + model_id * MODEL_SALT
 
 
-@pytest.fixture(autouse=True, params=[1, 2], ids=["dedup-conv-only", "dedup-every-net"])
+@pytest.fixture(autouse=True, params=[(1, 1), (1, 0), (2, 1)], ids=["fused-fixture-search", "launch-per-simulation", "dedup-every-net"])
 def dedup_mode(request, engine):
-    """Every test of this module runs twice: with the default setting (the stub / hash fixtures take the direct path) and
-    with leaf de-duplication + the evaluation cache switched on for EVERY net, so the election table, the unique batch,
-    the cache and the backup kernels' indirection are held to the same bit-exact bar against the oracle."""
-    engine.set_option("eval_dedup", request.param)
-    yield request.param
+    """Every test of this module runs three times, each held to the same bit-exact bar against the oracle:
+    the default (the stub / hash fixture nets search in ONE launch per move, k_search_fixture), one launch per simulation
+    step with a leaf batch (the path the conv net takes, without de-duplication), and that path with leaf de-duplication +
+    the evaluation cache switched on for EVERY net (election table, cache, the backup kernels' indirection)."""
+    engine.set_option("eval_dedup", request.param[0])
+    engine.set_option("fused_search", request.param[1])
+    yield request.param[0]
     engine.set_option("eval_dedup", 1)
+    engine.set_option("fused_search", 1)
 
 
 def play_episode_lockstep(engine, oracle, n_games, sims, model_id, okind, osalt, temp_schedule, seed, max_moves=42):

@@ -24,5 +24,5 @@ for L in [int(x) for x in os.environ.get("LEAVES", "1400,2048,2700,4096,5000,670
             cs.append(st['net_conv2_ms'] / st['net_launches'])
         row.append((np.median(cs), np.median(ts)))
     same = all(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) for o in outs[1:])
-    print(f"leaves {L}: " + " | ".join(f"{key}={v}: conv2 {c:.3f} ms ({L * 198.180864 / c / 1e6:.0f} TF) forward {t:.3f} ms ({L * 328.986624 / t / 1e6:.0f} TF)"
+    print(f"leaves {L}: " + " | ".join(f"{key}={v}: conv2 {c:.3f} ms ({L * 198.180864 / c / 1e3:.0f} TF) forward {t:.3f} ms ({L * 328.986624 / t / 1e3:.0f} TF)"
                                         for v, (c, t) in zip(vals, row)) + f"  bitwise {same}", flush=True)
