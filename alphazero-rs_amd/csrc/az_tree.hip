@@ -318,9 +318,15 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, const SearchPa
     float val = 0.0f;
     uint32_t n_exp = 0, n_link = 0, n_term = 0, n_depth = 0;
     typename G::State leaf_s = G::init();
+    // The record of an expanded child chosen at one level IS the parent of the next level and is already in the registers of
+    // the lane that evaluated it: it is handed down by shuffles, so a level costs one dependent fetch (the child block), not
+    // two.  Only the root and link targets (canonical nodes living elsewhere) are fetched by slot.
+    NodeRec pr{};
+    bool have_pr = false;
     while (act) {
         uint4* pp = node_ptr(t, base, cur);
-        const NodeRec pr = node_load(pp);
+        if (!have_pr) pr = node_load(pp);
+        have_pr = false;
         const uint64_t pc = pr.ctr + CTR_VISIT;                 // visit(), src/node.rs:77-80; S5: before the checks
         if (sub == 0) node_set_ctr(pp, pc);
         const uint32_t ecd = (pr.meta >> META_ECODE_SHIFT) & 3u;
@@ -357,7 +363,16 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, const SearchPa
         if (sub == 0) path[plen] = cur;                         // node_path.push, S3 / :270
         ++plen;
         if (clink != NONE) { cur = clink; ++depth; continue; }  // Exists(false): follow the link (S2: one level per iteration)
-        if (cmeta & META_EXPANDED) { cur = cslot; ++depth; continue; }   // Exists(true)
+        if (cmeta & META_EXPANDED) {                             // Exists(true)
+            pr.ctr = gshfl64<GW>(cr.ctr, (int)best);
+            pr.key = gshfl64<GW>(cr.key, (int)best);
+            pr.meta = cmeta;
+            pr.child_base = gshfl<GW>(cr.child_base, (int)best);
+            have_pr = true;
+            cur = cslot;
+            ++depth;
+            continue;
+        }
         // PlaceHolder (:261-268, S3): expand it.  B1: play the child's own action.
         const typename G::State s2 = G::play(G::unpack(pr.key), (int)(cmeta & META_A_MASK));       // :284-287 (B5)
         uint32_t found, ins;
