@@ -192,6 +192,8 @@ struct az_engine {
     std::vector<float> train_history;              // (loss_pi, loss_v) mean per epoch of the last az_net_train
     // leaf de-duplication + evaluation cache (az_set_option "eval_dedup", "eval_cache_log2", "eval_cache_max_stones",
     // "eval_cache_persist")
+    int profile_every = 1;          // profile mode: bracket every n-th simulation step ("profile_every")
+    uint64_t profile_tick = 0;
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
     int eval_cache_log2 = 26;       // entries = 2^log2 (40 B each: 2.7 GB); 0 = no cache, in-batch de-duplication only
@@ -240,9 +242,9 @@ NetWorkspace* workspace_for(az_engine* e, hipStream_t s) {
     return e->ws[i];
 }
 
-void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int rows_hint, hipStream_t s) {
+void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int rows_hint, hipStream_t s, int rows_typ = 0, bool timed = true) {
     if (net.kind == AZ_NET_CONV) {
-        convnet_forward(net.conv, workspace_for(e, s), eb, rows_hint, s, e->prof.on ? &e->netprof : nullptr);
+        convnet_forward(net.conv, workspace_for(e, s), eb, rows_hint, rows_typ, s, (e->prof.on && timed) ? &e->netprof : nullptr);
     } else {
         launch_net_fixture(eb, net.kind, net.salt, s);
     }
@@ -340,7 +342,7 @@ void harvest_dedup(az_engine* e) {
 // {select+expand (+ leaf request), predict, mask+store+backup}  (src/async_mcts.rs:81-82, :191-217).
 // rows_hint = host-side upper bound on the leaf batch (trees still searching): sizes the net's grids and picks tiles
 void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int num_sims, SearchParams sp,
-                NetModel& net, int rows_hint, hipStream_t s = nullptr) {
+                NetModel& net, int rows_hint, hipStream_t s = nullptr, int rows_typ = 0, uint32_t* d_max_rows = nullptr) {
     if (!s) s = e->stream;
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
     const bool dedup = dedup_applies(e, net);
@@ -349,7 +351,8 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
         hipEvent_t t0 = nullptr;
         if (e->prof.on) t0 = e->prof.begin(s);
         launch_search_fixture(th.d, d_root_states, sp, num_sims, net.kind, net.salt, s);
-        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
+        if (e->prof.on) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
+        e->stats.tree_launches += 1;
         return;
     }
     const EvalCache ec = cache_for(e, net);
@@ -365,23 +368,25 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
     };
     EvalBatch B[2] = {th.eb, th.eb2};
     B[0].dedup = B[1].dedup = dedup ? 1 : 0;
+    B[0].max_n = B[1].max_n = d_max_rows;
+    // profile mode brackets every "profile_every"-th simulation step (events cost GPU idle time between dependent kernels)
+    const int every = std::max(1, e->profile_every);
     // root: prepare (its leaf goes to batch 0), predict; then num_sims x {backup of the previous leaf + select of the next
     // (one launch, the new leaf goes to the other batch), predict}; a last backup closes the search.
     B[0].epoch = next_epoch();
     launch_root_prepare(th.d, B[0], ec, d_root_states, s);
-    net_forward(e, net, B[0], rows_hint, s);
+    net_forward(e, net, B[0], rows_hint, s, rows_typ, false);
     for (int i = 0; i < num_sims; ++i) {
+        const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
         hipEvent_t t0 = nullptr;
-        if (e->prof.on) t0 = e->prof.begin(s);
+        if (timed) t0 = e->prof.begin(s);
         B[(i + 1) & 1].epoch = next_epoch();
         launch_backup_select(th.d, B[i & 1], B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
-        if (e->prof.on) e->prof.end(t0, RG_TREE, s);
-        net_forward(e, net, B[(i + 1) & 1], rows_hint, s);
+        if (timed) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
+        e->stats.tree_launches += 1;
+        net_forward(e, net, B[(i + 1) & 1], rows_hint, s, rows_typ, timed);
     }
-    hipEvent_t t0 = nullptr;
-    if (e->prof.on) t0 = e->prof.begin(s);
     launch_backup(th.d, B[num_sims & 1], ec, 0, s);
-    if (e->prof.on) e->prof.end(t0, RG_TREE, s);
 }
 
 void resolve_profile(az_engine* e) {
@@ -509,6 +514,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = buf;       // returned through az_last_error
         return AZ_OK;
     }
+    if (std::strcmp(key, "profile_every") == 0 && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
     if (std::strcmp(key, "fused_search") == 0 && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_dedup") == 0 && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_log2") == 0 && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
@@ -1017,9 +1023,12 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         uint64_t moves = 0;
         az_status result = AZ_OK;
         int active = C;                               // slots still playing (read back after every move)
+        int rows_typ = 0;                             // expected rows per leaf batch (0 = unknown: assume `active`)
         for (int iter = 0;; ++iter) {
             launch_selfplay_sync_active(th.d, gd, s);
-            run_search(e, th, gd.state, p->num_sims, sp, *net, active);
+            // tile choice from the largest batch seen so far in this call (de-duplication makes batches much smaller than
+            // the number of searching trees); the grids still cover `active`
+            run_search(e, th, gd.state, p->num_sims, sp, *net, active, nullptr, rows_typ, gd.counters + 3);
             launch_selfplay_move(th.d, gd, mp, s);
             if (mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
             HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1027,6 +1036,7 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
             resolve_profile(e);
             ++moves;
             active = (int)h_ctr[2];
+            rows_typ = h_ctr[3] ? (int)std::min<uint64_t>((uint64_t)h_ctr[3] * 5 / 4 + 64, (uint64_t)C) : 0;
             if (h_ctr[1] >= (uint32_t)n_games) break;
             if ((iter & 7) == 7 || h_ctr[2] == 0) {
                 result = check_tree_errors(e, th);

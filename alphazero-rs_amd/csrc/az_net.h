@@ -68,6 +68,7 @@ void convnet_set_ring_max_tiles(int v);
 bool netws_read_clock_stamps(NetWorkspace* ws, unsigned long long* out2048);
 // forward for rows [0, *eb.n) of model n in workspace ws; n_rows_hint = host-side upper bound used to size the grids.
 // If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
-void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int n_rows_hint, hipStream_t s, NetProfile* prof);
+// n_rows_typ = expected row count (kernel / tile choice only; 0 = n_rows_hint).
+void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int n_rows_hint, int n_rows_typ, hipStream_t s, NetProfile* prof);
 
 }  // namespace az

@@ -1375,7 +1375,9 @@ int g_ring_max_tiles = 256;   // ... when the layer has at most this many tiles 
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
 
 template <int LAYER>
-static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
+// rows_hint = upper bound on the batch (the grids must cover it: tiles past the device-side count exit at once);
+// rows_typ = what the batch is expected to hold (picks the kernel / tile shape; any value is correct, a good one is fast)
+static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStream_t s) {
     const int v = g_gemm_variant;
     if ((v == 3 || v == 5) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
@@ -1385,7 +1387,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
         else hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
-    const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_hint >= 4096)))) &&
+    const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_typ >= 4096)))) &&
                      d.N % HBN_ == 0;
     if constexpr (LAYER == 2) if (v == 5 && d.N % 128 == 0 && d.cin % 64 == 0 && d.rows_per_sample == 20) {   // conv3 image-resident
         const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
@@ -1415,7 +1417,8 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     // LDS-DMA ring instead of register staging (bit-identical).  A grid that fits one round of one workgroup per CU is
     // latency / fetch bound: 4 stages (128 KiB) in flight; otherwise 2 stages (64 KiB) so that two workgroups share a CU.
     if (v == 5 && g_fc_ring) {
-        if (mt * (d.N / GBN) <= g_ring_max_tiles && (LAYER >= 4 || g_fc_ring == 2)) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(grid), dim3(256), 0, s, d);
+        const int mt_typ = (rows_typ * d.rows_per_sample + GBM - 1) / GBM;
+        if (mt_typ * (d.N / GBN) <= g_ring_max_tiles && (LAYER >= 4 || g_fc_ring == 2)) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(grid), dim3(256), 0, s, d);
         else hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);
         return;
     }
@@ -1463,10 +1466,11 @@ void convnet_set_ring_max_tiles(int v) { g_ring_max_tiles = v; }
 int g_conv1_table = 1;    // conv2 gathers its image from the conv1 table (default kernel set only); 0 = run k_conv1 into act1
 void convnet_set_conv1_table(int v) { g_conv1_table = v; }
 
-void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows_hint, hipStream_t s, NetProfile* prof) {
+void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows_hint, int rows_typ, hipStream_t s, NetProfile* prof) {
     const int C = n->C;
     if (rows_hint > ws->max_batch) rows_hint = ws->max_batch;
     if (rows_hint <= 0) return;
+    if (rows_typ <= 0 || rows_typ > rows_hint) rows_typ = rows_hint;
     NetWorkspace::Rec rec{};
     uint32_t* n_log = nullptr;
     const bool timed = prof != nullptr && ws->pinned_next < ws->pinned_cap;
@@ -1494,25 +1498,25 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.W = n->wg[0]; d.bias = n->bg[0]; d.out = ws->act2;
     d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;
     if (timed) (void)hipEventRecord(rec.e1, s);
-    launch_gemm<1>(d, rows_hint, s);
+    launch_gemm<1>(d, rows_hint, rows_typ, s);
     if (timed) (void)hipEventRecord(rec.e2, s);
     d.states = nullptr;
     // conv3: 3x3 valid [6][7][C] -> [4][5][C]
     d.A = ws->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = ws->act3;
     d.rows_per_sample = 20; d.out_w = 5; d.in_h = 6; d.in_w = 7;
-    launch_gemm<2>(d, rows_hint, s);
+    launch_gemm<2>(d, rows_hint, rows_typ, s);
     // conv4: 3x3 valid [4][5][C] -> [2][3][C]
     d.A = ws->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = ws->act4;
     d.rows_per_sample = 6; d.out_w = 3; d.in_h = 4; d.in_w = 5;
-    launch_gemm<3>(d, rows_hint, s);
+    launch_gemm<3>(d, rows_hint, rows_typ, s);
     // fc1: [6C] -> 1024
     d.A = ws->act4; d.W = n->wg[3]; d.bias = n->bg[3]; d.out = ws->fc1o;
     d.rows_per_sample = 1; d.out_w = 1; d.in_h = 1; d.in_w = 1; d.in_c = 6 * C; d.tap_w = 1; d.cin = 6 * C; d.K = 6 * C; d.N = 1024;
-    launch_gemm<4>(d, rows_hint, s);
+    launch_gemm<4>(d, rows_hint, rows_typ, s);
     // fc2: 1024 -> 512
     d.A = ws->fc1o; d.W = n->wg[4]; d.bias = n->bg[4]; d.out = ws->fc2o;
     d.in_c = 1024; d.cin = 1024; d.K = 1024; d.N = 512;
-    launch_gemm<5>(d, rows_hint, s);
+    launch_gemm<5>(d, rows_hint, rows_typ, s);
     hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, ws->fc2o, n->wh, n->bh, n_log);
     if (timed) {
         (void)hipEventRecord(rec.e3, s);

@@ -69,6 +69,7 @@ struct EvalBatch {
     ulonglong2* state;    // [cap] canonical state to featurise (to_features, connect_four_game.rs:219-237)
     float* pi;            // [cap*8] net output: pi[0..6], v in slot 7
     float* v;             // [cap]
+    uint32_t* max_n;      // device, may be nullptr: largest row count of any batch so far (feeds the host's tile choice)
     // ---- de-duplication (dedup == 0: every requesting tree takes its own row) --------------------------------------
     // Thousands of games share their openings and a row's (pi, v) depends on its state alone (BatchNorm is folded, every
     // row's K-sum has one order), so evaluating a state once per batch -- or once per call, through the engine's evaluation

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCach
     constexpr int GW = G::GROUP;
     const int tid = blockIdx.x * 64 + threadIdx.x;
     const int g = tid / GW, sub = tid % GW;
-    if (tid == 0) *eb.n = 0;            // the batch has been consumed (nothing in this kernel reads the count)
+    if (tid == 0) { if (eb.max_n && *eb.n > *eb.max_n) *eb.max_n = *eb.n; *eb.n = 0; }   // the batch has been consumed (nothing in this kernel reads the count)
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     backup_body<G>(t, h, eb, ec, apply_only, g, sub);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_pr
     constexpr int GW = G::GROUP;
     const int tid = blockIdx.x * 64 + threadIdx.x;
     const int g = tid / GW, sub = tid % GW;
-    if (tid == 0) *eb_prev.n = 0;
+    if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     backup_body<G>(t, h, eb_prev, ec, apply_only, g, sub);

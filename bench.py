@@ -100,6 +100,12 @@ def cpu_baseline(params, channels, sims, mean_plies=None, budget_s=20.0, seed=1)
     }
 
 
+def tree_gbps(st):
+    """Algorithmic tree bytes per launch (all launches) over the mean duration of the HIP-event-timed launches."""
+    per_launch = st["tree_bytes"] / max(1, st["tree_launches"])
+    return per_launch / (st["tree_ms"] * 1e-3 / max(1, st["tree_launches_timed"])) / 1e9
+
+
 def committed_pmc():
     """The newest committed PMC fold (tools/collect_profiles.sh -> profiles/r<NN><x>_pmc_traffic.json): bench.py cannot
     collect hardware counters itself, so per-kernel HBM bytes come from the rocprofv3 --pmc passes of this same command."""
@@ -181,6 +187,7 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
+    ap.add_argument("--profile-every", type=int, default=16, help="bracket every n-th simulation step with HIP events (each bracket idles the GPU a little)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary no-dedup and arena (config 3) measurements")
     ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
@@ -221,6 +228,7 @@ def main():
     from alphazero_rs_amd import dist as azdist
     e = azeng.Engine(device=local_rank, max_batch=args.games, net_channels=args.channels, profile=not args.no_profile)
     e.set_option("eval_dedup", args.dedup)
+    e.set_option("profile_every", args.profile_every)
     if args.net == "conv":
         e.net_init_random(0, seed=args.seed)       # identical weights on every rank (replicated, 21.5 MB bf16)
     else:
@@ -314,12 +322,12 @@ def main():
                     "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{traffic_src}: "
                                                         "bytes per executed row x this run's mean rows per launch)",
-                    "launches": st["net_launches"],
+                    "launches": st["net_launches"], "launches_are": f"every {args.profile_every}th simulation step of the timed region (HIP events on the engine's stream)",
                     "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"],
                     "avg_flop_per_launch": st["net_conv2_flops"] / st["net_launches"],
                     "net_forward_tflops": st["net_total_flops"] / (st["net_total_ms"] * 1e-3) / 1e12}
         elif not args.no_profile and st["tree_ms"] > 0:
-            ach = st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9
+            ach = tree_gbps(st)
             roof = {"bound": "hbm", "kernel": "k_select + k_backup (tree traversal)", "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
         line["roofline"] = roof
@@ -330,15 +338,16 @@ def main():
                 for k, v in pmc["kernels"].items():
                     if "k_backup_select" in k:
                         # counter bytes per launch of the committed PMC pass over this run's mean launch time
-                        launch_s = st["tree_ms"] * 1e-3 / max(1, st["net_launches"])      # one tree launch per net launch
+                        launch_s = st["tree_ms"] * 1e-3 / max(1, st["tree_launches_timed"])
                         tree_counter = {"hbm_bytes_per_launch_pmc": v["hbm_bytes_per_launch"], "source": f"profiles/{pmc_name}",
                                         "mean_launch_us_this_run": launch_s * 1e6,
                                         "counter_GBps": v["hbm_bytes_per_launch"] / launch_s / 1e9,
-                                        "counter_over_algorithmic": v["hbm_bytes_per_launch"] / max(1.0, st["tree_bytes"] / max(1, st["net_launches"]))}
-            line["tree_hbm"] = {"achieved_GBps": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                                        "counter_over_algorithmic": v["hbm_bytes_per_launch"] / max(1.0, st["tree_bytes"] / max(1, st["tree_launches"]))}
+            line["tree_hbm"] = {"achieved_GBps": tree_gbps(st), "peak_GBps": HBM_PEAK_GBS,
                                 "counter": tree_counter,
-                                "frac": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "frac_of_measured_copy_bw": st["tree_bytes"] / (st["tree_ms"] * 1e-3) / 1e9 / 6290.0,
+                                "frac": tree_gbps(st) / HBM_PEAK_GBS,
+                                "frac_of_measured_copy_bw": tree_gbps(st) / 6290.0,
+                                "launches_timed": st["tree_launches_timed"], "launches": st["tree_launches"],
                                 "algorithmic_bytes_per_sim": st["tree_bytes"] / max(1, st["simulations"]),
                                 "mean_depth": st["depth_sum"] / max(1, st["simulations"])}
         if world == 1 and not args.no_cpu_baseline and args.net == "conv":

@@ -92,6 +92,8 @@ typedef struct az_stats {
     uint64_t eval_cache_hits;
     uint64_t eval_batch_dups;
     uint64_t eval_cache_inserts;
+    uint64_t tree_launches;        /* select/backup launches (profile mode brackets every "profile_every"-th of them) */
+    uint64_t tree_launches_timed;  /* ... of which tree_ms was measured on */
     uint64_t tree_arena_allocs;  /* tree arenas hipMalloc'ed by az_selfplay / az_arena since az_create (kept and reused across
                                   * calls of the same shape; not cleared by az_reset_stats) */
 } az_stats;
@@ -104,7 +106,10 @@ const char* az_last_error(const az_engine* e);
 /* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
  * net uses (0 = 128x128 register-staged tiles for every layer, 1 / 2 = 256x256 LDS-DMA tiles, 3 = conv2 image-resident
  * in one 8-wave workgroup per CU, 5 = default, conv2 image-resident in two 4-wave workgroups per CU; 11-17 = timing
- * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto). "conv1_table" = 1 (default): conv2 of the default kernel set gathers its input image from the
+ * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto). "profile_every" = n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and tree_ms
+ * sums then cover that sample of launches; every bracket costs a little GPU idle time between dependent kernels). "fused_search" = 1
+ * (default): the stub / hash nets run a whole search in one launch, 0 = one launch per simulation like the conv net. "fc_ring" = 1
+ * (default): LDS-DMA ring kernel for fc1 / fc2 / small-batch conv4, 0 = register-staged tiles. "conv1_table" = 1 (default): conv2 of the default kernel set gathers its input image from the
  * per-model conv1 table (3^9 neighbourhood patterns x C channels) instead of running conv1 as a kernel, 0 = conv1 kernel; bit-identical.
  * Leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
  * src/node.rs:282-289): "eval_dedup" = 0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is
