@@ -108,8 +108,9 @@ struct TreeHost {
         HIPCHK(hipMemsetAsync(eb2.n, 0, sizeof(uint32_t), s));
         launch_init_heads(d, s);
     }
-    void create(int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int log_cap) {
+    void create(int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int log_cap, int game) {
         k_G = G; k_blocks = blocks; k_H = H; k_log = log_cap;
+        d.game = game;
         d.G = G; d.R = (uint32_t)(blocks * BLOCK_SLOTS); d.H = H; d.reserve_nodes = (uint32_t)reserve_nodes;
         size_t slots = (size_t)G * d.R;
         d.node = mem.alloc<uint4>(slots * 2);
@@ -318,7 +319,7 @@ void acquire_trees(az_engine* e, TreeLease& lease, int G, uint64_t blocks, uint6
         }
     }
     std::unique_ptr<TreeHost> th(new TreeHost());
-    th->create(G, blocks, reserve_nodes, H, log_cap);
+    th->create(G, blocks, reserve_nodes, H, log_cap, e->cfg.game);
     th->in_use = true;
     lease.th = th.get();
     e->tree_pool.push_back(std::move(th));
@@ -462,6 +463,7 @@ az_status az_create(const az_config* cfg, az_engine** out) {
     if (cfg) e->cfg = *cfg;
     if (e->cfg.max_batch <= 0) e->cfg.max_batch = 8192;
     if (e->cfg.net_channels <= 0) e->cfg.net_channels = 512;
+    if (e->cfg.game < 0 || e->cfg.game >= GAME_COUNT) return AZ_ERR_BAD_ARGUMENT;
     e->device = e->cfg.device;
     e->prof.on = e->cfg.profile != 0;
     try {
@@ -835,7 +837,7 @@ az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_
         t->e = e;
         t->num_sims = num_sims; t->max_depth = max_depth; t->model_id = model_id; t->cpuct = cpuct;
         const uint64_t nodes = std::min<uint64_t>(reserve, reachable_slots(num_sims, AZ_MAX_PLIES));
-        t->th.create(n_games, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(num_sims, AZ_MAX_PLIES), 0);
+        t->th.create(n_games, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(num_sims, AZ_MAX_PLIES), 0, e->cfg.game);
         t->d_root_states = t->mem.alloc<ulonglong2>(n_games);
         t->d_pi = t->mem.alloc<float>((size_t)n_games * 7);
         t->d_counts = t->mem.alloc<uint16_t>((size_t)n_games * 7);

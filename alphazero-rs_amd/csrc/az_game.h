@@ -123,6 +123,21 @@ struct ConnectFour {
     AZ_HD static float feature(State s, int f) { return c4_feature(s.x, s.y, f / 42, (f % 42) / 7, f % 7); }
 };
 
+// The seam's SECOND instantiation: Connect Four's board, moves, features and symmetries with three in a row winning.  The
+// reference has no second Game; this one exists so that the Game policy seam is exercised end to end (az_config.game = 1,
+// oracle twin CBits<3>): the tree kernels below it are the same templates, nothing in them names a rule.
+AZ_HD bool c4_has_three(uint64_t b) {
+    return ((b & (b >> 1) & (b >> 2)) | (b & (b >> 7) & (b >> 14)) | (b & (b >> 6) & (b >> 12)) | (b & (b >> 8) & (b >> 16))) != 0ull;
+}
+struct ConnectThree : ConnectFour {
+    AZ_HD static uint32_t ended_code(State s) {
+        if (c4_has_three(s.x)) return E_MINUS1;
+        if (c4_has_three(s.y)) return E_PLUS1;
+        if ((s.x | s.y) == C4_FULL) return E_DRAW;
+        return E_NONE;
+    }
+};
+
 // test-fixture net (exact in f32) on a 16-byte state; oracle twin: hashnet_eval in oracle/az_oracle_games.hpp
 AZ_HD void hashnet_eval(uint64_t mine, uint64_t theirs, uint64_t salt, float* pi, float* v) {
     uint64_t h = mix64(mine ^ mix64(theirs ^ mix64(salt)));

@@ -45,6 +45,7 @@ struct TreeDev {
     int32_t G;               // trees
     uint32_t R;              // slots per tree (a multiple of BLOCK_SLOTS)
     uint32_t H;              // hash entries per tree (power of two)
+    int32_t game;            // az_game: which Game policy the kernels are instantiated with (0 = ConnectFour)
     uint32_t reserve_nodes;  // reserve_space (src/node.rs:146): pushes beyond it are the reference's assert (src/node.rs:237)
     uint4* node;             // [G*R*2] 32-byte records as two uint4: {ctr.lo, ctr.hi, key.lo, key.hi} {prior, meta, link, child_base}
     uint32_t* hash;          // [G*H] `seen` (src/node.rs:135): open-addressing table of node slots, key = the node's own key word
@@ -143,7 +144,7 @@ struct ArenaDev {
     uint32_t* counters;    // [0] games still running, [1] invalid-move flag (src/arena.rs:31-35)
 };
 
-// ---- launchers (all asynchronous on `s`; instantiated for ConnectFour, the reference's one Game) -------------------
+// ---- launchers (all asynchronous on `s`; dispatch on TreeDev.game to the Game policy's instantiation) ------------------
 void launch_init_heads(const TreeDev& t, hipStream_t s);                      // zero every TreeHead, active = 1
 void launch_set_active(const TreeDev& t, uint32_t value, hipStream_t s);
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s,
@@ -162,6 +163,7 @@ void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t fi
 // sums the trees' counters into totals[ST_COUNT] (u64, accumulated) and clears them; node_counts [G] may be nullptr
 void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);
+constexpr int GAME_COUNT = 2;    // 0 = ConnectFour (the reference's Game), 1 = ConnectThree (the seam's second instantiation)
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s);
 void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDev& ad, hipStream_t s);
 void launch_arena_move(const TreeDev& t, const ArenaDev& ad, uint64_t seed, hipStream_t s);

@@ -851,12 +851,19 @@ __global__ void k_sync_active(TreeDev t, GamesDev gd) {
     if (g < t.G) t.head[g].active = gd.gid[g] >= 0 ? 1u : 0u;
 }
 
-// ---- launchers: the reference's one Game (ConnectFour) --------------------------------------------------------------
-using TheGame = ConnectFour;
-static_assert(TheGame::GROUP == BLOCK_SLOTS && TheGame::GROUP > TheGame::ACTIONS && (TheGame::GROUP & (TheGame::GROUP - 1)) == 0,
-              "one lane per child plus one, power of two, one child block per group");
-static_assert(sizeof(TheGame::State) == 16 && sizeof(TheGame::Packed) == 8, "16-byte states, 8-byte node-resident identity");
-static inline int group_blocks(int G) { return (G * TheGame::GROUP + 63) / 64; }
+// ---- launchers: one instantiation of every kernel per Game policy, chosen by TreeDev.game ------------------------------
+template <class G> constexpr bool game_ok() {
+    return G::GROUP == BLOCK_SLOTS && G::GROUP > G::ACTIONS && (G::GROUP & (G::GROUP - 1)) == 0 && sizeof(typename G::State) == 16 &&
+           sizeof(typename G::Packed) == 8;
+}
+static_assert(game_ok<ConnectFour>() && game_ok<ConnectThree>(),
+              "one lane per child plus one, power of two, one child block per group; 16-byte states, 8-byte node-resident identity");
+#define AZ_FOR_GAME(game_, ...)                                    \
+    do {                                                           \
+        if ((game_) == 1) { using TG = ConnectThree; __VA_ARGS__; } \
+        else { using TG = ConnectFour; __VA_ARGS__; }               \
+    } while (0)
+static inline int group_blocks(int G) { return (G * BLOCK_SLOTS + 63) / 64; }
 
 void launch_init_heads(const TreeDev& t, hipStream_t s) {
     hipLaunchKernelGGL(k_init_heads, dim3((t.G + 255) / 256), dim3(256), 0, s, t);
@@ -865,31 +872,31 @@ void launch_set_active(const TreeDev& t, uint32_t value, hipStream_t s) {
     hipLaunchKernelGGL(k_set_active, dim3((t.G + 255) / 256), dim3(256), 0, s, t, value);
 }
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags, hipStream_t s, const ulonglong2* roots) {
-    hipLaunchKernelGGL(k_reset_trees<TheGame>, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags), roots);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_reset_trees<TG>, dim3(t.G), dim3(256), 0, s, t, flags, const_cast<uint8_t*>(flags), roots));
 }
 void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, const ulonglong2* root_states, hipStream_t s) {
-    hipLaunchKernelGGL(k_root_prepare<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, root_states);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_root_prepare<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, root_states));
 }
 void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s) {
-    hipLaunchKernelGGL(k_backup<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, apply_only);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_backup<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, apply_only));
 }
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s) {
-    hipLaunchKernelGGL(k_backup_select<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, apply_only);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_backup_select<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, apply_only));
 }
 void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind, uint64_t salt,
                            hipStream_t s) {
-    hipLaunchKernelGGL(k_search_fixture<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, root_states, sp, num_sims, kind, salt);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_search_fixture<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, root_states, sp, num_sims, kind, salt));
 }
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s) {
-    hipLaunchKernelGGL(k_root_policy<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, temp, seed, first_game_id, pi, counts, q);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_root_policy<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, temp, seed, first_game_id, pi, counts, q));
 }
 void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s) {
     hipLaunchKernelGGL(k_harvest, dim3((t.G + 255) / 256), dim3(256), 0, s, t, totals, node_counts);
 }
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s) {
-    hipLaunchKernelGGL(k_selfplay_move<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, gd, mp);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_selfplay_move<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, gd, mp));
 }
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s) {
     hipLaunchKernelGGL(k_sync_active, dim3((t.G + 255) / 256), dim3(256), 0, s, t, gd);
@@ -898,11 +905,12 @@ void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDe
     hipLaunchKernelGGL(k_arena_sync, dim3((ad.G + 255) / 256), dim3(256), 0, s, t_new, t_old, ad);
 }
 void launch_arena_move(const TreeDev& t, const ArenaDev& ad, uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(k_arena_move<TheGame>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, ad, seed);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_arena_move<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, ad, seed));
 }
 void launch_emit_samples(const GamesDev& gd, const int64_t* offsets, int symmetries, ulonglong2* out_states,
                          float* out_boards, float* out_pis, float* out_zs, hipStream_t s) {
-    hipLaunchKernelGGL(k_emit_samples<TheGame>, dim3(gd.n_games), dim3(256), 0, s, gd, offsets, symmetries, out_states,
+    // features, mirror and plies are the board's, not the rules': both games share ConnectFour's
+    hipLaunchKernelGGL(k_emit_samples<ConnectFour>, dim3(gd.n_games), dim3(256), 0, s, gd, offsets, symmetries, out_states,
                        out_boards, out_pis, out_zs);
 }
 

@@ -27,6 +27,7 @@ STATUS_NAMES = {
     5: "AZ_ERR_TERMINAL_ROOT", 6: "AZ_ERR_NO_MODEL", 7: "AZ_ERR_IO", 8: "AZ_ERR_UNSUPPORTED",
 }
 NET_STUB, NET_HASH, NET_CONV = 0, 1, 2
+GAME_CONNECT_FOUR, GAME_CONNECT_THREE = 0, 1
 
 
 class AzError(RuntimeError):
@@ -36,7 +37,8 @@ class AzError(RuntimeError):
 
 
 class az_config(C.Structure):
-    _fields_ = [("device", C.c_int32), ("max_batch", C.c_int32), ("net_channels", C.c_int32), ("profile", C.c_int32)]
+    _fields_ = [("device", C.c_int32), ("max_batch", C.c_int32), ("net_channels", C.c_int32), ("profile", C.c_int32),
+                ("game", C.c_int32)]
 
 
 class az_stats(C.Structure):
@@ -145,8 +147,8 @@ def _as_ptr(x):
 class Engine:
     """az_engine handle.  One per process per GPU (one HIP stream)."""
 
-    def __init__(self, device=0, max_batch=8192, net_channels=512, profile=False):
-        cfg = az_config(device, max_batch, net_channels, 1 if profile else 0)
+    def __init__(self, device=0, max_batch=8192, net_channels=512, profile=False, game=0):
+        cfg = az_config(device, max_batch, net_channels, 1 if profile else 0, game)
         h = C.c_void_p()
         st = _lib.az_create(C.byref(cfg), C.byref(h))
         if st != AZ_OK:

@@ -64,7 +64,14 @@ typedef struct az_config {
     int32_t max_batch;     /* largest leaf batch the conv net is sized for (0 = 8192) */
     int32_t net_channels;  /* conv width; 0 = 512 (connect_four_net.py:21) */
     int32_t profile;       /* !=0: bracket the dominant kernels with HIP events (az_get_stats) */
+    int32_t game;          /* az_game: which Game (src/game.rs:10-28) the trees play; 0 = Connect Four */
 } az_config;
+
+/* The Game the engine's trees are instantiated for (trait Game, src/game.rs:10-28; the device-side seam is
+ * alphazero-rs_amd/csrc/az_game.h).  AZ_GAME_CONNECT_FOUR is the reference's one implementor
+ * (examples/connect_four_lib/connect_four_game.rs); AZ_GAME_CONNECT_THREE is the same board, moves, features and nets with
+ * three in a row winning: the seam's second instantiation (its CPU twin lives with the tests), there to prove the rules are a policy. */
+typedef enum az_game { AZ_GAME_CONNECT_FOUR = 0, AZ_GAME_CONNECT_THREE = 1 } az_game;
 
 /* Counters (SURVEY.md 8b "Introspection"); all cumulative since az_create / az_reset_stats. */
 typedef struct az_stats {

@@ -47,6 +47,7 @@ C4Array array_from_bits(uint64_t mine, uint64_t theirs, bool literal) {
 
 template <class G> G make_state(uint64_t mine, uint64_t theirs, const Quirks& q);
 template <> C4Bits make_state<C4Bits>(uint64_t mine, uint64_t theirs, const Quirks&) { return C4Bits{mine, theirs}; }
+template <> C3Bits make_state<C3Bits>(uint64_t mine, uint64_t theirs, const Quirks&) { return C3Bits{mine, theirs}; }
 template <> C4Array make_state<C4Array>(uint64_t mine, uint64_t theirs, const Quirks& q) {
     return array_from_bits(mine, theirs, q.b6_literal_windows);
 }
@@ -156,6 +157,7 @@ void azo_c4_play(uint64_t mine, uint64_t theirs, int a, uint64_t* out2) {
     out2[0] = c.p1; out2[1] = c.m1;
 }
 float azo_c4_ended(uint64_t mine, uint64_t theirs) { return C4Bits{mine, theirs}.get_game_ended(1); }
+float azo_c3_ended(uint64_t mine, uint64_t theirs) { return C3Bits{mine, theirs}.get_game_ended(1); }
 float azo_c4_ended_array(uint64_t mine, uint64_t theirs, int literal) {
     return array_from_bits(mine, theirs, literal != 0).get_game_ended(1);
 }
@@ -184,6 +186,8 @@ void* azo_tree_new(int game_kind, int has_root, uint64_t mine, uint64_t theirs, 
     try {
         if (game_kind == 0)
             return make_tree<C4Bits>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits);
+        if (game_kind == 2)
+            return make_tree<C3Bits>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits);
         return make_tree<C4Array>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits);
     } catch (const std::exception&) {
         return nullptr;
@@ -236,6 +240,11 @@ int64_t azo_selfplay(int64_t n_games, uint64_t first_game_id, uint64_t sims, uin
                 m.quirks = q;
                 res[g].s = execute_episode<C4Bits>(m, temp_threshold, seed, first_game_id + (uint64_t)g, &res[g].moves);
                 res[g].st = m.stats;
+            } else if (game_kind == 2) {
+                AsyncMcts<C3Bits> m(reserve, sims, 1, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
+                m.quirks = q;
+                res[g].s = execute_episode<C3Bits>(m, temp_threshold, seed, first_game_id + (uint64_t)g, &res[g].moves);
+                res[g].st = m.stats;
             } else {
                 AsyncMcts<C4Array> m(reserve, sims, 1, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
                 m.quirks = q;
@@ -282,8 +291,12 @@ int64_t azo_selfplay(int64_t n_games, uint64_t first_game_id, uint64_t sims, uin
 // ---- arena::play_games (C16), per-game tree pair (B8) -----------------------
 // model slot 0 = new net (salt_new / model id 1), slot 1 = old net (model id 0).
 // results[g] (optional, [num]) = +1 first seat won, -1 second seat won, 0 draw.
-int azo_arena(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
-              uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
+}  // extern "C" (the arena body is a template over the game; its C entry points follow it)
+
+template <class G>
+static int arena_impl(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
+                      uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
+    using C4Bits = G;      // the body below was written for the bitboard game; G is CBits<4> or CBits<3>
     try {
         uint64_t half = num / 2;
         std::vector<int8_t> res(2 * half, 0);
@@ -336,4 +349,13 @@ int azo_arena(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64
     }
 }
 
+extern "C" {
+int azo_arena(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
+              uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
+    return arena_impl<CBits<4>>(num, sims, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id, threads, wld3, results);
+}
+int azo_arena_c3(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
+                 uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
+    return arena_impl<CBits<3>>(num, sims, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id, threads, wld3, results);
+}
 }  // extern "C"

@@ -19,7 +19,10 @@ constexpr float DRAW_EPS = 1e-4f; // :16
 // bit of every column is a permanently clear sentinel.  `p1` holds player +1's
 // stones, `m1` player -1's.  In canonical form (side to move == +1) this is the
 // (mine, theirs) pair the HIP engine stores per node.
-struct C4Bits {
+// WIN = 4 is Connect Four (the reference's one Game); WIN = 3 ("Connect Three": same board, moves and features, three in a
+// row wins) is the twin of the engine's second Game policy, kept to exercise the Game seam end to end.
+template <int WIN>
+struct CBits {
     uint64_t p1 = 0, m1 = 0;
 
     static constexpr uint64_t col_mask(int c) { return 0x3Full << (c * 7); }
@@ -30,6 +33,10 @@ struct C4Bits {
     static bool has_four(uint64_t b) {
         // all 69 windows (B6 repair): vertical 1, horizontal 7, diagonals 6 and 8
         uint64_t m;
+        if (WIN == 3) {
+            for (int sft : {1, 7, 6, 8}) if (b & (b >> sft) & (b >> (2 * sft))) return true;
+            return false;
+        }
         m = b & (b >> 1); if (m & (m >> 2)) return true;
         m = b & (b >> 7); if (m & (m >> 14)) return true;
         m = b & (b >> 6); if (m & (m >> 12)) return true;
@@ -38,18 +45,18 @@ struct C4Bits {
     }
 
     struct Hasher {
-        size_t operator()(const C4Bits& g) const { return (size_t)mix64(g.p1 ^ mix64(g.m1)); }
+        size_t operator()(const CBits& g) const { return (size_t)mix64(g.p1 ^ mix64(g.m1)); }
     };
-    bool operator==(const C4Bits& o) const { return p1 == o.p1 && m1 == o.m1; }
+    bool operator==(const CBits& o) const { return p1 == o.p1 && m1 == o.m1; }
 
-    static C4Bits get_init_board() { return C4Bits{}; }                 // connect_four_game.rs:82-84
+    static CBits get_init_board() { return CBits{}; }                 // connect_four_game.rs:82-84
     static std::vector<size_t> get_feature_shape() { return {2, C4_H, C4_W}; } // :86-88 (S8: NCHW)
     // :90-103
-    std::pair<C4Bits, int8_t> get_next_state(int8_t player, uint8_t action) const {
+    std::pair<CBits, int8_t> get_next_state(int8_t player, uint8_t action) const {
         uint64_t mask = p1 | m1;
         uint64_t nb = (mask + bottom_bit(action)) & col_mask(action);
         assert(nb != 0);
-        C4Bits n = *this;
+        CBits n = *this;
         if (player == 1) n.p1 |= nb; else n.m1 |= nb;
         return {n, (int8_t)-player};
     }
@@ -68,17 +75,17 @@ struct C4Bits {
         return 0.0f;
     }
     // :198-203 with B5 repaired: board from the side-to-move's point of view
-    C4Bits get_canonical_form(int8_t player) const {
-        return player == 1 ? *this : C4Bits{m1, p1};
+    CBits get_canonical_form(int8_t player) const {
+        return player == 1 ? *this : CBits{m1, p1};
     }
     static uint64_t mirror(uint64_t b) {
         uint64_t r = 0;
         for (int c = 0; c < C4_W; ++c) r |= ((b >> (c * 7)) & 0x7Full) << ((C4_W - 1 - c) * 7);
         return r;
     }
-    C4Bits flip() const { return C4Bits{mirror(p1), mirror(m1)}; }      // :65-78
+    CBits flip() const { return CBits{mirror(p1), mirror(m1)}; }      // :65-78
     // :205-211
-    std::vector<std::pair<C4Bits, std::vector<float>>> get_symmetries(const std::vector<float>& pi) const {
+    std::vector<std::pair<CBits, std::vector<float>>> get_symmetries(const std::vector<float>& pi) const {
         std::vector<float> rp(pi.rbegin(), pi.rend());
         return {{*this, pi}, {flip(), rp}};
     }
@@ -95,6 +102,8 @@ struct C4Bits {
         return f;
     }
 };
+using C4Bits = CBits<4>;
+using C3Bits = CBits<3>;
 
 // ---------------------------------------------------------------------------
 // Array Connect Four: the reference's own data layout (i8[6][7], row 0 = top,

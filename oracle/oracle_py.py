@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_DIR, "libaz_oracle.so")
 TEST_BIN = os.path.join(_DIR, "test_oracle")
 
 NET_STUB, NET_HASH, NET_REPLAY, NET_CALLBACK = 0, 1, 2, 3
-GAME_BITS, GAME_ARRAY = 0, 1
+GAME_BITS, GAME_ARRAY, GAME_CONNECT3 = 0, 1, 2     # 2 = the engine's second Game policy (three in a row wins)
 QUIRK_B1, QUIRK_B2, QUIRK_B4, QUIRK_B6 = 1, 2, 4, 8
 
 
@@ -69,6 +69,9 @@ def lib():
                                    vp, vp, vp, vp, vp, vp, vp, vp]
         L.azo_arena.restype = i32
         L.azo_arena.argtypes = [u64, u64, i32, u64, u64, u64, i32, u64, i32, i32, i32, vp, vp]
+        L.azo_arena_c3.restype = i32
+        L.azo_arena_c3.argtypes = L.azo_arena.argtypes
+        L.azo_c3_ended.restype = f32; L.azo_c3_ended.argtypes = [u64, u64]
         _lib = L
     return _lib
 
@@ -161,12 +164,13 @@ def selfplay(n_games, sims, net_kind=NET_STUB, salt=0, seed=0, first_game_id=0, 
 
 
 def arena(num, sims, net_kind=NET_HASH, salt=0, seed=0, new_model_id=1, old_model_id=0, cpuct=1, max_depth=1000,
-          reserve=None, threads=1):
+          reserve=None, threads=1, game_kind=GAME_BITS):
     reserve = reserve or default_reserve(sims)
     wld = np.zeros(3, np.uint64)
     results = np.zeros(max(num, 1), np.int8)
-    rc = lib().azo_arena(num, sims, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id,
-                         threads, _p(wld), _p(results))
+    fn = lib().azo_arena_c3 if game_kind == GAME_CONNECT3 else lib().azo_arena
+    rc = fn(num, sims, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id,
+            threads, _p(wld), _p(results))
     if rc != 0:
         raise RuntimeError("oracle arena failed")
     return wld, results[: 2 * (num // 2)]
@@ -200,6 +204,11 @@ def c4_play(mine, theirs, a):
 
 def c4_ended(mine, theirs):
     return float(lib().azo_c4_ended(int(mine), int(theirs)))
+
+
+def c3_ended(mine, theirs):
+    """get_game_ended(1) of the Connect Three variant (GAME_CONNECT3)."""
+    return float(lib().azo_c3_ended(int(mine), int(theirs)))
 
 
 def c4_valid_mask(mine, theirs):

@@ -14,7 +14,7 @@ use ndarray::{Array1, Array2, ArrayView1, ArrayView2, ArrayViewD};
 #[repr(C)] pub struct az_tree { _p: [u8; 0] }
 
 #[repr(C)] #[derive(Default, Clone, Copy)]
-pub struct az_config { pub device: i32, pub max_batch: i32, pub net_channels: i32, pub profile: i32 }
+pub struct az_config { pub device: i32, pub max_batch: i32, pub net_channels: i32, pub profile: i32, pub game: i32 }
 
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct az_stats {

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported(engine_mod):
 
 
 def test_struct_layouts_match_header(engine_mod):
-    assert ctypes.sizeof(engine_mod.az_config) == 16
+    assert ctypes.sizeof(engine_mod.az_config) == 20
     assert ctypes.sizeof(engine_mod.az_selfplay_params) == 64
     assert ctypes.sizeof(engine_mod.az_samples) == 64
     assert ctypes.sizeof(engine_mod.az_arena_params) == 48

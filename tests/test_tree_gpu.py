@@ -478,3 +478,41 @@ def test_tree_arena_is_kept_across_calls(engine, oracle, dedup_mode):
     w2, r2 = engine.arena(num_games=24, num_sims=25, new_model_id=10, old_model_id=11, seed=3)
     assert engine.stats()["tree_arena_allocs"] == a1 and np.array_equal(w1, w2) and np.array_equal(r1, r2)
     _compare_selfplay(engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=31, concurrent=16), ref)
+
+
+def test_second_game_through_the_seam(engine_mod, oracle):
+    """trait Game is a seam, not a hard-wired rule set (src/game.rs:10-28): an engine created with az_config.game =
+    AZ_GAME_CONNECT_THREE (Connect Four's board and moves, three in a row wins) runs the SAME tree kernel templates
+    instantiated with another policy struct (csrc/az_game.h) and matches the oracle's generic AsyncMcts<G> / execute_episode /
+    play_games on the twin game bit for bit, in all three tree modes; and it does not play Connect Four."""
+    e = engine_mod.Engine(device=0, max_batch=256, net_channels=128, game=engine_mod.GAME_CONNECT_THREE)
+    try:
+        e.net_set_kind(10, engine_mod.NET_HASH, HASH_SALT)
+        e.net_set_kind(11, engine_mod.NET_HASH, HASH_SALT)
+        n, sims = 96, 25
+        ref = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=5, threads=8, game_kind=oracle.GAME_CONNECT3)
+        ref4 = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=5, threads=8)
+        assert ref["game_len"].mean() < ref4["game_len"].mean() and not np.array_equal(ref["moves"], ref4["moves"])
+        owld, ores = oracle.arena(16, 25, net_kind=oracle.NET_HASH, salt=HASH_SALT, seed=9, new_model_id=10, old_model_id=11, threads=8,
+                                  game_kind=oracle.GAME_CONNECT3)
+        for dedup, fused in ((1, 1), (1, 0), (2, 1)):
+            e.set_option("eval_dedup", dedup)
+            e.set_option("fused_search", fused)
+            _compare_selfplay(e.selfplay(n_games=n, num_sims=sims, model_id=10, seed=5, concurrent=40), ref)
+            wld, res = e.arena(num_games=16, num_sims=25, new_model_id=10, old_model_id=11, seed=9)
+            assert np.array_equal(wld, owld) and np.array_equal(res, ores)
+        # fine-grained entry: one search from a position where three in a row is one move away for the side to move
+        s = (0, 0)
+        for a in (0, 6, 0, 5):
+            s = oracle.c4_play(s[0], s[1], a)
+        assert oracle.c3_ended(*oracle.c4_play(s[0], s[1], 0)) == -1.0 and oracle.c4_ended(*oracle.c4_play(s[0], s[1], 0)) == 0.0
+        tb = e.tree_create(2, reserve=oracle.default_reserve(50), num_sims=50, max_depth=1000, model_id=10, cpuct=1)
+        pi, counts, q = tb.get_action_prob(np.array([s, s], dtype=np.uint64), 1.0)
+        t = oracle.Tree(50, net_kind=oracle.NET_HASH, salt=oracle_salt(10), game_kind=oracle.GAME_CONNECT3)
+        opi, ocnt, oq = t.get_action_prob(s[0], s[1], 1.0)
+        assert np.array_equal(counts[0], ocnt) and np.array_equal(pi[1], opi) and np.array_equal(q[0], oq)
+        assert int(tb.node_counts()[0]) == t.stats()["nodes"]
+    finally:
+        e.close()
+    with pytest.raises(engine_mod.AzError):
+        engine_mod.Engine(device=0, game=7)
