@@ -524,6 +524,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "eval_cache_persist") == 0 && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
     if (std::strcmp(key, "fc_ring") == 0 && value >= 0 && value <= 2) { convnet_set_fc_ring((int)value); return AZ_OK; }
     if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
+    if (std::strcmp(key, "conv2_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv2_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv1_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv1_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {
         convnet_set_conv4_big((int)value);
@@ -547,6 +548,9 @@ az_status az_get_stats(az_engine* e, az_stats* out) {
     out->net_conv2_flops = e->netprof.conv2_flops;
     out->net_total_ms = e->netprof.total_ms;
     out->net_total_flops = e->netprof.total_flops;
+    out->net_conv3_ms = e->netprof.conv3_ms;
+    out->net_conv3_flops = e->netprof.conv3_flops;
+    out->net_conv2_bytes = e->netprof.conv2_bytes;
     out->tree_arena_allocs = e->tree_pool_allocs;
     return AZ_OK;
 }

@@ -36,8 +36,10 @@ struct Layout {
 };
 
 
-struct NetProfile {          // filled when profiling is on
-    double conv2_ms = 0, conv2_flops = 0, total_ms = 0, total_flops = 0;
+struct NetProfile {          // filled when profiling is on; flops = what the matrix cores were asked to do (a layer that
+    double conv2_ms = 0, conv2_flops = 0, total_ms = 0, total_flops = 0;   // runs as a table lookup contributes time, not flops)
+    double conv3_ms = 0, conv3_flops = 0;
+    double conv2_bytes = 0;  // conv2 as a table: table rows gathered + activation rows written (algorithmic bytes)
     uint64_t launches = 0;
 };
 
@@ -62,6 +64,7 @@ void netws_resolve_profile(NetWorkspace* ws, NetProfile* prof);
 void convnet_set_variant(int v);
 void convnet_set_conv4_big(int v);
 void convnet_set_conv1_table(int v);
+void convnet_set_conv2_table(int v);
 void convnet_set_fc_ring(int v);
 void convnet_set_ring_max_tiles(int v);
 // diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop

@@ -60,6 +60,11 @@ AZ_D uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
 }
 
+AZ_D uint32_t pack_f16x2(float lo, float hi) {
+    _Float16 a = (_Float16)lo, b = (_Float16)hi;       // round to nearest even
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
 // ---- conv1: 3x3 'same', 2 -> C, reading the bitboards (K4 + first conv fused) -------------------------
 // out: act1 [n][8][9][C] bf16, interior rows 1..6 / cols 1..7 (the zero halo is conv2's 'same' padding).
 // One WAVE = one board, a lane = 8 output channels (one 16-byte store per position; lanes c8 = lane, lane+64, ...).
@@ -169,6 +174,64 @@ __global__ __launch_bounds__(64) void k_conv1_table(const float* __restrict__ w 
     }
 }
 
+// ---- conv2 as a TABLE ---------------------------------------------------------------------------------------------
+// conv2 is LINEAR in conv1's output, and conv1's output at a position is one of 19683 table rows (above).  So the
+// contribution of filter tap t at a neighbour with pattern q is itself tabulated:  U[q][t][co] = sum_ci W2[co][t][ci] * T[q][ci]
+// ([19683][9][C] f16, 181 MB at C = 512; built once per weight upload as ONE bf16 MFMA GEMM of 93 GFLOP, M = 19683 patterns,
+// K = C, N = 9C, f32 accumulate), and conv2 at an output position is  relu(b + sum over its <= 9 in-board taps of U[pattern
+// of that neighbour][t]): nine gathered 1-KiB rows and 9 x C f32 adds instead of a 4608-long dot product per channel --
+// 198 of the net's 329 MFLOP per leaf are never executed.  Same network function; the rounding differs from the MFMA
+// path's (f32 sums over ci rounded to f16 -- 2^-11, below the bf16 rounding of the activation that follows -- then summed over
+// taps in f32), so it is a kernel set of its own ("conv2_table"), not bit-identical to the GEMM sets but equally
+// batch-independent and held to the same tolerance against the torch reference.
+// One wave per board: lanes 0..41 compute the board's 42 neighbourhood patterns once, then the wave walks the 42 output
+// positions; a lane owns 8 channels (16-byte f16 loads, one 16-byte bf16 store).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_conv2_table(const EvalBatch eb, const uint16_t* __restrict__ U /*[19683][9][C] f16*/,
+                                                     const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out /*[n][42][C] bf16*/,
+                                                     int C) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t boards = *eb.n;
+    const uint32_t wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    const int cg = C / 8;
+    for (uint32_t b = wave0; b < boards; b += nwaves) {
+        const ulonglong2 sv = eb.state[b];
+        const int ly = lane < 42 ? lane / 7 : 0, lx = lane < 42 ? lane % 7 : 0;
+        const uint32_t mypat = conv1_pattern(sv.x, sv.y, ly, lx);
+        for (int p = 0; p < 42; ++p) {
+            const int y = p / 7, x = p - y * 7;
+            uint32_t row[9];                       // table row (pattern * 9 + tap) of every in-board tap, else ~0
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int qy = y + t / 3 - 1, qx = x + t % 3 - 1;
+                const bool in = qy >= 0 && qy < 6 && qx >= 0 && qx < 7;
+                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)mypat, in ? qy * 7 + qx : 0);
+                row[t] = in ? pq * 9u + (uint32_t)t : 0xFFFFFFFFu;
+            }
+            for (int c8 = lane; c8 < cg; c8 += 64) {
+                f16x8 u[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if (row[t] != 0xFFFFFFFFu) u[t] = *(const f16x8*)(U + ((size_t)row[t] * C + (size_t)c8 * 8));
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; ++t)                 // taps in (ky, kx) order: the fixed summation order of a row
+                    if (row[t] != 0xFFFFFFFFu) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] += (float)u[t][i];
+                    }
+                const float4 b0 = *(const float4*)(bias + c8 * 8), b1 = *(const float4*)(bias + c8 * 8 + 4);
+                uint4 o;
+                o.x = pack_bf16x2(fmaxf(acc[0] + b0.x, 0.f), fmaxf(acc[1] + b0.y, 0.f));
+                o.y = pack_bf16x2(fmaxf(acc[2] + b0.z, 0.f), fmaxf(acc[3] + b0.w, 0.f));
+                o.z = pack_bf16x2(fmaxf(acc[4] + b1.x, 0.f), fmaxf(acc[5] + b1.y, 0.f));
+                o.w = pack_bf16x2(fmaxf(acc[6] + b1.z, 0.f), fmaxf(acc[7] + b1.w, 0.f));
+                *(uint4*)(out + ((size_t)b * 42 + p) * C + (size_t)c8 * 8) = o;
+            }
+        }
+    }
+}
+
 // ---- implicit GEMM on MFMA: out[M,N] = relu(A_gather[M,K] * W[N,K]^T + bias) ---------------------------
 // Row m = (sample b, output position (y,x)); K index = tap * cin + c with tap = ky*tap_w + kx reading the
 // input at position (y+ky, x+kx) of an [in_h][in_w][in_c] channels-last image (the 'same' conv reads a
@@ -188,6 +251,7 @@ struct GemmDesc {
     int relu;
     unsigned long long* dbg;   // diagnostic builds only (ABLATE == 3): per-block {shader cycles, 100 MHz ticks}
     const ulonglong2* states;  // k_conv_img2<.., true> only: the batch's canonical bitboards (A is then the conv1 table)
+    int out_f16;               // k_gemm_mfma only: store the raw f32 accumulators as f16 (no bias, no ReLU): the conv2 table build
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -278,11 +342,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
     }
 #undef AZ_GLOAD
 #undef AZ_SWRITE
-    // epilogue: + bias, ReLU, bf16, out[m][n .. n+3]
+    // epilogue: + bias, ReLU, bf16, out[m][n .. n+3]  (out_f16: the raw sums as f16)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
+        const float4 bv = d.out_f16 ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(d.bias + n);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int m = m0 + wr * 64 + mt * 16 + frow;
@@ -291,8 +355,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
                   r3 = acc[mt][nt][3] + bv.w;
             if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
             uint2 o;
-            o.x = pack_bf16x2(r0, r1);
-            o.y = pack_bf16x2(r2, r3);
+            if (d.out_f16) {
+                o.x = pack_f16x2(r0, r1);
+                o.y = pack_f16x2(r2, r3);
+            } else {
+                o.x = pack_bf16x2(r0, r1);
+                o.y = pack_bf16x2(r2, r3);
+            }
             *(uint2*)(d.out + (size_t)m * d.N + n) = o;
         }
     }
@@ -1159,6 +1228,9 @@ struct ConvNet {                      // the WEIGHTS of one model id (21 MB bf16
     std::vector<void*> dev;           // every device allocation
     float *w1 = nullptr, *b1 = nullptr;              // conv1 folded f32 [18][C], [C]
     uint16_t* t1 = nullptr;                            // conv1 table [19683][C] bf16 (k_conv1_table)
+    uint16_t* u2 = nullptr;                            // conv2 table [19683][9][C] f16
+    uint16_t* w2r = nullptr;                           // conv2's folded weights rearranged [tap*C + co][ci] bf16 (the table GEMM's W)
+    uint32_t* npat = nullptr;                          // device constant 19683 (the table GEMM's row count)
     uint16_t* wg[5] = {nullptr};                       // conv2,3,4, fc1, fc2 folded bf16 [N][K]
     float* bg[5] = {nullptr};                          // folded bias f32 [N]
     float *wh = nullptr, *bh = nullptr;              // heads f32 [8][512], [8]
@@ -1177,7 +1249,7 @@ struct NetWorkspace {
     std::vector<void*> dev;
     uint16_t *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *fc1o = nullptr, *fc2o = nullptr;
     // profiling: event quads per forward + pinned copies of the batch size
-    struct Rec { hipEvent_t e0, e1, e2, e3; uint32_t* n; };
+    struct Rec { hipEvent_t e0, e1, e2, e2b, e3; uint32_t* n; int table2; };   // e1..e2 conv2, e2..e2b conv3
     std::vector<Rec> open;
     std::vector<hipEvent_t> ev_pool;
     uint32_t* pinned_n = nullptr;          // host copy of d_nlog (one copy per resolve, not one per forward)
@@ -1203,6 +1275,10 @@ ConvNet* convnet_create(int channels, const char** err) {
     ok &= (n->w1 = n->dalloc<float>(18 * (size_t)C)) != nullptr;
     ok &= (n->b1 = n->dalloc<float>(C)) != nullptr;
     ok &= (n->t1 = n->dalloc<uint16_t>((size_t)CONV1_PATTERNS * C)) != nullptr;
+    ok &= (n->u2 = n->dalloc<uint16_t>((size_t)CONV1_PATTERNS * 9 * C)) != nullptr;
+    ok &= (n->w2r = n->dalloc<uint16_t>((size_t)9 * C * C)) != nullptr;
+    ok &= (n->npat = n->dalloc<uint32_t>(1)) != nullptr;
+    if (ok) { const uint32_t np = CONV1_PATTERNS; ok = hipMemcpy(n->npat, &np, sizeof np, hipMemcpyHostToDevice) == hipSuccess; }
     const size_t wk[5] = {9 * (size_t)C, 9 * (size_t)C, 9 * (size_t)C, 6 * (size_t)C, 1024};
     const size_t wn[5] = {(size_t)C, (size_t)C, (size_t)C, 1024, 512};
     for (int l = 0; l < 5; ++l) {
@@ -1261,7 +1337,7 @@ static bool netws_need_act1(NetWorkspace* n) {
 void netws_destroy(NetWorkspace* n) {
     if (!n) return;
     for (void* p : n->dev) (void)hipFree(p);
-    for (auto& r : n->open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); (void)hipEventDestroy(r.e3); }
+    for (auto& r : n->open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); (void)hipEventDestroy(r.e2b); (void)hipEventDestroy(r.e3); }
     for (auto e : n->ev_pool) (void)hipEventDestroy(e);
     if (n->pinned_n) (void)hipHostFree(n->pinned_n);
     delete n;
@@ -1310,6 +1386,20 @@ bool convnet_set_params(ConvNet* net, const float* p, int64_t count) {
         }
         ok &= hipMemcpy(net->wg[l], w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
         ok &= hipMemcpy(net->bg[l], b.data(), b.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if (l == 0) {   // conv2: the same bf16 values as [tap*C + co][ci] for the table GEMM, then U = T x W2r^T
+            std::vector<uint16_t> wr((size_t)9 * C * C);
+            for (int co = 0; co < C; ++co)
+                for (int t = 0; t < 9; ++t)
+                    std::memcpy(&wr[((size_t)t * C + co) * C], &w[(size_t)co * K[0] + (size_t)t * C], (size_t)C * 2);
+            ok &= hipMemcpy(net->w2r, wr.data(), wr.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+            GemmDesc d{};
+            d.A = net->t1; d.W = net->w2r; d.bias = net->bg[0]; d.out = net->u2; d.n_dev = net->npat;
+            d.rows_per_sample = 1; d.out_w = 1; d.in_h = 1; d.in_w = 1; d.in_c = C; d.tap_w = 1; d.cin = C; d.K = C; d.N = 9 * C;
+            d.relu = 0; d.out_f16 = 1;
+            const int mt8 = ((CONV1_PATTERNS + GBM - 1) / GBM + 7) / 8 * 8;
+            hipLaunchKernelGGL(k_gemm_mfma<6>, dim3(mt8 * (d.N / GBN)), dim3(256), 0, nullptr, d);
+            ok &= hipDeviceSynchronize() == hipSuccess;
+        }
     }
     {   // heads: f32 [8][512]
         std::vector<float> w(8 * 512), b(8);
@@ -1441,16 +1531,24 @@ void netws_resolve_profile(NetWorkspace* n, NetProfile* prof) {
     if (!n->open.empty() && hipMemcpy(n->pinned_n, n->d_nlog, (size_t)n->pinned_next * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
         prof = nullptr;
     for (auto& r : n->open) {
-        float conv2 = 0, total = 0;
-        if (hipEventElapsedTime(&conv2, r.e1, r.e2) == hipSuccess && hipEventElapsedTime(&total, r.e0, r.e3) == hipSuccess && prof) {
+        float conv2 = 0, conv3 = 0, total = 0;
+        if (hipEventElapsedTime(&conv2, r.e1, r.e2) == hipSuccess && hipEventElapsedTime(&conv3, r.e2, r.e2b) == hipSuccess &&
+            hipEventElapsedTime(&total, r.e0, r.e3) == hipSuccess && prof) {
             const double rows = (double)*r.n;
             prof->conv2_ms += conv2;
-            prof->conv2_flops += f_conv * 42.0 * rows;
+            prof->conv3_ms += conv3;
+            prof->conv3_flops += f_conv * 20.0 * rows;
             prof->total_ms += total;
-            prof->total_flops += per_sample * rows;
+            if (r.table2) {     // conv1 + conv2 are table lookups
+                prof->conv2_bytes += rows * (304.0 * C * 2 + 42.0 * C * 2);      // 16 x 19 = 304 in-board (position, tap) pairs
+                prof->total_flops += (per_sample - 2.0 * (42.0 * 18 * C) - f_conv * 42.0) * rows;
+            } else {
+                prof->conv2_flops += f_conv * 42.0 * rows;
+                prof->total_flops += per_sample * rows;
+            }
             prof->launches += 1;
         }
-        n->ev_pool.push_back(r.e0); n->ev_pool.push_back(r.e1); n->ev_pool.push_back(r.e2); n->ev_pool.push_back(r.e3);
+        n->ev_pool.push_back(r.e0); n->ev_pool.push_back(r.e1); n->ev_pool.push_back(r.e2); n->ev_pool.push_back(r.e2b); n->ev_pool.push_back(r.e3);
     }
     n->open.clear();
     n->pinned_next = 0;
@@ -1463,6 +1561,8 @@ bool netws_read_clock_stamps(NetWorkspace* n, unsigned long long* out2048) {
 void convnet_set_conv4_big(int v) { g_conv4_big = v; }
 void convnet_set_fc_ring(int v) { g_fc_ring = v; }
 void convnet_set_ring_max_tiles(int v) { g_ring_max_tiles = v; }
+int g_conv2_table = 1;    // conv2 as nine gathered rows of the per-model U table (default kernel set only; "conv2_table"); 0 = MFMA GEMM
+void convnet_set_conv2_table(int v) { g_conv2_table = v; }
 int g_conv1_table = 1;    // conv2 gathers its image from the conv1 table (default kernel set only); 0 = run k_conv1 into act1
 void convnet_set_conv1_table(int v) { g_conv1_table = v; }
 
@@ -1475,14 +1575,16 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     uint32_t* n_log = nullptr;
     const bool timed = prof != nullptr && ws->pinned_next < ws->pinned_cap;
     if (timed) {
-        rec.e0 = net_event(ws); rec.e1 = net_event(ws); rec.e2 = net_event(ws); rec.e3 = net_event(ws);
+        rec.e0 = net_event(ws); rec.e1 = net_event(ws); rec.e2 = net_event(ws); rec.e2b = net_event(ws); rec.e3 = net_event(ws);
         rec.n = ws->pinned_n + ws->pinned_next;
         n_log = ws->d_nlog + ws->pinned_next++;
         (void)hipEventRecord(rec.e0, s);
     }
     // conv1 + conv2: the default kernel set gathers conv2's image from the conv1 table; the others run conv1 into act1
-    const bool table = g_conv1_table && g_gemm_variant == 5 && C % HBN_ == 0;
-    if (!table) {
+    const bool table2 = g_conv2_table && g_gemm_variant == 5;
+    const bool table = !table2 && g_conv1_table && g_gemm_variant == 5 && C % HBN_ == 0;
+    rec.table2 = table2 ? 1 : 0;
+    if (!table && !table2) {
         if (!netws_need_act1(ws)) return;
         const size_t waves = (size_t)rows_hint;                                        // one wave per board
         const size_t blocks = std::min<size_t>((waves + 3) / 4, 256 * 4);            // 4 persistent blocks per CU (38 KiB LDS each)
@@ -1498,13 +1600,19 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.W = n->wg[0]; d.bias = n->bg[0]; d.out = ws->act2;
     d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;
     if (timed) (void)hipEventRecord(rec.e1, s);
-    launch_gemm<1>(d, rows_hint, rows_typ, s);
+    if (table2) {
+        const size_t blocks = std::min<size_t>(((size_t)rows_hint + 3) / 4, 256 * 8);       // one wave per board
+        hipLaunchKernelGGL(k_conv2_table, dim3((unsigned)blocks), dim3(256), 0, s, eb, n->u2, n->bg[0], ws->act2, C);
+    } else {
+        launch_gemm<1>(d, rows_hint, rows_typ, s);
+    }
     if (timed) (void)hipEventRecord(rec.e2, s);
     d.states = nullptr;
     // conv3: 3x3 valid [6][7][C] -> [4][5][C]
     d.A = ws->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = ws->act3;
     d.rows_per_sample = 20; d.out_w = 5; d.in_h = 6; d.in_w = 7;
     launch_gemm<2>(d, rows_hint, rows_typ, s);
+    if (timed) (void)hipEventRecord(rec.e2b, s);
     // conv4: 3x3 valid [4][5][C] -> [2][3][C]
     d.A = ws->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = ws->act4;
     d.rows_per_sample = 6; d.out_w = 3; d.in_h = 4; d.in_w = 5;

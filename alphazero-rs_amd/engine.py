@@ -47,7 +47,9 @@ class az_stats(C.Structure):
                [(n, C.c_double) for n in ("net_conv2_ms", "net_conv2_flops", "net_total_ms", "net_total_flops",
                                           "tree_ms", "tree_bytes", "device_ms")] + \
                [(n, C.c_uint64) for n in ("leaf_rows_requested", "leaf_rows_executed", "eval_cache_hits", "eval_batch_dups",
-                                          "eval_cache_inserts", "tree_launches", "tree_launches_timed", "tree_arena_allocs")]
+                                          "eval_cache_inserts")] + \
+               [(n, C.c_double) for n in ("net_conv3_ms", "net_conv3_flops", "net_conv2_bytes")] + \
+               [(n, C.c_uint64) for n in ("tree_launches", "tree_launches_timed", "tree_arena_allocs")]
 
 
 class az_selfplay_params(C.Structure):

@@ -86,9 +86,9 @@ typedef struct az_stats {
     uint64_t samples;        /* training tuples emitted (before symmetries) */
     uint64_t net_launches;   /* conv2 launches timed (profile mode) */
     double net_conv2_ms;     /* summed conv2 kernel time (profile mode) */
-    double net_conv2_flops;  /* summed conv2 algorithmic flops (profile mode) */
+    double net_conv2_flops;  /* summed conv2 MFMA flops (profile mode); 0 while conv2 runs as a table lookup */
     double net_total_ms;     /* summed whole-forward time (profile mode) */
-    double net_total_flops;  /* summed whole-forward algorithmic flops (profile mode) */
+    double net_total_flops;  /* summed whole-forward flops of the layers that ran as arithmetic (profile mode) */
     double tree_ms;          /* summed select+backup kernel time (profile mode) */
     double tree_bytes;       /* summed algorithmic tree bytes, SURVEY.md 8d (profile mode) */
     double device_ms;        /* summed wall time spent inside engine calls */
@@ -99,6 +99,9 @@ typedef struct az_stats {
     uint64_t eval_cache_hits;
     uint64_t eval_batch_dups;
     uint64_t eval_cache_inserts;
+    double net_conv3_ms;           /* summed conv3 kernel time (profile mode) */
+    double net_conv3_flops;        /* summed conv3 algorithmic flops (profile mode) */
+    double net_conv2_bytes;        /* conv2 as a table ("conv2_table"): summed algorithmic bytes (table rows gathered + rows written) */
     uint64_t tree_launches;        /* select/backup launches (profile mode brackets every "profile_every"-th of them) */
     uint64_t tree_launches_timed;  /* ... of which tree_ms was measured on */
     uint64_t tree_arena_allocs;  /* tree arenas hipMalloc'ed by az_selfplay / az_arena since az_create (kept and reused across
@@ -116,7 +119,11 @@ const char* az_last_error(const az_engine* e);
  * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto). "profile_every" = n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and tree_ms
  * sums then cover that sample of launches; every bracket costs a little GPU idle time between dependent kernels). "fused_search" = 1
  * (default): the stub / hash nets run a whole search in one launch, 0 = one launch per simulation like the conv net. "fc_ring" = 1
- * (default): LDS-DMA ring kernel for fc1 / fc2 / small-batch conv4, 0 = register-staged tiles. "conv1_table" = 1 (default): conv2 of the default kernel set gathers its input image from the
+ * (default): LDS-DMA ring kernel for fc1 / fc2 / small-batch conv4, 0 = register-staged tiles. "conv2_table" = 1 (default): conv2 of the
+ * default kernel set is nine gathered rows of a per-model table (conv2 is linear in conv1's output, which is one of 3^9 table rows
+ * per position: csrc/az_net.hip) -- 198 of the net's 329 MFLOP per leaf are never executed; 0 = conv2 as the MFMA implicit GEMM
+ * (same function, different rounding: each is batch-independent and within the stated tolerance of the fp32 reference).
+ * "conv1_table" = 1 (default): conv2 of the default kernel set gathers its input image from the
  * per-model conv1 table (3^9 neighbourhood patterns x C channels) instead of running conv1 as a kernel, 0 = conv1 kernel; bit-identical.
  * Leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
  * src/node.rs:282-289): "eval_dedup" = 0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is

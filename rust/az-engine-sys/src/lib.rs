@@ -23,7 +23,8 @@ pub struct az_stats {
     pub net_conv2_ms: f64, pub net_conv2_flops: f64, pub net_total_ms: f64, pub net_total_flops: f64,
     pub tree_ms: f64, pub tree_bytes: f64, pub device_ms: f64,
     pub leaf_rows_requested: u64, pub leaf_rows_executed: u64, pub eval_cache_hits: u64, pub eval_batch_dups: u64,
-    pub eval_cache_inserts: u64, pub tree_launches: u64, pub tree_launches_timed: u64, pub tree_arena_allocs: u64,
+    pub eval_cache_inserts: u64, pub net_conv3_ms: f64, pub net_conv3_flops: f64, pub net_conv2_bytes: f64,
+    pub tree_launches: u64, pub tree_launches_timed: u64, pub tree_arena_allocs: u64,
 }
 
 #[repr(C)] #[derive(Clone, Copy)]

@@ -82,6 +82,7 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
     tile-aligned batch sizes, so the A/B switch never changes what a search sees."""
     conv_engine.net_init_random(5, seed=21)
     try:
+        conv_engine.set_option("conv2_table", 0)        # the GEMM kernel sets; conv2 as a table has its own rounding (below)
         for n in (1, 257, 1530):
             states = random_states(oracle, n, seed=900 + n)
             outs = []
@@ -99,6 +100,7 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
     finally:
         conv_engine.set_option("gemm_variant", 5)
         conv_engine.set_option("conv4_big", 2)
+        conv_engine.set_option("conv2_table", 1)
 
 
 def test_net_parity_at_bench_scale(engine, oracle):
@@ -112,6 +114,7 @@ def test_net_parity_at_bench_scale(engine, oracle):
     try:
         engine.set_option("gemm_variant", 5)
         engine.set_option("conv4_big", 2)
+        engine.set_option("conv2_table", 0)
         ref_pi = np.empty((8192, 7), np.float32)
         ref_v = np.empty(8192, np.float32)
         for o in range(0, 8192, 256):
@@ -135,11 +138,28 @@ def test_net_parity_at_bench_scale(engine, oracle):
         engine.set_option("gemm_variant", 5)
         engine.set_option("conv4_big", 2)
         engine.set_option("conv1_table", 1)
+        engine.set_option("conv2_table", 1)
     n = 4096
     boards = np.stack([oracle.c4_features(int(m), int(t)) for m, t in states[:n]])
     rpi, rv = forward_ref(engine.net_get_params(20), boards, C, emulate_bf16=True)
     assert np.abs(ref_pi[:n] - rpi).max() <= 2e-3, np.abs(ref_pi[:n] - rpi).max()
     assert np.abs(ref_v[:n] - rv).max() <= 6e-3, np.abs(ref_v[:n] - rv).max()
+    # the default set: conv2 as nine gathered table rows.  Its own rounding, so its own reference chunks: full-size calls ==
+    # chunks of 256 == any row order, bit for bit, and the same tolerance against the torch reference
+    tab_pi = np.empty((8192, 7), np.float32)
+    tab_v = np.empty(8192, np.float32)
+    for o in range(0, 8192, 256):
+        tab_pi[o:o + 256], tab_v[o:o + 256] = engine.predict_states(states[o:o + 256], 20)
+    for m in (8192, 5003):
+        pi, v = engine.predict_states(states[:m], 20)
+        assert np.array_equal(pi, tab_pi[:m]) and np.array_equal(v, tab_v[:m]), m
+    pi, v = engine.predict_states(states[perm], 20)
+    assert np.array_equal(pi, tab_pi[perm]) and np.array_equal(v, tab_v[perm])
+    assert np.abs(tab_pi[:n] - rpi).max() <= 2e-3, np.abs(tab_pi[:n] - rpi).max()
+    assert np.abs(tab_v[:n] - rv).max() <= 6e-3, np.abs(tab_v[:n] - rv).max()
+    assert not np.array_equal(tab_pi, ref_pi)                       # (a different rounding, not a different function)
+    print("conv2 table vs GEMM sets: max |dpi|", np.abs(tab_pi - ref_pi).max(), "max |dv|", np.abs(tab_v - ref_v).max(),
+          "| vs torch: table", np.abs(tab_pi[:n] - rpi).max(), np.abs(tab_v[:n] - rv).max(), "GEMM", np.abs(ref_pi[:n] - rpi).max(), np.abs(ref_v[:n] - rv).max())
 
 
 def test_init_random_and_checkpoint_roundtrip(conv_engine, oracle, tmp_path):
