@@ -184,35 +184,43 @@ __global__ __launch_bounds__(64) void k_conv1_table(const float* __restrict__ w 
 // path's (f32 sums over ci rounded to f16 -- 2^-11, below the bf16 rounding of the activation that follows -- then summed over
 // taps in f32), so it is a kernel set of its own ("conv2_table"), not bit-identical to the GEMM sets but equally
 // batch-independent and held to the same tolerance against the torch reference.
-// One wave per board: lanes 0..41 compute the board's 42 neighbourhood patterns once, then the wave walks the 42 output
-// positions; a lane owns 8 channels (16-byte f16 loads, one 16-byte bf16 store).
+// One wave per (board, board row): lanes 0..20 compute the patterns of the three rows of neighbours, then the wave walks the
+// row's 7 output positions; a lane owns 8 channels (16-byte f16 loads, one 16-byte bf16 store).  The rows of pattern 0 (an
+// empty neighbourhood -- the most frequent one by far) are staged in LDS once per block.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void k_conv2_table(const EvalBatch eb, const uint16_t* __restrict__ U /*[19683][9][C] f16*/,
                                                      const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out /*[n][42][C] bf16*/,
                                                      int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char u0_lds[];       // U[0][0..8][C] f16
+    for (int i = threadIdx.x; i < 9 * C / 8; i += blockDim.x) ((uint4*)u0_lds)[i] = ((const uint4*)U)[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t boards = *eb.n;
+    const uint32_t items = *eb.n * 6u;
     const uint32_t wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
     const int cg = C / 8;
-    for (uint32_t b = wave0; b < boards; b += nwaves) {
+    for (uint32_t it = wave0; it < items; it += nwaves) {
+        const uint32_t b = it / 6u;
+        const int y = (int)(it - b * 6u);
         const ulonglong2 sv = eb.state[b];
-        const int ly = lane < 42 ? lane / 7 : 0, lx = lane < 42 ? lane % 7 : 0;
-        const uint32_t mypat = conv1_pattern(sv.x, sv.y, ly, lx);
-        for (int p = 0; p < 42; ++p) {
-            const int y = p / 7, x = p - y * 7;
+        const int ly = y - 1 + (lane < 21 ? lane / 7 : 0), lx = lane < 21 ? lane % 7 : 0;
+        const uint32_t mypat = (ly >= 0 && ly < 6) ? conv1_pattern(sv.x, sv.y, ly, lx) : 0u;
+        for (int x = 0; x < 7; ++x) {
             uint32_t row[9];                       // table row (pattern * 9 + tap) of every in-board tap, else ~0
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int qy = y + t / 3 - 1, qx = x + t % 3 - 1;
+                const int ky = t / 3, qy = y + ky - 1, qx = x + t % 3 - 1;
                 const bool in = qy >= 0 && qy < 6 && qx >= 0 && qx < 7;
-                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)mypat, in ? qy * 7 + qx : 0);
+                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)mypat, in ? ky * 7 + qx : 0);
                 row[t] = in ? pq * 9u + (uint32_t)t : 0xFFFFFFFFu;
             }
             for (int c8 = lane; c8 < cg; c8 += 64) {
                 f16x8 u[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    if (row[t] != 0xFFFFFFFFu) u[t] = *(const f16x8*)(U + ((size_t)row[t] * C + (size_t)c8 * 8));
+                for (int t = 0; t < 9; ++t) {
+                    if (row[t] == 0xFFFFFFFFu) continue;
+                    if (row[t] < 9u) u[t] = *(const f16x8*)(u0_lds + ((size_t)row[t] * C + (size_t)c8 * 8) * 2);
+                    else u[t] = *(const f16x8*)(U + ((size_t)row[t] * C + (size_t)c8 * 8));
+                }
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 9; ++t)                 // taps in (ky, kx) order: the fixed summation order of a row
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void k_conv2_table(const EvalBatch eb, const u
                 o.y = pack_bf16x2(fmaxf(acc[2] + b0.z, 0.f), fmaxf(acc[3] + b0.w, 0.f));
                 o.z = pack_bf16x2(fmaxf(acc[4] + b1.x, 0.f), fmaxf(acc[5] + b1.y, 0.f));
                 o.w = pack_bf16x2(fmaxf(acc[6] + b1.z, 0.f), fmaxf(acc[7] + b1.w, 0.f));
-                *(uint4*)(out + ((size_t)b * 42 + p) * C + (size_t)c8 * 8) = o;
+                *(uint4*)(out + ((size_t)b * 42 + (size_t)(y * 7 + x)) * C + (size_t)c8 * 8) = o;
             }
         }
     }
@@ -1601,8 +1609,8 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;
     if (timed) (void)hipEventRecord(rec.e1, s);
     if (table2) {
-        const size_t blocks = std::min<size_t>(((size_t)rows_hint + 3) / 4, 256 * 8);       // one wave per board
-        hipLaunchKernelGGL(k_conv2_table, dim3((unsigned)blocks), dim3(256), 0, s, eb, n->u2, n->bg[0], ws->act2, C);
+        const size_t blocks = std::min<size_t>(((size_t)rows_hint * 6 + 3) / 4, 256 * 8);   // one wave per (board, board row)
+        hipLaunchKernelGGL(k_conv2_table, dim3((unsigned)blocks), dim3(256), (size_t)9 * C * 2, s, eb, n->u2, n->bg[0], ws->act2, C);
     } else {
         launch_gemm<1>(d, rows_hint, rows_typ, s);
     }

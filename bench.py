@@ -27,7 +27,9 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0
-FLOP_PER_LEAF = 328_986_624
+FLOP_PER_LEAF = 328_986_624  # the net as dense arithmetic
+# with conv1 and conv2 as table lookups (az_set_option "conv2_table", the default) those two layers' flops are never executed
+FLOP_PER_LEAF_TABLES = FLOP_PER_LEAF - 2 * 42 * 18 * 512 - 2 * 42 * 512 * 4608
 
 
 def cpu_baseline(params, channels, sims, mean_plies=None, budget_s=20.0, seed=1):
@@ -191,6 +193,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary no-dedup and arena (config 3) measurements")
     ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
+    ap.add_argument("--conv2-table", type=int, default=1, choices=[0, 1], help="conv1 + conv2 as table lookups (default) / 0 = conv2 as the MFMA implicit GEMM")
     ap.add_argument("--dedup", type=int, default=1, choices=[0, 1], help="leaf de-duplication + per-call evaluation cache (bit-exact); 0 = every requested row runs")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and run the gather even at world size 1 (rehearsal)")
     ap.add_argument("--dry-dist", default="", choices=["", "gloo"],
@@ -229,6 +232,7 @@ def main():
     e = azeng.Engine(device=local_rank, max_batch=args.games, net_channels=args.channels, profile=not args.no_profile)
     e.set_option("eval_dedup", args.dedup)
     e.set_option("profile_every", args.profile_every)
+    e.set_option("conv2_table", args.conv2_table)
     if args.net == "conv":
         e.net_init_random(0, seed=args.seed)       # identical weights on every rank (replicated, 21.5 MB bf16)
     else:
@@ -282,6 +286,7 @@ def main():
         expansions, simulations, leaf_evals, plies_all = st["expansions"], st["simulations"], st["leaf_evals"], plies
         rows_exec, cache_hits, batch_dups = st["leaf_rows_executed"], st["eval_cache_hits"], st["eval_batch_dups"]
 
+    flop_exec = FLOP_PER_LEAF_TABLES if args.conv2_table else FLOP_PER_LEAF
     if rank == 0:
         games = episodes * args.steps * world
         line = {
@@ -302,30 +307,55 @@ def main():
                           "executed_over_requested": rows_exec / max(1.0, leaf_evals),
                           "cache_hits_over_requested": cache_hits / max(1.0, leaf_evals),
                           "batch_duplicates_over_requested": batch_dups / max(1.0, leaf_evals), "dedup": args.dedup},
-            "mfma_fraction_end_to_end": (rows_exec / dt) * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12 * world) if args.net == "conv" else None,
+            # MFMA flops the chip really executed (conv3, conv4, fc1, fc2 + heads; conv1 / conv2 are table lookups unless
+            # --conv2-table 0) over the dense bf16 peak; "as_dense" prices the same rows as if every layer were dense arithmetic
+            "mfma_fraction_end_to_end": (rows_exec / dt) * flop_exec / (MFMA_PEAK_TFLOPS * 1e12 * world) if args.net == "conv" else None,
+            "net_flops": {"per_row_executed": flop_exec, "per_row_as_dense": FLOP_PER_LEAF, "conv2_table": args.conv2_table,
+                          "fraction_as_dense": (rows_exec / dt) * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12 * world)} if args.net == "conv" else None,
         }
         roof = None
         if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:
-            ach = st["net_conv2_flops"] / (st["net_conv2_ms"] * 1e-3) / 1e12
-            # HBM traffic of the same kernel from the committed PMC passes (profiles/r01k_pmc_traffic.json: separate
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command -- tools/collect_profiles.sh, gfx950 correction
-            # applied), scaled by this run's mean leaves per launch.  bench.py cannot collect PMC counters itself.
-            traffic, traffic_src = None, None
             pmc, pmc_name = committed_pmc()
-            if pmc:
+
+            def pmc_traffic(kernel_substr, flop_sum, flop_per_row):
+                """HBM bytes per launch of the committed PMC passes, scaled to this run's mean rows per launch."""
+                if not pmc:
+                    return None, None
                 for k, v in pmc["kernels"].items():
-                    if "k_conv_img2<1" in k:
-                        traffic = v["hbm_bytes_per_leaf"] * (st["net_conv2_flops"] / st["net_launches"]) / (2.0 * 42 * 512 * 4608)
-                        traffic_src = pmc_name
-            roof = {"bound": "mfma", "kernel": "k_conv_img2<1, true> (conv2: 3x3 same, 512->512, image-resident implicit GEMM on MFMA, two 4-wave "
-                                               "workgroups per CU, input image gathered from the conv1 pattern table)",
-                    "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{traffic_src}: "
-                                                        "bytes per executed row x this run's mean rows per launch)",
-                    "launches": st["net_launches"], "launches_are": f"every {args.profile_every}th simulation step of the timed region (HIP events on the engine's stream)",
-                    "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"],
-                    "avg_flop_per_launch": st["net_conv2_flops"] / st["net_launches"],
-                    "net_forward_tflops": st["net_total_flops"] / (st["net_total_ms"] * 1e-3) / 1e12}
+                    if kernel_substr in k:
+                        return v["hbm_bytes_per_leaf"] * (flop_sum / st["net_launches"]) / flop_per_row, pmc_name
+                return None, None
+            common = {"peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": st["net_launches"],
+                      "launches_are": f"every {args.profile_every}th simulation step of the timed region (HIP events on the engine's stream)",
+                      "net_forward_tflops": st["net_total_flops"] / (st["net_total_ms"] * 1e-3) / 1e12,
+                      "net_forward_ms": st["net_total_ms"] / st["net_launches"]}
+            if args.conv2_table:
+                # conv2 is a table gather now; the dominant kernel (and the dominant MFMA kernel) is conv3
+                ach = st["net_conv3_flops"] / (st["net_conv3_ms"] * 1e-3) / 1e12
+                traffic, src = pmc_traffic("k_conv_valid_img2<2", st["net_conv3_flops"], 2.0 * 20 * 512 * 4608)
+                roof = {"bound": "mfma", "kernel": "k_conv_valid_img2<2, 12, 6, 7, 2> (conv3: 3x3 valid, 512->512, image-resident implicit GEMM on "
+                                                   "MFMA, 12 boards x 128 channels per tile, two 4-wave workgroups per CU)",
+                        "achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{src}: bytes per executed row x "
+                                        "this run's mean rows per launch)",
+                        "avg_launch_ms": st["net_conv3_ms"] / st["net_launches"], "avg_flop_per_launch": st["net_conv3_flops"] / st["net_launches"],
+                        **common}
+                gb = st["net_conv2_bytes"] / (st["net_conv2_ms"] * 1e-3) / 1e9
+                line["conv2_table"] = {"bound": "hbm", "kernel": "k_conv2_table (conv1 + conv2 as nine gathered rows of the per-model U table per output "
+                                                                 "position; 181 MB f16 table, served mostly from L2 / Infinity Cache)",
+                                       "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                                       "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"],
+                                       "algorithmic_bytes_per_row": st["net_conv2_bytes"] / max(1.0, st["net_conv3_flops"] / (2.0 * 20 * 512 * 4608)),
+                                       "note": "achieved counts the table rows gathered + activation rows written per launch; above the HBM peak means cache hits"}
+            else:
+                ach = st["net_conv2_flops"] / (st["net_conv2_ms"] * 1e-3) / 1e12
+                traffic, src = pmc_traffic("k_conv_img2<1", st["net_conv2_flops"], 2.0 * 42 * 512 * 4608)
+                roof = {"bound": "mfma", "kernel": "k_conv_img2<1, true> (conv2: 3x3 same, 512->512, image-resident implicit GEMM on MFMA, two 4-wave "
+                                                   "workgroups per CU, input image gathered from the conv1 pattern table)",
+                        "achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{src})",
+                        "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"], "avg_flop_per_launch": st["net_conv2_flops"] / st["net_launches"],
+                        **common}
         elif not args.no_profile and st["tree_ms"] > 0:
             ach = tree_gbps(st)
             roof = {"bound": "hbm", "kernel": "k_select + k_backup (tree traversal)", "achieved": ach,
@@ -390,13 +420,33 @@ def main():
                 dta = time.perf_counter() - t1
                 sa = e.stats()
                 line["no_dedup"] = {"games_per_sec": args.games / dta, "episodes": args.games, "leaf_evals_per_sec": sa["leaf_evals"] / dta,
-                                    "mfma_fraction_end_to_end": sa["leaf_rows_executed"] / dta * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12),
-                                    "conv2_tflops": sa["net_conv2_flops"] / (sa["net_conv2_ms"] * 1e-3) / 1e12 if sa["net_conv2_ms"] else None,
+                                    "mfma_fraction_end_to_end": sa["leaf_rows_executed"] / dta * flop_exec / (MFMA_PEAK_TFLOPS * 1e12),
+                                    "conv3_tflops": sa["net_conv3_flops"] / (sa["net_conv3_ms"] * 1e-3) / 1e12 if sa["net_conv3_ms"] else None,
                                     "note": "one episode batch of --games episodes (no refill), eval_dedup = 0"}
             except Exception as ex:
                 line["no_dedup"] = {"error": repr(ex)}
             finally:
                 e.set_option("eval_dedup", args.dedup)
+            # (a2) the same workload with conv2 as the MFMA implicit GEMM (round 1's dominant kernel), de-duplication on
+            try:
+                e.set_option("conv2_table", 0)
+                e.reset_stats()
+                t1 = time.perf_counter()
+                r = e.selfplay(n_games=args.games, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
+                               first_game_id=2 * 10**9, symmetries=False, want_boards=False, out=out)
+                torch.cuda.synchronize()
+                dta = time.perf_counter() - t1
+                sa = e.stats()
+                line["mfma_conv2"] = {"games_per_sec": args.games / dta, "episodes": args.games,
+                                      "mfma_fraction_end_to_end": sa["leaf_rows_executed"] / dta * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12),
+                                      "conv2_tflops": sa["net_conv2_flops"] / (sa["net_conv2_ms"] * 1e-3) / 1e12 if sa["net_conv2_ms"] else None,
+                                      "conv2_frac_of_mfma_peak": sa["net_conv2_flops"] / (sa["net_conv2_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if sa["net_conv2_ms"] else None,
+                                      "conv2_avg_launch_ms": sa["net_conv2_ms"] / max(1, sa["net_launches"]),
+                                      "note": "one episode batch of --games episodes (no refill), conv2_table = 0: k_conv_img2<1,true> on the matrix cores"}
+            except Exception as ex:
+                line["mfma_conv2"] = {"error": repr(ex)}
+            finally:
+                e.set_option("conv2_table", args.conv2_table)
             # (b) BASELINE config 3: arena.rs head-to-head, 4096 paired games new-vs-old net, 400 sims/move, two seeded bf16 nets
             try:
                 e.net_init_random(2, seed=args.seed + 1)

@@ -27,7 +27,7 @@ def main():
     # rows the net really ran (leaf de-duplication): every per-leaf figure below is per EXECUTED row
     per_sec = line["leaf_rows"]["executed_per_sec"] if "leaf_rows" in line else line["leaf_evals_per_sec"]
     leaf_evals = per_sec * line["ms_per_step"] * line["steps"] / 1e3
-    conv = [k for k in fetch if "k_conv_img" in k]   # k_conv_img2<1> (default) or k_conv_img<1>
+    conv = [k for k in fetch if "k_heads" in k]      # one k_heads launch per forward, whatever kernels the layers use
     launches = nf[conv[0]] if conv else max(nf.values())
     per_launch_leaves = leaf_evals / launches
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --episodes 16384 "
@@ -45,7 +45,7 @@ def main():
                              "hbm_bytes_per_leaf": b / per_launch_leaves}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     for k, v in out["kernels"].items():
-        if "gemm" in k or "conv" in k:
+        if "gemm" in k or "conv" in k or "backup_select" in k:
             print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch {v['hbm_bytes_per_leaf'] / 1e3:8.1f} KB/leaf")
 
 
