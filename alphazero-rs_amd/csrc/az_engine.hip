@@ -1032,8 +1032,8 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         int rows_typ = 0;                             // expected rows per leaf batch (0 = unknown: assume `active`)
         for (int iter = 0;; ++iter) {
             launch_selfplay_sync_active(th.d, gd, s);
-            // tile choice from the largest batch seen so far in this call (de-duplication makes batches much smaller than
-            // the number of searching trees); the grids still cover `active`
+            // tile choice from the largest batch of the previous move (de-duplication makes batches much smaller than the
+            // number of searching trees); the grids still cover `active`
             run_search(e, th, gd.state, p->num_sims, sp, *net, active, nullptr, rows_typ, gd.counters + 3);
             launch_selfplay_move(th.d, gd, mp, s);
             if (mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
@@ -1042,7 +1042,8 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
             resolve_profile(e);
             ++moves;
             active = (int)h_ctr[2];
-            rows_typ = h_ctr[3] ? (int)std::min<uint64_t>((uint64_t)h_ctr[3] * 5 / 4 + 64, (uint64_t)C) : 0;
+            rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)C) : 0;      // this move's largest batch
+            HIPCHK(hipMemsetAsync(gd.counters + 3, 0, sizeof(uint32_t), s));
             if (h_ctr[1] >= (uint32_t)n_games) break;
             if ((iter & 7) == 7 || h_ctr[2] == 0) {
                 result = check_tree_errors(e, th);
