@@ -115,7 +115,7 @@ struct TreeHost {
         size_t slots = (size_t)G * d.R;
         d.node = mem.alloc<uint4>(slots * 2);
         d.hash = mem.alloc<uint32_t>((size_t)G * H);
-        d.head = mem.alloc<TreeHead>(G);
+        d.head = mem.alloc<TreeLine>(G);
         d.path = mem.alloc<uint32_t>((size_t)G * PATH_CAP);
         d.err = mem.alloc<uint32_t>(ERR_COUNT);
         d.log_cap = log_cap;
@@ -900,10 +900,10 @@ az_status az_tree_get_evals(az_tree* t, int32_t* rec_count, uint64_t* states, fl
         TreeDev& d = t->th.d;
         size_t n = (size_t)d.G * d.log_cap;
         if (rec_count) {
-            std::vector<TreeHead> heads(d.G);
-            HIPCHK(hipMemcpy(heads.data(), d.head, (size_t)d.G * sizeof(TreeHead), hipMemcpyDeviceToHost));
+            std::vector<TreeLine> heads(d.G);
+            HIPCHK(hipMemcpy(heads.data(), d.head, (size_t)d.G * sizeof(TreeLine), hipMemcpyDeviceToHost));
             std::vector<int32_t> cnt(d.G);
-            for (int g = 0; g < d.G; ++g) cnt[g] = (int32_t)heads[g].log_len;
+            for (int g = 0; g < d.G; ++g) cnt[g] = (int32_t)heads[g].head.log_len;
             HIPCHK(hipMemcpy(rec_count, cnt.data(), d.G * sizeof(int32_t), hipMemcpyDefault));
         }
         if (states) HIPCHK(hipMemcpy(states, d.log_state, n * 16, hipMemcpyDefault));
@@ -917,10 +917,10 @@ az_status az_tree_node_counts(az_tree* t, uint32_t* out) {
     if (!t || !out) return AZ_ERR_BAD_ARGUMENT;
     try {
         HIPCHK(hipSetDevice(t->e->device));
-        std::vector<TreeHead> heads(t->th.d.G);
-        HIPCHK(hipMemcpy(heads.data(), t->th.d.head, heads.size() * sizeof(TreeHead), hipMemcpyDeviceToHost));
+        std::vector<TreeLine> heads(t->th.d.G);
+        HIPCHK(hipMemcpy(heads.data(), t->th.d.head, heads.size() * sizeof(TreeLine), hipMemcpyDeviceToHost));
         std::vector<uint32_t> cnt(heads.size());
-        for (size_t g = 0; g < heads.size(); ++g) cnt[g] = heads[g].count;
+        for (size_t g = 0; g < heads.size(); ++g) cnt[g] = heads[g].head.count;
         HIPCHK(hipMemcpy(out, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyDefault));
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(t->e, f); }
@@ -1093,9 +1093,9 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
             e->sp_log_pi.resize((size_t)n_games * cap * 7);
             e->sp_log_v.resize((size_t)n_games * cap);
             {
-                std::vector<TreeHead> heads(n_games);
-                HIPCHK(hipMemcpy(heads.data(), th.d.head, (size_t)n_games * sizeof(TreeHead), hipMemcpyDeviceToHost));
-                for (int g = 0; g < n_games; ++g) e->sp_log_count[g] = (int32_t)heads[g].log_len;
+                std::vector<TreeLine> heads(n_games);
+                HIPCHK(hipMemcpy(heads.data(), th.d.head, (size_t)n_games * sizeof(TreeLine), hipMemcpyDeviceToHost));
+                for (int g = 0; g < n_games; ++g) e->sp_log_count[g] = (int32_t)heads[g].head.log_len;
             }
             HIPCHK(hipMemcpy(e->sp_log_states.data(), th.d.log_state, e->sp_log_states.size() * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(e->sp_log_pi.data(), th.d.log_pi, e->sp_log_pi.size() * 4, hipMemcpyDeviceToHost));

@@ -40,6 +40,15 @@ struct TreeHead {
     uint32_t stat[ST_COUNT];   // counters since the last harvest
 };
 static_assert(sizeof(TreeHead) == 64, "TreeHead is one 64-byte line");
+// What a tree keeps per launch is one 128-byte line: the head and the first 16 entries of node_path (src/async_mcts.rs:229);
+// lane j of the tree's 8 lanes holds entries j and j + 8 in registers, so pushing and walking the path costs no memory round
+// trip (longer paths spill to TreeDev.path).
+constexpr int PATH_INLINE = 16;
+struct TreeLine {
+    TreeHead head;
+    uint32_t path16[PATH_INLINE];
+};
+static_assert(sizeof(TreeLine) == 128, "head + inline path = one 128-byte line");
 
 struct TreeDev {
     int32_t G;               // trees
@@ -49,8 +58,8 @@ struct TreeDev {
     uint32_t reserve_nodes;  // reserve_space (src/node.rs:146): pushes beyond it are the reference's assert (src/node.rs:237)
     uint4* node;             // [G*R*2] 32-byte records as two uint4: {ctr.lo, ctr.hi, key.lo, key.hi} {prior, meta, link, child_base}
     uint32_t* hash;          // [G*H] `seen` (src/node.rs:135): open-addressing table of node slots, key = the node's own key word
-    TreeHead* head;          // [G]
-    uint32_t* path;          // [G*PATH_CAP]
+    TreeLine* head;          // [G]
+    uint32_t* path;          // [G*PATH_CAP] node_path entries beyond PATH_INLINE
     uint32_t* err;           // [ERR_COUNT]
     // eval log (replay parity): raw (pi, v) of every NNet::predict row, per tree, in order
     int32_t log_cap;

@@ -113,6 +113,11 @@ AZ_D bool node_upgrade(const TreeDev& t, TreeHead& h, int g, size_t base, uint32
     return true;
 }
 
+// lane `sub`'s two inline node_path entries (j = sub and sub + 8)
+struct PathRegs { uint32_t lo, hi; };
+AZ_D PathRegs path_load(const TreeDev& t, int g, int sub) { return PathRegs{t.head[g].path16[sub], t.head[g].path16[8 + sub]}; }
+AZ_D void path_store(const TreeDev& t, int g, int sub, const PathRegs& p) { t.head[g].path16[sub] = p.lo; t.head[g].path16[8 + sub] = p.hi; }
+
 AZ_D TreeHead head_load(const TreeDev& t, int g) {
     const uint4* p = (const uint4*)(t.head + g);
     const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -140,7 +145,7 @@ __global__ void k_init_heads(TreeDev t) {
 }
 __global__ void k_set_active(TreeDev t, uint32_t value) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < t.G) t.head[g].active = value;
+    if (g < t.G) t.head[g].head.active = value;
 }
 
 // ---- NodeStore::new (src/node.rs:156-166): clear `seen`, push + upgrade the initial board ----
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, Ev
 
 // ---- search_iteration: select + expand (src/async_mcts.rs:226-299, Appendix A of SURVEY.md) ----
 template <class G>
-AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, const SearchParams& sp, int g, int sub) {
+AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth, const SearchParams& sp, int g, int sub) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
     const bool act = h.active != 0;
@@ -360,7 +365,11 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, const SearchPa
             kind = LEAF_NONE;
             break;
         }
-        if (sub == 0) path[plen] = cur;                         // node_path.push, S3 / :270
+        if (plen < (uint32_t)PATH_INLINE) {                      // node_path.push, S3 / :270: lane plen & 7 keeps it
+            if ((uint32_t)sub == (plen & 7u)) { if (plen < 8u) pth.lo = cur; else pth.hi = cur; }
+        } else if (sub == 0) {
+            path[plen] = cur;
+        }
         ++plen;
         if (clink != NONE) { cur = clink; ++depth; continue; }  // Exists(false): follow the link (S2: one level per iteration)
         if (cmeta & META_EXPANDED) {                             // Exists(true)
@@ -411,29 +420,38 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, const SearchPa
 }
 
 // `seen`-style sharing of evaluations across trees: a tree whose row was really evaluated publishes (pi, v) under its
-// state's key.  Bucket = one 64-byte line of 8 keys; lane j looks at way j, lane 0 claims the first empty way with a CAS
-// (another inserter may have taken it: try the next empty one), then lanes 0..7 write the 32-byte payload.
+// state's key.  Bucket = one 64-byte line of 8 keys.  The claim (a CAS of an empty way, starting at a way picked by the key's
+// hash) is ISSUED as soon as the leaf's key is known and CHECKED at the end of the backup, so its round trip overlaps the
+// prior / counter updates; a way taken by another key costs one more attempt on the next way (at most three).
+struct CacheClaim {
+    unsigned long long key, prev;
+    uint32_t slot;
+    bool open;
+};
 template <class G>
-AZ_D void cache_insert(const EvalCache& ec, typename G::State s, float pv, int sub) {
+AZ_D CacheClaim cache_claim_begin(const EvalCache& ec, typename G::State s, int sub) {
+    CacheClaim c{0ull, 0ull, 0u, false};
+    if (G::stones(s) > ec.max_stones) return c;
+    c.key = (unsigned long long)G::pack(s) | ec.tag;
+    const unsigned long long hsh = mix64(c.key);
+    c.slot = ((uint32_t)(hsh >> 20) & ec.bmask) * 8u + ((uint32_t)(hsh >> 50) & 7u);
+    c.open = true;
+    if (sub == 0) c.prev = atomicCAS(&ec.key[c.slot], 0ull, c.key);
+    return c;
+}
+template <class G>
+AZ_D void cache_claim_finish(const EvalCache& ec, CacheClaim c, float pv, int sub) {
     constexpr int GW = G::GROUP;
     bool inserted = false;
-    if (G::stones(s) <= ec.max_stones) {
-        const unsigned long long key = (unsigned long long)G::pack(s) | ec.tag;
-        const uint32_t bucket = (uint32_t)(mix64(key) >> 20) & ec.bmask;
-        unsigned long long* keys = ec.key + (size_t)bucket * 8;
-        uint32_t empties = gballot<GW>(keys[sub] == 0ull);
-        uint32_t way = NONE;
-        while (empties) {
-            const uint32_t w = (uint32_t)__ffs((int)empties) - 1u;
-            unsigned long long prev = 0ull;
-            if (sub == 0) prev = atomicCAS(&keys[w], 0ull, key);
+    if (c.open) {
+        unsigned long long prev = gshfl64<GW>(c.prev, 0);
+        for (int attempt = 0; prev != 0ull && prev != c.key && attempt < 2; ++attempt) {
+            c.slot = (c.slot & ~7u) | ((c.slot + 1u) & 7u);
+            if (sub == 0) prev = atomicCAS(&ec.key[c.slot], 0ull, c.key);
             prev = gshfl64<GW>(prev, 0);
-            if (prev == 0ull) { way = w; break; }
-            if (prev == key) break;                       // already published
-            empties &= empties - 1u;
         }
-        if (way != NONE) {                                // (bucket full: not cached)
-            ec.pv[((size_t)bucket * 8 + way) * 8 + sub] = pv;
+        if (prev == 0ull) {                               // claimed (prev == key: already published; else: bucket busy, not cached)
+            ec.pv[(size_t)c.slot * 8 + sub] = pv;
             inserted = true;
         }
     }
@@ -445,8 +463,8 @@ AZ_D void cache_insert(const EvalCache& ec, typename G::State s, float pv, int s
 // INLINE_PV: the leaf's (pi, v) row is handed over in a register (pv_in: lane a < ACTIONS holds pi[a], lane ACTIONS holds v)
 // instead of being read through TreeHead.src -- the fused search of the fixture nets.
 template <class G, bool INLINE_PV = false>
-AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g, int sub,
-                      float pv_in = 0.0f) {
+AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g,
+                      int sub, float pv_in = 0.0f) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
     const uint32_t kind = h.leaf_kind;
@@ -454,12 +472,14 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const 
     const size_t base = (size_t)g * t.R;
     const uint32_t leaf = h.leaf;
     float val;
+    float pv = 0.0f;                                // lanes 0..NA-1: pi[sub], lane NA: v
+    CacheClaim claim{0ull, 0ull, 0u, false};
+    bool publish = false;
     if (kind == LEAF_EVAL) {
         uint4* lp = node_ptr(t, base, leaf);
         const NodeRec lr = node_load(lp);
         const typename G::State s = G::unpack(lr.key);
         const uint32_t src = h.src;
-        float pv;                                   // lanes 0..NA-1: pi[sub], lane NA: v
         if constexpr (INLINE_PV) {
             pv = pv_in;
         } else if (src & SRC_CACHE) {
@@ -467,7 +487,8 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const 
         } else {
             const uint32_t row = (src & SRC_TABLE) ? eb.tuniq[src & SRC_INDEX] : src;
             pv = eb.pi[(size_t)row * 8 + sub];
-            if (!(src & SRC_TABLE) && eb.dedup && ec.key) cache_insert<G>(ec, s, pv, sub);
+            publish = !(src & SRC_TABLE) && eb.dedup && ec.key;
+            if (publish) claim = cache_claim_begin<G>(ec, s, sub);
         }
         float p = sub < NA ? pv : 0.0f;
         const float v = gshflf<GW>(pv, NA);
@@ -505,17 +526,24 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const EvalBatch& eb, const 
     } else {
         val = h.leaf_val;
     }
-    if (apply_only) return;
-    // unvisit() leaf -> root along node_path; B2: the sign alternates toward the root.
-    // A Connect Four line never repeats a node, so the lanes update distinct counters.
-    const uint32_t plen = h.path_len;
-    const uint32_t* path = t.path + (size_t)g * PATH_CAP;
-    for (uint32_t i = (uint32_t)sub; i <= plen; i += GW) {
-        uint32_t node = i == 0 ? leaf : path[plen - i];
-        float x = (i & 1u) ? -val : val;
-        uint4* np = node_ptr(t, base, node);
-        node_set_ctr(np, node_ctr(np) - ctr_unvisit_delta(x));      // src/node.rs:83-92
+    if (!apply_only) {
+        // unvisit() leaf -> root along node_path; B2: the sign alternates toward the root.
+        // A Connect Four line never repeats a node, so the lanes update distinct counters.
+        const uint32_t plen = h.path_len;
+        const uint32_t* path = t.path + (size_t)g * PATH_CAP;
+        for (uint32_t r = 0; r <= plen; r += GW) {                      // round r: lane sub takes step i = r + sub (group-uniform trips)
+            const uint32_t i = r + (uint32_t)sub;
+            const uint32_t j = i >= 1u && i <= plen ? plen - i : 0u;    // node_path index of step i >= 1
+            const uint32_t lo = gshfl<GW>(pth.lo, (int)(j & 7u)), hi = gshfl<GW>(pth.hi, (int)(j & 7u));
+            if (i <= plen) {
+                uint32_t node = i == 0 ? leaf : (j < 8u ? lo : (j < (uint32_t)PATH_INLINE ? hi : path[j]));
+                float x = (i & 1u) ? -val : val;
+                uint4* np = node_ptr(t, base, node);
+                node_set_ctr(np, node_ctr(np) - ctr_unvisit_delta(x));  // src/node.rs:83-92
+            }
+        }
     }
+    if constexpr (!INLINE_PV) { if (publish) cache_claim_finish<G>(ec, claim, pv, sub); }
 }
 
 // ---- get_action_prob epilogue (src/async_mcts.rs:84-114): counts -> pi ----------------------
@@ -575,7 +603,8 @@ __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCach
     if (tid == 0) { if (eb.max_n && *eb.n > *eb.max_n) *eb.max_n = *eb.n; *eb.n = 0; }   // the batch has been consumed (nothing in this kernel reads the count)
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
-    backup_body<G>(t, h, eb, ec, apply_only, g, sub);
+    const PathRegs pth = path_load(t, g, sub);
+    backup_body<G>(t, h, pth, eb, ec, apply_only, g, sub);
     h.leaf_kind = LEAF_NONE;
     if (sub == 0) head_store(t, g, h);
 }
@@ -592,15 +621,17 @@ __global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_pr
     if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
-    backup_body<G>(t, h, eb_prev, ec, apply_only, g, sub);
+    PathRegs pth = path_load(t, g, sub);
+    backup_body<G>(t, h, pth, eb_prev, ec, apply_only, g, sub);
     // the counters this tree's other lanes just wrote are read by the selection below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const typename G::State leaf_s = select_body<G>(t, h, sp, g, sub);
+    const typename G::State leaf_s = select_body<G>(t, h, pth, sp, g, sub);
     const uint32_t src = leaf_request<G>(eb_next, ec, h.leaf_kind == LEAF_EVAL, leaf_s, sub);
     if (h.leaf_kind == LEAF_EVAL) h.src = src;
     if (sub == 0) head_store(t, g, h);
+    path_store(t, g, sub, pth);
 }
 
 // ---- the whole get_action_prob search in ONE launch, for nets that are a pure function of the state on the device ----
@@ -638,15 +669,16 @@ __global__ __launch_bounds__(64) void k_search_fixture(TreeDev t, const ulonglon
     const EvalBatch no_eb{};
     const EvalCache no_ec{};
     TreeHead h = head_load(t, g);
+    PathRegs pth{0u, 0u};
     typename G::State ls = root_prepare_body<G>(t, h, root_states, g, sub);
     for (int i = 0; i <= num_sims; ++i) {
         group_memory_sync();
         // backup of the previous leaf (i == 0: the root's priors only, S1), then the next selection
         const float pv = h.leaf_kind == LEAF_EVAL ? fixture_row<G>(ls, kind, salt, sub) : 0.0f;
-        backup_body<G, true>(t, h, no_eb, no_ec, i == 0 ? 1 : 0, g, sub, pv);
+        backup_body<G, true>(t, h, pth, no_eb, no_ec, i == 0 ? 1 : 0, g, sub, pv);
         if (i == num_sims) break;
         group_memory_sync();
-        ls = select_body<G>(t, h, sp, g, sub);
+        ls = select_body<G>(t, h, pth, sp, g, sub);
     }
     h.leaf_kind = LEAF_NONE;
     if (sub == 0) head_store(t, g, h);
@@ -677,7 +709,7 @@ __global__ __launch_bounds__(256) void k_harvest(TreeDev t, unsigned long long* 
     const int lane = threadIdx.x & 63;
     uint32_t st[ST_COUNT] = {0, 0, 0, 0, 0, 0};
     if (g < t.G) {
-        TreeHead* hp = t.head + g;
+        TreeHead* hp = &t.head[g].head;
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) { st[k] = hp->stat[k]; hp->stat[k] = 0; }
         if (node_counts) node_counts[g] = hp->count;
@@ -759,7 +791,7 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
                 gd.ply[g] = 0;
                 gd.need_reset[g] = 1;
             } else {
-                t.head[g].active = 0;
+                t.head[g].head.active = 0;
                 atomicSub(&gd.counters[2], 1u);
             }
         } else {
@@ -805,8 +837,8 @@ __global__ void k_arena_sync(TreeDev tn, TreeDev to, ArenaDev ad) {
     const bool alive = ad.alive[g] != 0;
     const int first_model = ad.first + g < ad.half ? 0 : 1;            // 0 = new, 1 = old (global game index)
     const int mover = ad.player[g] == 1 ? first_model : 1 - first_model;
-    tn.head[g].active = (alive && mover == 0) ? 1u : 0u;
-    to.head[g].active = (alive && mover == 1) ? 1u : 0u;
+    tn.head[g].head.active = (alive && mover == 0) ? 1u : 0u;
+    to.head[g].head.active = (alive && mover == 1) ? 1u : 0u;
 }
 
 // The searching tree's owner plays argmax(get_action_prob(s, temp = 0)) (src/coach.rs:356-372).
@@ -848,7 +880,7 @@ __global__ __launch_bounds__(64) void k_arena_move(TreeDev t, ArenaDev ad, uint6
 
 __global__ void k_sync_active(TreeDev t, GamesDev gd) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < t.G) t.head[g].active = gd.gid[g] >= 0 ? 1u : 0u;
+    if (g < t.G) t.head[g].head.active = gd.gid[g] >= 0 ? 1u : 0u;
 }
 
 // ---- launchers: one instantiation of every kernel per Game policy, chosen by TreeDev.game ------------------------------
