@@ -197,7 +197,7 @@ struct az_engine {
     uint64_t profile_tick = 0;
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
-    int eval_cache_log2 = 26;       // entries = 2^log2 (40 B each: 2.7 GB); 0 = no cache, in-batch de-duplication only
+    int eval_cache_log2 = 27;       // entries = 2^log2 (40 B each: 5.4 GB); 0 = no cache, in-batch de-duplication only
     int eval_cache_max_stones = 42;
     int eval_cache_persist = 0;     // 0: az_selfplay / az_arena / az_tree_get_action_prob start from an empty cache
     DeviceMem cache_mem;

@@ -5,8 +5,8 @@ Metric (BASELINE.json): self-play games/sec (+ MCTS node-expansions/sec) on conn
 8192 concurrent games per GPU, bf16 policy+value net (C=512), random-init weights, synthetic = self-generated
 positions from the empty board.
 
-A "step" = one episode batch through the hot path: `--episodes` (default 4 x --games) self-play games per GPU played to completion on
-`--games` concurrent slots (finished slots are refilled), then the RCCL gather of the (s, pi, z) tuples to rank 0
+A "step" = one episode batch through the hot path: `--episodes` (default 8 x --games) self-play games per GPU played to completion on
+`--games` concurrent slots (finished slots are refilled; the last `--games` episodes of a step drain on shrinking batches, which is part of the measurement), then the RCCL gather of the (s, pi, z) tuples to rank 0
 when N > 1.  Weak scaling: per-GPU work is fixed; `value` = all ranks' games / max-over-ranks time.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel (conv2's implicit-GEMM MFMA kernel, timed
@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=8192, help="concurrent game slots per GPU")
-    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU per step (0 = 4 x --games)")
+    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU per step (0 = 8 x --games)")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--net", default="conv", choices=["conv", "stub"])
     ap.add_argument("--channels", type=int, default=512)
@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--dry-dist", default="", choices=["", "gloo"],
                     help="rehearse the N-rank launcher + gather on CPU over gloo with synthetic tuples (no engine, no GPU; value = 0)")
     args = ap.parse_args()
-    episodes = args.episodes or 4 * args.games
+    episodes = args.episodes or 8 * args.games
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python3 bench.py --gpus N`: this parent never touches the GPU (no torch import, no engine); it starts the

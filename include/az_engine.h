@@ -127,7 +127,7 @@ const char* az_last_error(const az_engine* e);
  * per-model conv1 table (3^9 neighbourhood patterns x C channels) instead of running conv1 as a kernel, 0 = conv1 kernel; bit-identical.
  * Leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
  * src/node.rs:282-289): "eval_dedup" = 0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is
- * evaluated once; "eval_cache_log2" = log2 entries of the engine's evaluation cache shared by all trees (default 26, 0 = none,
+ * evaluated once; "eval_cache_log2" = log2 entries of the engine's evaluation cache shared by all trees (default 27, 0 = none,
  * 40 bytes per entry); "eval_cache_max_stones" = only states with at most that many stones are cached (default 42);
  * "eval_cache_persist" = 0 (default): every az_selfplay / az_arena / az_tree_get_action_prob call starts from an empty cache,
  * 1: entries live until the model's weights change.  Unknown keys or values return AZ_ERR_BAD_ARGUMENT. */
