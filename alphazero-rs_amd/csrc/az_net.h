@@ -66,6 +66,7 @@ void convnet_set_conv4_big(int v);
 void convnet_set_conv1_table(int v);
 void convnet_set_conv2_table(int v);
 void convnet_set_fc_ring(int v);
+void convnet_set_conv3_ring(int v);
 void convnet_set_ring_max_tiles(int v);
 // diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop
 bool netws_read_clock_stamps(NetWorkspace* ws, unsigned long long* out2048);

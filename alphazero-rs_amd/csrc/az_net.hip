@@ -1468,6 +1468,8 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants
                           // git history): 4-stage ring, XCD column remap, third weight buffer, late / spread DMA issue, mid
                           // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
                           // split, cross-step fragment prefetch, weights straight into registers.
+int g_conv3_ring = 0;
+void convnet_set_conv3_ring(int v) { g_conv3_ring = v; }
 int g_fc_ring = 1;        // 128x128 LDS-DMA ring kernel for under-filled grids (az_set_option "fc_ring"); bit-identical
 int g_ring_max_tiles = 256;   // ... when the layer has at most this many tiles ("ring_max_tiles")
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
@@ -1487,6 +1489,13 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     }
     const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_typ >= 4096)))) &&
                      d.N % HBN_ == 0;
+    if constexpr (LAYER == 2) if (v == 5 && g_conv3_ring) {      // experiment: conv3 on the 128x128 LDS-DMA ring (im2col from act2)
+        const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
+        const int mt8 = (mt + 7) / 8 * 8;
+        if (g_conv3_ring == 2) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
+        return;
+    }
     if constexpr (LAYER == 2) if (v == 5 && d.N % 128 == 0 && d.cin % 64 == 0 && d.rows_per_sample == 20) {   // conv3 image-resident
         const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
         const int t8 = (tiles + 7) / 8 * 8;
