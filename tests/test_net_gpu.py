@@ -95,12 +95,21 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
             conv_engine.set_option("conv4_big", big)
             pi, v = conv_engine.predict_states(states, 5)
             assert np.array_equal(pi, outs[0][0]) and np.array_equal(v, outs[0][1])
+        conv_engine.set_option("conv4_big", 2)
+        for key, vals in (("fc_ring", (0, 2, 1)), ("conv3_ring", (1, 2, 0)), ("conv1_table", (0, 1))):   # the LDS-DMA ring GEMM on fc1 /
+            for val in vals:                                                                            # fc2 / conv4 / conv3, conv1 as a kernel
+                conv_engine.set_option(key, val)
+                pi, v = conv_engine.predict_states(states, 5)
+                assert np.array_equal(pi, outs[0][0]) and np.array_equal(v, outs[0][1]), (key, val)
         with pytest.raises(Exception):
             conv_engine.set_option("gemm_variant", 4)         # removed variants are refused, not silently mapped
     finally:
         conv_engine.set_option("gemm_variant", 5)
         conv_engine.set_option("conv4_big", 2)
         conv_engine.set_option("conv2_table", 1)
+        conv_engine.set_option("fc_ring", 1)
+        conv_engine.set_option("conv3_ring", 0)
+        conv_engine.set_option("conv1_table", 1)
 
 
 def test_net_parity_at_bench_scale(engine, oracle):
