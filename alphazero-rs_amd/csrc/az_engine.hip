@@ -195,6 +195,7 @@ struct az_engine {
     // "eval_cache_persist")
     int profile_every = 1;          // profile mode: bracket every n-th simulation step ("profile_every")
     uint64_t profile_tick = 0;
+    int dedup_epoch_max = 0x7FFF;   // election-table epochs before the tables are cleared (15 bits; tests lower it: "dedup_epoch_max")
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
     int eval_cache_log2 = 27;       // entries = 2^log2 (40 B each: 5.4 GB); 0 = no cache, in-batch de-duplication only
@@ -360,7 +361,7 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
     // every launch that requests leaves gets its own election-table epoch (15 bits; stale keys could look current again
     // after a wrap, so the tables are cleared then)
     auto next_epoch = [&]() -> uint32_t {
-        if (++th.dd_epoch > 0x7FFFu) {
+        if (++th.dd_epoch > (uint32_t)e->dedup_epoch_max) {
             HIPCHK(hipMemsetAsync(th.eb.tkey, 0, ((size_t)th.eb.tmask + 1) * 8, s));
             HIPCHK(hipMemsetAsync(th.eb2.tkey, 0, ((size_t)th.eb2.tmask + 1) * 8, s));
             th.dd_epoch = 1;
@@ -517,6 +518,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         return AZ_OK;
     }
     if (std::strcmp(key, "profile_every") == 0 && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "dedup_epoch_max") == 0 && value >= 3 && value <= 0x7FFF) { e->dedup_epoch_max = (int)value; return AZ_OK; }
     if (std::strcmp(key, "fused_search") == 0 && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_dedup") == 0 && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_log2") == 0 && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
