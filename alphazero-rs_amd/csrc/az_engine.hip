@@ -524,7 +524,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "eval_cache_log2") == 0 && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_max_stones") == 0 && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_persist") == 0 && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "fc_ring") == 0 && value >= 0 && value <= 2) { convnet_set_fc_ring((int)value); return AZ_OK; }
+    if (std::strcmp(key, "fc_ring") == 0 && value >= 0 && value <= 3) { convnet_set_fc_ring((int)value); return AZ_OK; }
     if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv3_ring") == 0 && value >= 0 && value <= 2) { convnet_set_conv3_ring((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv2_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv2_table((int)value); return AZ_OK; }

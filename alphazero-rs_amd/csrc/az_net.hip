@@ -382,27 +382,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
 // same per-row K order (bit-identical), but the operands go global -> LDS with global_load_lds into a ring of NS stages
 // (32 KiB each, 128 KiB at NS = 4: the LDS an under-filled CU has to spare), NS-1 stages in flight, retired with a COUNTED
 // s_waitcnt (never 0 inside the loop) and one raw barrier per step.
-template <int LAYER, int NS>
+// BM = 128 or 64 rows per tile: the 64-row tile doubles the workgroups of a layer whose 128-row grid leaves CUs idle (fc1 / fc2 at
+// de-duplicated batch sizes: a CU fetches L2 -> LDS at ~19 B/clk whatever else it does, so idle CUs are idle fetch bandwidth).
+template <int LAYER, int NS, int BM = 128>
 __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * 32768];      // [stage][A 128 x 128 B | W 128 x 128 B]
+    constexpr int MT = BM / 32;                       // 16-row tiles per wave (2 x 2 waves) = A pieces per wave
+    constexpr int STAGE = BM * 128 + 16384;           // [A BM x 128 B | W 128 x 128 B]
+    constexpr int NDMA = MT + 4;                      // DMA instructions per wave per stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
     const int ntaps = d.K / d.cin;
     const int NT = d.N / GBN;
     const int id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
     const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int m0 = mtile * GBM, n0 = ntile * GBN;
+    const int m0 = mtile * BM, n0 = ntile * GBN;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    // DMA map: piece q (0..3) of wave w fills tile rows (q*4 + w)*8 .. +7 of both operands; lane -> row lane>>3, slot lane&7
+    // DMA map: piece q of wave w fills tile rows (q*4 + w)*8 .. +7 (A: q < MT, W: q < 4); lane -> row lane>>3, slot lane&7
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ lrow;
     uint32_t a_ob[4], b_ob[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        int m = m0 + (q * 4 + wave) * 8 + lrow;
+        int m = m0 + ((q < MT ? q : 0) * 4 + wave) * 8 + lrow;
         m = m < M ? m : M - 1;
         const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
         const int y = r / d.out_w, x = r - y * d.out_w;
@@ -418,9 +423,9 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
     {                                                                                                   \
         const char* abase = (const char*)(d.A + ks_toff);                                               \
         const char* wbase = (const char*)(d.W + ks_kk);                                                 \
-        unsigned char* la = smem + (buf_) * 32768 + wave * 1024;                                        \
-        unsigned char* lb = la + 16384;                                                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                \
+        unsigned char* la = smem + (buf_) * STAGE + wave * 1024;                                        \
+        unsigned char* lb = la + BM * 128;                                                              \
+        _Pragma("unroll") for (int q_ = 0; q_ < MT; ++q_)                                               \
             __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                \
             __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob[q_]), (lds_ptr)(lb + q_ * 4096), 16, 0, 0); \
@@ -428,9 +433,9 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
         if (ks_kx == d.tap_w) { ks_kx = 0; ks_toff += (uint32_t)((d.in_w - d.tap_w) * d.in_c); }        \
         if (ks_tap == ntaps) { ks_tap = 0; ks_kx = 0; ks_c0 += GBK; ks_toff = ks_c0; ks_kk = ks_c0; }   \
     }
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = d.K / GBK;
@@ -439,26 +444,26 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
     for (int st = 0; st < NS - 1; ++st)
         if (st < nk) AZ_RDMA(st);
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt must have landed; up to NS-2 younger stages (8 DMA instructions each) may stay in flight
+        // stage kt must have landed; up to NS-2 younger stages (NDMA instructions each) may stay in flight
         const int younger = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (younger >= 2) { if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        else if (younger == 1) { if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // raw: every wave is also done with stage kt-1's buffer
         __builtin_amdgcn_sched_barrier(0);
         if (kt + NS - 1 < nk) AZ_RDMA((kt + NS - 1) % NS);
-        const unsigned char* sA = smem + (kt % NS) * 32768;
-        const unsigned char* sB = sA + 16384;
+        const unsigned char* sA = smem + (kt % NS) * STAGE;
+        const unsigned char* sB = sA + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = ((ks * 4 + fq) ^ fsw) << 4;
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[MT], fb[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * 64 + mt * 16 + frow) * 128 + coff);
+            for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * (BM / 2) + mt * 16 + frow) * 128 + coff);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
@@ -470,8 +475,8 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
         const int n = n0 + wc * 64 + nt * 16 + fq * 4;
         const float4 bv = *(const float4*)(d.bias + n);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wr * 64 + mt * 16 + frow;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wr * (BM / 2) + mt * 16 + frow;
             if (m >= M) continue;
             float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
                   r3 = acc[mt][nt][3] + bv.w;
@@ -1471,6 +1476,7 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants
 int g_conv3_ring = 0;
 void convnet_set_conv3_ring(int v) { g_conv3_ring = v; }
 int g_fc_ring = 1;        // 128x128 LDS-DMA ring kernel for under-filled grids (az_set_option "fc_ring"); bit-identical
+int g_ring64_max_tiles = 512;   // ... 64-row tiles for the FCs when twice the 128-row tile count is at most this ("fc_ring" = 3: never)
 int g_ring_max_tiles = 256;   // ... when the layer has at most this many tiles ("ring_max_tiles")
 int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
 
@@ -1525,8 +1531,15 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     // latency / fetch bound: 4 stages (128 KiB) in flight; otherwise 2 stages (64 KiB) so that two workgroups share a CU.
     if (v == 5 && g_fc_ring) {
         const int mt_typ = (rows_typ * d.rows_per_sample + GBM - 1) / GBM;
-        if (mt_typ * (d.N / GBN) <= g_ring_max_tiles && (LAYER >= 4 || g_fc_ring == 2)) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(grid), dim3(256), 0, s, d);
-        else hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);
+        if (LAYER >= 4 && g_fc_ring != 3 && 2 * mt_typ * (d.N / GBN) <= g_ring64_max_tiles) {
+            // the FCs at de-duplicated batch sizes: 64-row tiles put a workgroup on every CU (each CU's L2 -> LDS rate is the limit)
+            const int mt64 = ((rows_hint * d.rows_per_sample + 63) / 64 + 7) / 8 * 8;
+            hipLaunchKernelGGL((k_gemm_ring<LAYER, 4, 64>), dim3(mt64 * (d.N / GBN)), dim3(256), 0, s, d);
+        } else if (mt_typ * (d.N / GBN) <= g_ring_max_tiles && (LAYER >= 4 || g_fc_ring == 2)) {
+            hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(grid), dim3(256), 0, s, d);
+        } else {
+            hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);
+        }
         return;
     }
     hipLaunchKernelGGL(k_gemm_mfma<LAYER>, dim3(grid), dim3(256), 0, s, d);
