@@ -358,7 +358,7 @@ def main():
                         **common}
         elif not args.no_profile and st["tree_ms"] > 0:
             ach = tree_gbps(st)
-            roof = {"bound": "hbm", "kernel": "k_select + k_backup (tree traversal)", "achieved": ach,
+            roof = {"bound": "hbm", "kernel": "k_search_fixture (tree traversal: the whole search of a move in one launch; stub net evaluated in registers)", "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
         line["roofline"] = roof
         if not args.no_profile and st["tree_ms"] > 0:
