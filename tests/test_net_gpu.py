@@ -294,3 +294,36 @@ def test_model_slots_do_not_leak(engine_mod):
         assert np.isfinite(pi).all()
     finally:
         e.close()
+
+
+def test_bench_scale_replay_parity_with_the_conv_net(engine, oracle):
+    """The bench configuration itself -- 8192 concurrent games, 100 sims/move, the bf16 C=512 net with conv1 / conv2 as table
+    lookups, leaf de-duplication and the evaluation cache on -- held to the oracle: every game's NNet::predict rows are
+    recorded, 24 game ids picked at random are re-played on the oracle from their own records (replay parity: the oracle asks
+    for the same states in the same order and gets the engine's rows back), and must match move for move, pi for pi, z for z.
+    Game g depends only on (seed, g): what its 8191 neighbours do -- sharing its leaf rows through the election table and the
+    cache -- must not show."""
+    engine.net_init_random(21, seed=5)
+    n, sims, seed = 8192, 100, 33
+    cap = 42 * (sims + 1) + 8
+    engine.reset_stats()
+    got = engine.selfplay(n_games=n, num_sims=sims, model_id=21, seed=seed, want_boards=False, record_evals=cap)
+    st = engine.stats()
+    assert st["leaf_rows_executed"] < 0.8 * st["leaf_rows_requested"]            # the sharing really happened
+    cnt, states, pis, vs = engine.selfplay_get_evals(n, cap)
+    assert cnt.max() <= cap and cnt.min() > 0
+    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
+    for g in np.random.default_rng(1).choice(n, size=24, replace=False):
+        c = int(cnt[g])
+        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_REPLAY, seed=seed, first_game_id=int(g),
+                              replay=(np.array([0, c], np.int64), np.ascontiguousarray(states[g, :c]), np.ascontiguousarray(pis[g, :c]),
+                                      np.ascontiguousarray(vs[g, :c])))
+        assert not ref["replay_bad"].any(), g
+        L = int(ref["game_len"][0])
+        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
+        lo, hi = offs[g], offs[g + 1]
+        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+    # and the recorded rows are what NNet::predict returns for those states
+    g = 17
+    pi2, v2 = engine.predict_states(states[g, :256], 21)
+    assert np.array_equal(pi2, pis[g, :256]) and np.array_equal(v2, vs[g, :256])
