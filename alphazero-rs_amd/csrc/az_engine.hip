@@ -517,6 +517,23 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = buf;       // returned through az_last_error
         return AZ_OK;
     }
+    if (std::strcmp(key, "print_seg_stamps") == 0) {
+        // diagnostic (conv3_pipe 3): per-segment cycle sums of wave 0 of the first 128 workgroups of the last conv3 launch, median over blocks
+        std::vector<unsigned long long> st(2048);
+        if (!e->ws[0] || !netws_read_clock_stamps(e->ws[0], st.data())) return fail(e, AZ_ERR_BAD_ARGUMENT, "no workspace");
+        std::string out;
+        for (int i = 0; i < 10; ++i) {
+            std::vector<unsigned long long> v;
+            for (int b = 0; b < 128; ++b) if (st[16 * b + 8]) v.push_back(st[16 * b + i]);
+            if (v.empty()) return fail(e, AZ_ERR_BAD_ARGUMENT, "no stamps (run a forward with conv3_pipe 3 first)");
+            std::sort(v.begin(), v.end());
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "%s%llu", i ? " " : "", v[v.size() / 2]);
+            out += buf;
+        }
+        e->err = out;
+        return AZ_OK;
+    }
     if (std::strcmp(key, "profile_every") == 0 && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
     if (std::strcmp(key, "dedup_epoch_max") == 0 && value >= 3 && value <= 0x7FFF) { e->dedup_epoch_max = (int)value; return AZ_OK; }
     if (std::strcmp(key, "fused_search") == 0 && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
@@ -525,8 +542,10 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "eval_cache_max_stones") == 0 && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
     if (std::strcmp(key, "eval_cache_persist") == 0 && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
     if (std::strcmp(key, "fc_ring") == 0 && value >= 0 && value <= 3) { convnet_set_fc_ring((int)value); return AZ_OK; }
+    if (std::strcmp(key, "ring_tile") == 0 && value >= 0 && value < 60000) { convnet_set_ring_tile((int)(value / 10000), (int)(value % 10000)); return AZ_OK; }
     if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv3_ring") == 0 && value >= 0 && value <= 2) { convnet_set_conv3_ring((int)value); return AZ_OK; }
+    if (std::strcmp(key, "conv3_pipe") == 0 && ((value >= 0 && value <= 3) || (value >= 11 && value <= 15))) { convnet_set_conv3_pipe((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv2_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv2_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv1_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv1_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {

@@ -67,7 +67,9 @@ void convnet_set_conv1_table(int v);
 void convnet_set_conv2_table(int v);
 void convnet_set_fc_ring(int v);
 void convnet_set_conv3_ring(int v);
+void convnet_set_conv3_pipe(int v);
 void convnet_set_ring_max_tiles(int v);
+void convnet_set_ring_tile(int layer, int tile);
 // diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop
 bool netws_read_clock_stamps(NetWorkspace* ws, unsigned long long* out2048);
 // forward for rows [0, *eb.n) of model n in workspace ws; n_rows_hint = host-side upper bound used to size the grids.

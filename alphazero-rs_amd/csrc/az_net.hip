@@ -375,6 +375,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
     }
 }
 
+// ---- LDS-DMA issued from inline asm ---------------------------------------------------------------------------------------
+// hipcc models `__builtin_amdgcn_global_load_lds` as a FLAT access that may touch LDS and global memory at once: while one is
+// pending, EVERY s_waitcnt the compiler inserts is vmcnt(0) / lgkmcnt(0), so each MFMA cluster waits for fragment reads issued
+// just before it for the NEXT cluster.  Issued from inline asm (saddr form: uniform base in SGPRs + a 32-bit lane offset, LDS
+// base in M0) the compiler does not see the DMA: its own lgkmcnt waits are counted, and the kernels below wait for the DMA
+// themselves (explicit vmcnt + barrier before the first read of a landed tile).
+__device__ __forceinline__ void lds_dma16(const void* sbase /*uniform*/, uint32_t voff, uint32_t lds_addr /*uniform*/) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
 // ---- 128x128 tile, LDS-DMA RING: the small-grid layers (fc1, fc2; conv4 on small batches) ---------------------------
 // fc1 (M = leaves, N = 1024, K = 3072) has 176 tiles at 2700 leaves and fc2 88: fewer workgroups than CUs, so k_gemm_mfma
 // runs one 4-wave workgroup per CU and every K-step exposes a full L2 / HBM round trip between its global loads and the
@@ -386,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const GemmDesc d) {
 // de-duplicated batch sizes: a CU fetches L2 -> LDS at ~19 B/clk whatever else it does, so idle CUs are idle fetch bandwidth).
 template <int LAYER, int NS, int BM = 128>
 __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const GemmDesc d) {
+    static_assert(BM % 32 == 0 && BM >= 64 && BM <= 192 && NS * (BM * 128 + 16384) <= 163840 && 2 * (BM / 32 + 4) <= 63, "tile");
     constexpr int MT = BM / 32;                       // 16-row tiles per wave (2 x 2 waves) = A pieces per wave
     constexpr int STAGE = BM * 128 + 16384;           // [A BM x 128 B | W 128 x 128 B]
     constexpr int NDMA = MT + 4;                      // DMA instructions per wave per stage
@@ -404,18 +415,19 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
     // DMA map: piece q of wave w fills tile rows (q*4 + w)*8 .. +7 (A: q < MT, W: q < 4); lane -> row lane>>3, slot lane&7
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ lrow;
-    uint32_t a_ob[4], b_ob[4];
+    uint32_t a_ob[MT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int m = m0 + ((q < MT ? q : 0) * 4 + wave) * 8 + lrow;
+    for (int q = 0; q < MT; ++q) {
+        int m = m0 + (q * 4 + wave) * 8 + lrow;
         m = m < M ? m : M - 1;
         const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
         const int y = r / d.out_w, x = r - y * d.out_w;
         a_ob[q] = (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8) * 2u;
-        b_ob[q] = (uint32_t)((n0 + (q * 4 + wave) * 8 + lrow) * d.K + chunk * 8) * 2u;
     }
+    const uint32_t b_ob = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;      // W piece q: + q * w_stride on the SGPR base
+    const size_t w_stride = (size_t)64 * d.K;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
     // K-step walker (channel block outer, tap inner), scalars only
     int ks_tap = 0, ks_kx = 0;
     uint32_t ks_c0 = 0, ks_toff = 0, ks_kk = 0;
@@ -423,12 +435,9 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
     {                                                                                                   \
         const char* abase = (const char*)(d.A + ks_toff);                                               \
         const char* wbase = (const char*)(d.W + ks_kk);                                                 \
-        unsigned char* la = smem + (buf_) * STAGE + wave * 1024;                                        \
-        unsigned char* lb = la + BM * 128;                                                              \
-        _Pragma("unroll") for (int q_ = 0; q_ < MT; ++q_)                                               \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob[q_]), (lds_ptr)(lb + q_ * 4096), 16, 0, 0); \
+        const uint32_t la = lds0 + (buf_) * STAGE;                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < MT; ++q_) lds_dma16(abase, a_ob[q_], la + q_ * 4096);   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) lds_dma16(wbase + q_ * w_stride, b_ob, la + BM * 128 + q_ * 4096); \
         ++ks_tap; ++ks_kx; ks_toff += (uint32_t)d.in_c; ks_kk += (uint32_t)d.cin;                       \
         if (ks_kx == d.tap_w) { ks_kx = 0; ks_toff += (uint32_t)((d.in_w - d.tap_w) * d.in_c); }        \
         if (ks_tap == ntaps) { ks_tap = 0; ks_kx = 0; ks_c0 += GBK; ks_toff = ks_c0; ks_kk = ks_c0; }   \
@@ -446,28 +455,43 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt must have landed; up to NS-2 younger stages (NDMA instructions each) may stay in flight
         const int younger = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
-        if (younger >= 2) { if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-        else if (younger == 1) { if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // raw: every wave is also done with stage kt-1's buffer
         __builtin_amdgcn_sched_barrier(0);
         if (kt + NS - 1 < nk) AZ_RDMA((kt + NS - 1) % NS);
         const unsigned char* sA = smem + (kt % NS) * STAGE;
         const unsigned char* sB = sA + BM * 128;
+        // both 32-deep halves' fragments are requested up front: the second half's reads sit between the first half's MFMAs
+        const int coff0 = ((0 + fq) ^ fsw) << 4, coff1 = ((4 + fq) ^ fsw) << 4;
+        bf16x8 fa0[MT], fb0[4], fa1[MT], fb1[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fq) ^ fsw) << 4;
-            bf16x8 fa[MT], fb[4];
+        for (int mt = 0; mt < MT; ++mt) fa0[mt] = *(const bf16x8*)(sA + (wr * (BM / 2) + mt * 16 + frow) * 128 + coff0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * (BM / 2) + mt * 16 + frow) * 128 + coff);
+        for (int nt = 0; nt < 4; ++nt) fb0[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
+        for (int mt = 0; mt < MT; ++mt) fa1[mt] = *(const bf16x8*)(sA + (wr * (BM / 2) + mt * 16 + frow) * 128 + coff1);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int nt = 0; nt < 4; ++nt) fb1[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff1);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nt], fa0[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt], fa1[mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + 4, 0);
+#pragma unroll
+        for (int g = 0; g < MT + 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MT - (MT + 4), 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #undef AZ_RDMA
 #pragma unroll
@@ -1187,6 +1211,205 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_img2(const GemmDesc d) {
 }
 constexpr int C3_NB = 12;     // (conv4 as <L, 19, 4, 5, 4> is bit-identical too and was measured neutral: it stays on k_gemm256)
 
+// ---- the same tile with the LDS-DMA issued from inline asm and a software-pipelined K-step ---------------------------
+// hipcc models `__builtin_amdgcn_global_load_lds` as a FLAT access that may touch LDS and global memory at once: while one
+// is pending EVERY s_waitcnt it inserts is vmcnt(0) / lgkmcnt(0), so in k_conv_valid_img2 each MFMA cluster waits for the
+// fragment reads issued just before it (meant for the NEXT cluster) -- three exposed LDS latencies per K-step.  Issued
+// from inline asm (saddr form: uniform base in SGPRs + one loop-invariant 32-bit offset VGPR per piece, LDS base in M0)
+// the compiler does not see the DMA, its own lgkmcnt waits become counted, and the waits for the DMA are the explicit
+// vmcnt(0) + barrier pairs below.  K-step schedule (fbX / faX of step k were requested under step k-1's last cluster):
+//   reads fbY, faY(ks0) | MFMA fbX x faX(ks0) | lgkmcnt(0), barrier: W(k) is in registers everywhere | DMA W(k+1)
+//   reads faX(ks1) | MFMA fbX x faY(ks0) | reads faY(ks1) | MFMA fbY x faX(ks1) | vmcnt(0), barrier: W(k+1) landed
+//   reads fbX, faX(ks0) of step k+1 | MFMA fbY x faY(ks1)
+// Same K order per accumulator as k_conv_valid_img2 (and every other conv3 kernel): bit-identical.
+
+template <int LAYER, int NB, int IH, int IW, bool STAMP = false, int ABLATE = 0, bool IL = false>   // IL: fragment reads interleaved into the MFMA clusters (sched_group_barrier); STAMP: diagnostic build, per-segment s_memtime sums of wave 0 into d.dbg; ABLATE (timing only, WRONG results): 1 no image switch, 2 + no wait for the weight DMA
+__global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
+    constexpr int OH = IH - 2, OW = IW - 2, OUT_PER = OH * OW, IN_PER = IH * IW;
+    constexpr int OUT_ROWS = NB * OUT_PER, IMG_R = NB * IN_PER;
+    constexpr int NCOL = 128;
+    constexpr int IMG_BYTES = (IMG_R * 128 + 1023) / 1024 * 1024;
+    constexpr int IPIECES = (IMG_R + 31) / 32, WPIECES = NCOL / 32;       // 1 KiB DMA pieces per wave
+    static_assert(IMG_BYTES + NCOL * 128 <= 81920, "two workgroups must fit a CU's 160 KiB");
+    static_assert(IMG_R % 8 == 0 && NB <= 16, "whole 8-row DMA sub-pieces; NetWorkspace keeps 16 boards of slack");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IMG_BYTES + NCOL * 128];   // img | w
+    const int n_boards = (int)(*d.n_dev);
+    const int M = n_boards * OUT_PER;
+    const int C = d.cin;
+    const int NT = d.N / NCOL;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * NB, n0 = ntile * NCOL;
+    if (b0 >= n_boards) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // DMA addresses: one loop-invariant 32-bit lane offset per operand; piece q adds a uniform stride to the SGPR base.  Image rows
+    // past the batch's last board are read unclamped (the workspace keeps 16 boards of slack; their output rows are never stored).
+    const uint32_t i_ob = (uint32_t)((b0 * IN_PER + wave * 8 + lrow) * C + chunk * 8) * 2u;
+    const uint32_t w_ob = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
+    const uint32_t lds_img = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
+    const uint32_t lds_w = (uint32_t)(uintptr_t)(lds_ptr)(smem + IMG_BYTES + wave * 1024);
+    const size_t i_stride = (size_t)64 * C, w_stride = (size_t)64 * d.K;          // 32 rows, in bytes
+#define AZ_PDMA_W(kk_)                                                                                       \
+    {                                                                                                        \
+        const char* wbase = (const char*)(d.W + (kk_));                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < WPIECES; ++q_) lds_dma16(wbase + q_ * w_stride, w_ob, lds_w + q_ * 4096); \
+    }
+#define AZ_PDMA_IMG(cb_)                                                                                     \
+    {                                                                                                        \
+        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < IPIECES; ++q_)                                               \
+            if ((q_ * 4 + 3) * 8 + 7 < IMG_R || (q_ * 4 + wave) * 8 + 7 < IMG_R)                             \
+                lds_dma16(ibase + q_ * i_stride, i_ob, lds_img + q_ * 4096);                                 \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    int rbase[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        int ml = wr * 128 + mt * 16 + frow;
+        ml = ml < OUT_ROWS ? ml : 0;
+        const int bl = ml / OUT_PER, p = ml - bl * OUT_PER, y = p / OW, x = p - y * OW;
+        rbase[mt] = bl * IN_PER + y * IW + x;
+    }
+    const int b_row0 = IMG_BYTES + (wc * 64 + frow) * 128;
+    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
+#define AZ_PLDA(dst_, mt0_, ks_, dt_)                                                                        \
+    if constexpr (ABLATE < 5) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+        const int r_ = rbase[(mt0_) + i_] + (dt_);                                                           \
+        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
+    }
+#define AZ_PLDB(dst_, coff_)                                                                                 \
+    if constexpr (ABLATE < 5) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        dst_[i_] = *(const bf16x8*)(smem + b_row0 + i_ * 2048 + (coff_));
+#define AZ_PMMA(mt0_, fb_, fa_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+#define AZ_PSB __builtin_amdgcn_sched_barrier(0)
+#define AZ_PFENCE if constexpr (!IL) __builtin_amdgcn_sched_barrier(0)
+    // IL: the region's reads (for the NEXT cluster) go between this cluster's MFMAs: rep_ x { nmf_ MFMAs, 1 LDS read }
+#define AZ_PMIX(nmf_, rep_, tail_)                                                                           \
+    if constexpr (IL) {                                                                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < (rep_); ++g_) {                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, (nmf_), 0);                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+        }                                                                                                    \
+        if ((tail_) > 0) __builtin_amdgcn_sched_group_barrier(0x008, (tail_), 0);                            \
+    }
+    AZ_PDMA_W(0);
+    AZ_PDMA_IMG(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+    if constexpr (ABLATE >= 5) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fbX[i] = fbY[i] = faX[i] = faY[i] = *(const bf16x8*)(smem + lane * 16 + i * 1024);
+    }
+    AZ_PLDB(fbX, coffB0);
+    AZ_PLDA(faX, 0, 0, 0);
+    const int ncb = C / 64;
+    const int nk = ncb * 9;
+    int cb = 0, tap = 0, dt = 0;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, t_begin = 0, r_begin = 0;
+    if constexpr (STAMP) { t_begin = tprev = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
+#define AZ_PSTAMP(i_) if constexpr (STAMP) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[i_] += t_ - tprev; tprev = t_; }
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool sw = tap == 8;
+        const int ntap = sw ? 0 : tap + 1, ncbi = sw ? cb + 1 : cb;
+        const int nky = ntap / 3, ndt = nky * IW + (ntap - nky * 3);
+        const int kk = kt + 1 < nk ? ntap * C + ncbi * 64 : 8 * C + cb * 64;      // last step: re-fetch its own tile (unused)
+        AZ_PLDB(fbY, coffB1);
+        AZ_PLDA(faY, 4, 0, dt);
+        AZ_PFENCE;
+        AZ_PMMA(0, fbX, faX);
+        AZ_PMIX(1, 8, 8);
+        AZ_PSB;
+        AZ_PSTAMP(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this step's weight fragments are in registers
+        if constexpr (ABLATE < 4) __builtin_amdgcn_s_barrier();
+        AZ_PSB;
+        AZ_PSTAMP(1);
+        if constexpr (ABLATE < 3) AZ_PDMA_W(kk);
+        AZ_PSTAMP(2);
+        AZ_PLDA(faX, 0, 1, dt);
+        AZ_PFENCE;
+        AZ_PMMA(4, fbX, faY);
+        AZ_PMIX(2, 4, 8);
+        AZ_PSB;
+        AZ_PSTAMP(3);
+        AZ_PLDA(faY, 4, 1, dt);
+        AZ_PFENCE;
+        AZ_PMMA(0, fbY, faX);
+        AZ_PMIX(2, 4, 8);
+        AZ_PSB;
+        AZ_PSTAMP(4);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // my reads of the image slice are done (they are: one cluster old)
+        if constexpr (ABLATE < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next weight tile has landed
+        if constexpr (ABLATE < 4) __builtin_amdgcn_s_barrier();
+        AZ_PSB;
+        AZ_PSTAMP(5);
+        if (ABLATE == 0 && sw && ncbi < ncb) {                                  // single image buffer: the switch is covered by the CU's other workgroup
+            AZ_PDMA_IMG(ncbi);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        AZ_PSB;
+        AZ_PSTAMP(6);
+        AZ_PLDB(fbX, coffB0);                                    // next step's first fragments, under this step's last cluster
+        AZ_PLDA(faX, 0, 0, ndt);
+        AZ_PFENCE;
+        AZ_PMMA(4, fbY, faY);
+        AZ_PMIX(1, 8, 8);
+        AZ_PSB;
+        AZ_PSTAMP(7);
+        tap = ntap; cb = ncbi; dt = ndt;
+    }
+    if constexpr (STAMP) {
+        if (tid == 0 && d.dbg && blockIdx.x < 128) {
+            for (int i = 0; i < 8; ++i) d.dbg[16 * blockIdx.x + i] = seg[i];
+            d.dbg[16 * blockIdx.x + 8] = __builtin_amdgcn_s_memtime() - t_begin;
+            d.dbg[16 * blockIdx.x + 9] = __builtin_amdgcn_s_memrealtime() - r_begin;
+        }
+    }
+#undef AZ_PSTAMP
+#undef AZ_PDMA_W
+#undef AZ_PDMA_IMG
+#undef AZ_PLDA
+#undef AZ_PLDB
+#undef AZ_PMMA
+#undef AZ_PSB
+#undef AZ_PFENCE
+#undef AZ_PMIX
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ml = wr * 128 + mt * 16 + frow;
+            const int m = b0 * OUT_PER + ml;
+            if (ml >= OUT_ROWS || m >= M) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+        }
+    }
+}
+
 // ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
 // one wave per sample; lane holds 8 of the 512 inputs.
 __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_t* __restrict__ x /*[n][512] bf16*/,
@@ -1321,7 +1544,7 @@ NetWorkspace* netws_create(int channels, int max_batch, const char** err) {
     const int C = channels;
     const size_t B = (size_t)max_batch;
     bool ok = true;
-    ok &= (n->act2 = n->dalloc<uint16_t>(B * 42 * C)) != nullptr;
+    ok &= (n->act2 = n->dalloc<uint16_t>((B + 16) * 42 * C)) != nullptr;     // + 16 boards: k_conv_valid_pipe reads its last tile unclamped
     ok &= (n->act3 = n->dalloc<uint16_t>(B * 20 * C)) != nullptr;
     ok &= (n->act4 = n->dalloc<uint16_t>(B * 6 * C)) != nullptr;
     ok &= (n->fc1o = n->dalloc<uint16_t>(B * 1024)) != nullptr;
@@ -1474,11 +1697,16 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants
                           // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
                           // split, cross-step fragment prefetch, weights straight into registers.
 int g_conv3_ring = 0;
+int g_conv3_pipe = 1;       // conv3: 1 (default) k_conv_valid_pipe, fragment reads interleaved into the MFMA clusters; 2 the same without the interleave;
+                            // 0 k_conv_valid_img2 (round 1); all bit-identical.  3: 1 with per-segment clock stamps (tools/seg_probe.py); 11-15: the
+                            // timing ladder of 1 (WRONG results): no image switch, + no wait for the weight DMA, + no weight DMA, + no barriers, + no fragment reads
 void convnet_set_conv3_ring(int v) { g_conv3_ring = v; }
+void convnet_set_conv3_pipe(int v) { g_conv3_pipe = v; }
 int g_fc_ring = 1;        // 128x128 LDS-DMA ring kernel for under-filled grids (az_set_option "fc_ring"); bit-identical
 int g_ring64_max_tiles = 512;   // ... 64-row tiles for the FCs when twice the 128-row tile count is at most this ("fc_ring" = 3: never)
 int g_ring_max_tiles = 256;   // ... when the layer has at most this many tiles ("ring_max_tiles")
-int g_conv4_big = 2;      // conv4 on the 256x256 LDS-DMA kernel: 0 never, 1 always, 2 (default) when the batch bound >= 4096
+int g_ring_tile[6] = {0, 0, 0, 0, 0, 0};   // per layer: 0 = automatic, else BM * 10 + NS forced ("ring_tile" = layer * 10000 + BM * 10 + NS; measurement)
+int g_conv4_big = 0;      // conv4 on the 256x256 LDS-DMA kernel: 0 (default) never -- the ring tiles are faster at every batch size --, 1 always, 2 when the batch bound >= 4096
 
 template <int LAYER>
 // rows_hint = upper bound on the batch (the grids must cover it: tiles past the device-side count exit at once);
@@ -1493,7 +1721,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
         else hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;
     }
-    const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_typ >= 4096)))) &&
+    const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && !g_ring_tile[3] && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_typ >= 4096)))) &&
                      d.N % HBN_ == 0;
     if constexpr (LAYER == 2) if (v == 5 && g_conv3_ring) {      // experiment: conv3 on the 128x128 LDS-DMA ring (im2col from act2)
         const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
@@ -1505,7 +1733,18 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     if constexpr (LAYER == 2) if (v == 5 && d.N % 128 == 0 && d.cin % 64 == 0 && d.rows_per_sample == 20) {   // conv3 image-resident
         const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
         const int t8 = (tiles + 7) / 8 * 8;
-        hipLaunchKernelGGL((k_conv_valid_img2<LAYER, C3_NB, 6, 7, 2>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
+        const dim3 g3(t8 * (d.N / 128)), b3(256);
+        switch (g_conv3_pipe) {
+            case 1: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 0, true>), g3, b3, 0, s, d); break;
+            case 2: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 0, false>), g3, b3, 0, s, d); break;
+            case 3: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, true, 0, true>), g3, b3, 0, s, d); break;
+            case 11: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 1, true>), g3, b3, 0, s, d); break;
+            case 12: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 2, true>), g3, b3, 0, s, d); break;
+            case 13: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 3, true>), g3, b3, 0, s, d); break;
+            case 14: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 4, true>), g3, b3, 0, s, d); break;
+            case 15: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 5, true>), g3, b3, 0, s, d); break;
+            default: hipLaunchKernelGGL((k_conv_valid_img2<LAYER, C3_NB, 6, 7, 2>), g3, b3, 0, s, d); break;
+        }
         return;
     }
     if (big) {
@@ -1530,16 +1769,60 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     // LDS-DMA ring instead of register staging (bit-identical).  A grid that fits one round of one workgroup per CU is
     // latency / fetch bound: 4 stages (128 KiB) in flight; otherwise 2 stages (64 KiB) so that two workgroups share a CU.
     if (v == 5 && g_fc_ring) {
-        const int mt_typ = (rows_typ * d.rows_per_sample + GBM - 1) / GBM;
-        if (LAYER >= 4 && g_fc_ring != 3 && 2 * mt_typ * (d.N / GBN) <= g_ring64_max_tiles) {
-            // the FCs at de-duplicated batch sizes: 64-row tiles put a workgroup on every CU (each CU's L2 -> LDS rate is the limit)
-            const int mt64 = ((rows_hint * d.rows_per_sample + 63) / 64 + 7) / 8 * 8;
-            hipLaunchKernelGGL((k_gemm_ring<LAYER, 4, 64>), dim3(mt64 * (d.N / GBN)), dim3(256), 0, s, d);
-        } else if (mt_typ * (d.N / GBN) <= g_ring_max_tiles && (LAYER >= 4 || g_fc_ring == 2)) {
-            hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(grid), dim3(256), 0, s, d);
-        } else {
-            hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);
+        auto ring = [&](auto bm_c, auto ns_c) {
+            constexpr int BM = decltype(bm_c)::value, NS = decltype(ns_c)::value;
+            const int mtb = ((rows_hint * d.rows_per_sample + BM - 1) / BM + 7) / 8 * 8;
+            hipLaunchKernelGGL((k_gemm_ring<LAYER, NS, BM>), dim3(mtb * (d.N / GBN)), dim3(256), 0, s, d);
+        };
+        using std::integral_constant;
+        if constexpr (LAYER >= 3) {
+            const int f = g_ring_tile[LAYER];
+            if (f) {
+                switch (f) {
+                    case 642: ring(integral_constant<int, 64>{}, integral_constant<int, 2>{}); return;
+                    case 644: ring(integral_constant<int, 64>{}, integral_constant<int, 4>{}); return;
+                    case 962: ring(integral_constant<int, 96>{}, integral_constant<int, 2>{}); return;
+                    case 964: ring(integral_constant<int, 96>{}, integral_constant<int, 4>{}); return;
+                    case 1282: ring(integral_constant<int, 128>{}, integral_constant<int, 2>{}); return;
+                    case 1284: ring(integral_constant<int, 128>{}, integral_constant<int, 4>{}); return;
+                    case 1602: ring(integral_constant<int, 160>{}, integral_constant<int, 2>{}); return;
+                    case 1922: ring(integral_constant<int, 192>{}, integral_constant<int, 2>{}); return;
+                    default: break;
+                }
+            }
         }
+        // Tile choice from the expected row count (measured: tools/ring_tiles.py, profiles/README.md).  A workgroup's time grows with its
+        // tile, a launch's with its ROUNDS of workgroup slots (NS = 4: one per CU, 256 slots; NS = 2: two per CU, 512), so the best
+        // tile is the smallest that still fits the expected rows into whole rounds: conv4 at 3072 rows takes 120 us on 128-row tiles
+        // (576 workgroups: a second round for 64 of them) and 78 us on 160-row tiles (464 workgroups).
+        const int m_typ = (rows_typ > 0 ? rows_typ : rows_hint) * d.rows_per_sample, ncol = d.N / GBN;
+        auto wgs = [&](int bm) { return (m_typ + bm - 1) / bm * ncol; };
+        if (g_fc_ring == 1 || g_fc_ring == 2) {
+            if (wgs(64) <= 256) { ring(integral_constant<int, 64>{}, integral_constant<int, 4>{}); return; }
+            if (wgs(96) <= 256) { ring(integral_constant<int, 96>{}, integral_constant<int, 4>{}); return; }
+            if (LAYER >= 4 && wgs(128) <= 256) { ring(integral_constant<int, 128>{}, integral_constant<int, 4>{}); return; }
+            if (LAYER >= 4) {
+                if (wgs(96) <= 512) ring(integral_constant<int, 96>{}, integral_constant<int, 2>{});
+                else ring(integral_constant<int, 128>{}, integral_constant<int, 2>{});
+                return;
+            }
+            // conv4 (K = 9 * cin): two workgroups per CU; cost = time of one round of BM-row tiles x (whole rounds + what the last, partly
+            // filled round costs: workgroups alone on their CU finish in ~0.6 of a shared round)
+            int best = 128; float best_cost = 1e30f;
+            for (int bm : {96, 128, 160, 192}) {
+                const int w = wgs(bm), full = w / 512, rem = w % 512;
+                const float cost = (10.f + 0.42f * (float)bm) * ((float)full + (rem == 0 ? 0.f : rem <= 256 ? 0.6f : 1.f));
+                if (cost < best_cost) { best_cost = cost; best = bm; }
+            }
+            switch (best) {
+                case 96: ring(integral_constant<int, 96>{}, integral_constant<int, 2>{}); break;
+                case 160: ring(integral_constant<int, 160>{}, integral_constant<int, 2>{}); break;
+                case 192: ring(integral_constant<int, 192>{}, integral_constant<int, 2>{}); break;
+                default: ring(integral_constant<int, 128>{}, integral_constant<int, 2>{}); break;
+            }
+            return;
+        }
+        hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);     // "fc_ring" = 3: the plain 128-row ring
         return;
     }
     hipLaunchKernelGGL(k_gemm_mfma<LAYER>, dim3(grid), dim3(256), 0, s, d);
@@ -1591,6 +1874,7 @@ bool netws_read_clock_stamps(NetWorkspace* n, unsigned long long* out2048) {
 void convnet_set_conv4_big(int v) { g_conv4_big = v; }
 void convnet_set_fc_ring(int v) { g_fc_ring = v; }
 void convnet_set_ring_max_tiles(int v) { g_ring_max_tiles = v; }
+void convnet_set_ring_tile(int layer, int tile) { if (layer >= 3 && layer <= 5) g_ring_tile[layer] = tile; }
 int g_conv2_table = 1;    // conv2 as nine gathered rows of the per-model U table (default kernel set only; "conv2_table"); 0 = MFMA GEMM
 void convnet_set_conv2_table(int v) { g_conv2_table = v; }
 int g_conv1_table = 1;    // conv2 gathers its image from the conv1 table (default kernel set only); 0 = run k_conv1 into act1

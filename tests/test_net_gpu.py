@@ -95,9 +95,11 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
             conv_engine.set_option("conv4_big", big)
             pi, v = conv_engine.predict_states(states, 5)
             assert np.array_equal(pi, outs[0][0]) and np.array_equal(v, outs[0][1])
-        conv_engine.set_option("conv4_big", 2)
-        for key, vals in (("fc_ring", (0, 2, 1)), ("conv3_ring", (1, 2, 0)), ("conv1_table", (0, 1))):   # the LDS-DMA ring GEMM on fc1 /
-            for val in vals:                                                                            # fc2 / conv4 / conv3, conv1 as a kernel
+        conv_engine.set_option("conv4_big", 0)
+        ring_tiles = tuple(layer * 10000 + t for layer in (3, 4, 5) for t in (642, 644, 962, 964, 1282, 1284, 1602, 1922)) + (30000, 40000, 50000)
+        for key, vals in (("fc_ring", (0, 2, 3, 1)), ("conv3_ring", (1, 2, 0)), ("conv1_table", (0, 1)),   # the LDS-DMA ring GEMM on fc1 /
+                          ("conv3_pipe", (0, 2, 3, 1)), ("ring_tile", ring_tiles)):   # fc2 / conv4 / conv3, conv1 as a kernel, the conv3 kernels, every ring tile
+            for val in vals:
                 conv_engine.set_option(key, val)
                 pi, v = conv_engine.predict_states(states, 5)
                 assert np.array_equal(pi, outs[0][0]) and np.array_equal(v, outs[0][1]), (key, val)
@@ -105,8 +107,11 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
             conv_engine.set_option("gemm_variant", 4)         # removed variants are refused, not silently mapped
     finally:
         conv_engine.set_option("gemm_variant", 5)
-        conv_engine.set_option("conv4_big", 2)
+        conv_engine.set_option("conv4_big", 0)
         conv_engine.set_option("conv2_table", 1)
+        conv_engine.set_option("conv3_pipe", 1)
+        for layer in (3, 4, 5):
+            conv_engine.set_option("ring_tile", layer * 10000)
         conv_engine.set_option("fc_ring", 1)
         conv_engine.set_option("conv3_ring", 0)
         conv_engine.set_option("conv1_table", 1)
@@ -139,13 +144,13 @@ def test_net_parity_at_bench_scale(engine, oracle):
         engine.set_option("conv1_table", 1)
         # a different row order through the full-size kernels (rows land in other tiles / XCDs)
         engine.set_option("gemm_variant", 5)
-        engine.set_option("conv4_big", 2)
+        engine.set_option("conv4_big", 0)
         perm = np.random.default_rng(3).permutation(8192)
         pi, v = engine.predict_states(states[perm], 20)
         assert np.array_equal(pi, ref_pi[perm]) and np.array_equal(v, ref_v[perm])
     finally:
         engine.set_option("gemm_variant", 5)
-        engine.set_option("conv4_big", 2)
+        engine.set_option("conv4_big", 0)
         engine.set_option("conv1_table", 1)
         engine.set_option("conv2_table", 1)
     n = 4096
