@@ -240,6 +240,68 @@ __global__ __launch_bounds__(256) void k_conv2_table(const EvalBatch eb, const u
     }
 }
 
+// The same gather with the CHANNELS split over the XCDs.  The 181 MB table does not fit the 8 x 4 MiB of L2, and in k_conv2_table
+// every XCD gathers whole 1-KiB rows, so each L2 holds a random eighth of the hot rows and half of the gathered bytes come from
+// beyond it (PMC: 177 of 354 KB per board).  Workgroup ids go round the XCDs, so here workgroup id handles the 64-channel slice
+// id & 7 of its boards: an XCD only ever touches ITS 128-byte column of every row -- 22.6 MB, of which the rows that occur in play
+// (a stone never floats over an empty cell: ~4000 of the 19683 patterns) are ~4.6 MB, about one L2.  One wave per (board, slice):
+// lanes 0..41 compute the board's 42 patterns once, then six passes of one board row each, lane = (x, 16-byte chunk); the nine
+// neighbour patterns come from the owning lanes by ds_bpermute.  Same per-channel summation order as k_conv2_table: bit-identical.
+__global__ __launch_bounds__(256, 4) void k_conv2_table_x(const EvalBatch eb, const uint16_t* __restrict__ U /*[19683 + 1][9][C] f16, last row 0*/,
+                                                       const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out /*[n][42][C] bf16*/,
+                                                       int C) {
+    const int nsl = C / 64;                                   // channel slices (8 at C = 512: one per XCD)
+    const int slice = blockIdx.x % nsl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = *eb.n;
+    const int x = lane < 56 ? lane >> 3 : 6, chunk = lane & 7;      // lanes 56..63 shadow x = 6 and do not store
+    const int coff = slice * 64 + chunk * 8;                  // first of this lane's 8 channels
+    const float4 b0 = *(const float4*)(bias + coff), b1 = *(const float4*)(bias + coff + 4);
+    const uint32_t stride = (gridDim.x / nsl) * 4u;
+    const float one = 1.0f;                                   // v_fma_mix_f32's f32 multiplier, in an SGPR
+    // bpermute source lane (x 4) of every tap's neighbour in board row y = 1 (rows shift by 7 lanes); taps outside the board read
+    // lane 63, which holds the all-zero row appended to the table: every load is unconditional, and adding +0 changes no sum
+    for (uint32_t b = (blockIdx.x / nsl) * 4u + wave; b < n; b += stride) {
+        const ulonglong2 sv = eb.state[b];
+        // byte offset of U[pattern of this lane's position][0][0]; lanes 42.. : the zero row
+        const uint32_t mybase = (lane < 42 ? conv1_pattern(sv.x, sv.y, lane / 7, lane % 7) : (uint32_t)CONV1_PATTERNS) * (uint32_t)(18 * C);
+#pragma unroll 1
+        for (int y = 0; y < 6; ++y) {
+            uint32_t base[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int qy = y + t / 3 - 1, qx = x + t % 3 - 1;
+                const bool in = qy >= 0 && qy < 6 && qx >= 0 && qx < 7;
+                base[t] = (uint32_t)__builtin_amdgcn_ds_bpermute((in ? qy * 7 + qx : 63) << 2, (int)mybase);
+            }
+            __builtin_amdgcn_sched_barrier(0);              // all nine permutes in flight before the first load waits for one
+            uint4 u[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) u[t] = *(const uint4*)((const char*)U + (base[t] + (uint32_t)(t * 2 * C + coff * 2)));
+            __builtin_amdgcn_sched_barrier(0);              // ... and all nine loads before the first add waits for one
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {                   // taps in (ky, kx) order: the fixed summation order of a row
+                const uint32_t w[4] = {u[t].x, u[t].y, u[t].z, u[t].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // acc += (float)f16 as ONE v_fma_mix_f32 (exact convert, one rounding: the same bits as convert + add)
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * i]) : "v"(w[i]), "s"(one));
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * i + 1]) : "v"(w[i]), "s"(one));
+                }
+            }
+            if (lane < 56) {
+                uint4 o;
+                o.x = pack_bf16x2(fmaxf(acc[0] + b0.x, 0.f), fmaxf(acc[1] + b0.y, 0.f));
+                o.y = pack_bf16x2(fmaxf(acc[2] + b0.z, 0.f), fmaxf(acc[3] + b0.w, 0.f));
+                o.z = pack_bf16x2(fmaxf(acc[4] + b1.x, 0.f), fmaxf(acc[5] + b1.y, 0.f));
+                o.w = pack_bf16x2(fmaxf(acc[6] + b1.z, 0.f), fmaxf(acc[7] + b1.w, 0.f));
+                *(uint4*)(out + ((size_t)b * 42 + (size_t)(y * 7 + x)) * C + coff) = o;
+            }
+        }
+    }
+}
+
 // ---- implicit GEMM on MFMA: out[M,N] = relu(A_gather[M,K] * W[N,K]^T + bias) ---------------------------
 // Row m = (sample b, output position (y,x)); K index = tap * cin + c with tap = ky*tap_w + kx reading the
 // input at position (y+ky, x+kx) of an [in_h][in_w][in_c] channels-last image (the 'same' conv reads a
@@ -394,14 +456,12 @@ __device__ __forceinline__ void lds_dma16(const void* sbase /*uniform*/, uint32_
 // s_waitcnt (never 0 inside the loop) and one raw barrier per step.
 // BM = 128 or 64 rows per tile: the 64-row tile doubles the workgroups of a layer whose 128-row grid leaves CUs idle (fc1 / fc2 at
 // de-duplicated batch sizes: a CU fetches L2 -> LDS at ~19 B/clk whatever else it does, so idle CUs are idle fetch bandwidth).
-template <int LAYER, int NS, int BM = 128>
-__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const GemmDesc d) {
+template <int NS, int BM>
+__device__ __forceinline__ void gemm_ring_body(const GemmDesc& d, unsigned char* smem /*NS * (BM * 128 + 16384) bytes of LDS*/, const int M) {
     static_assert(BM % 32 == 0 && BM >= 64 && BM <= 192 && NS * (BM * 128 + 16384) <= 163840 && 2 * (BM / 32 + 4) <= 63, "tile");
     constexpr int MT = BM / 32;                       // 16-row tiles per wave (2 x 2 waves) = A pieces per wave
     constexpr int STAGE = BM * 128 + 16384;           // [A BM x 128 B | W 128 x 128 B]
     constexpr int NDMA = MT + 4;                      // DMA instructions per wave per stage
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
-    const int M = (int)(*d.n_dev) * d.rows_per_sample;
     const int ntaps = d.K / d.cin;
     const int NT = d.N / GBN;
     const int id = blockIdx.x;
@@ -510,6 +570,49 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const Gemm
             o.y = pack_bf16x2(r2, r3);
             *(uint2*)(d.out + (size_t)m * d.N + n) = o;
         }
+    }
+}
+
+template <int LAYER, int NS, int BM = 128>
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BM * 128 + 16384)];
+    gemm_ring_body<NS, BM>(d, smem, (int)(*d.n_dev) * d.rows_per_sample);
+}
+
+// Tile rows chosen ON THE DEVICE from the batch's row count (the host only knows an estimate when it launches).  A workgroup's time
+// grows with its tile, a launch's with its ROUNDS of workgroup slots (NS = 4: one workgroup per CU, 256 slots; NS = 2: two, 512), so
+// the best tile is the smallest whose grid still fits whole rounds (measured: tools/ring_tiles.py, profiles/README.md: conv4 at 3072
+// rows takes 120 us on 128-row tiles -- 576 workgroups, a second round for 64 of them -- and 78 us on 160-row tiles).
+AZ_HD int ring_pick_bm(int M, int ncol, int ns, bool conv) {
+    auto wgs = [&](int bm) { return (M + bm - 1) / bm * ncol; };
+    if (ns == 4) return wgs(64) <= 256 ? 64 : wgs(96) <= 256 ? 96 : 128;
+    if (!conv) return wgs(96) <= 512 ? 96 : 128;
+    // conv4 (K = 9 * cin), two workgroups per CU: cost = one round of BM-row tiles x (whole rounds + the last, partly filled one:
+    // workgroups alone on their CU finish in ~0.6 of a shared round)
+    int best = 128;
+    float best_cost = 1e30f;
+    for (int bm = 96; bm <= 192; bm += 32) {
+        const int w = wgs(bm), full = w / 512, rem = w % 512;
+        const float cost = (10.f + 0.42f * (float)bm) * ((float)full + (rem == 0 ? 0.f : rem <= 256 ? 0.6f : 1.f));
+        if (cost < best_cost) { best_cost = cost; best = bm; }
+    }
+    return best;
+}
+template <int LAYER, int NS>
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring_auto(const GemmDesc d) {
+    constexpr int BMAX = NS == 2 ? 192 : 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BMAX * 128 + 16384)];
+    const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    const int bm = __builtin_amdgcn_readfirstlane(ring_pick_bm(M, d.N / GBN, NS, d.tap_w > 1));
+    if constexpr (NS == 2) {
+        if (bm == 96) gemm_ring_body<2, 96>(d, smem, M);
+        else if (bm == 160) gemm_ring_body<2, 160>(d, smem, M);
+        else if (bm == 192) gemm_ring_body<2, 192>(d, smem, M);
+        else gemm_ring_body<2, 128>(d, smem, M);
+    } else {
+        if (bm == 64) gemm_ring_body<4, 64>(d, smem, M);
+        else if (bm == 96) gemm_ring_body<4, 96>(d, smem, M);
+        else gemm_ring_body<4, 128>(d, smem, M);
     }
 }
 
@@ -1511,7 +1614,8 @@ ConvNet* convnet_create(int channels, const char** err) {
     ok &= (n->w1 = n->dalloc<float>(18 * (size_t)C)) != nullptr;
     ok &= (n->b1 = n->dalloc<float>(C)) != nullptr;
     ok &= (n->t1 = n->dalloc<uint16_t>((size_t)CONV1_PATTERNS * C)) != nullptr;
-    ok &= (n->u2 = n->dalloc<uint16_t>((size_t)CONV1_PATTERNS * 9 * C)) != nullptr;
+    ok &= (n->u2 = n->dalloc<uint16_t>((size_t)(CONV1_PATTERNS + 1) * 9 * C)) != nullptr;     // + one all-zero row (k_conv2_table_x)
+    if (n->u2) ok &= hipMemset(n->u2 + (size_t)CONV1_PATTERNS * 9 * C, 0, (size_t)9 * C * sizeof(uint16_t)) == hipSuccess;
     ok &= (n->w2r = n->dalloc<uint16_t>((size_t)9 * C * C)) != nullptr;
     ok &= (n->npat = n->dalloc<uint32_t>(1)) != nullptr;
     if (ok) { const uint32_t np = CONV1_PATTERNS; ok = hipMemcpy(n->npat, &np, sizeof np, hipMemcpyHostToDevice) == hipSuccess; }
@@ -1795,31 +1899,31 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
         // tile, a launch's with its ROUNDS of workgroup slots (NS = 4: one per CU, 256 slots; NS = 2: two per CU, 512), so the best
         // tile is the smallest that still fits the expected rows into whole rounds: conv4 at 3072 rows takes 120 us on 128-row tiles
         // (576 workgroups: a second round for 64 of them) and 78 us on 160-row tiles (464 workgroups).
-        const int m_typ = (rows_typ > 0 ? rows_typ : rows_hint) * d.rows_per_sample, ncol = d.N / GBN;
-        auto wgs = [&](int bm) { return (m_typ + bm - 1) / bm * ncol; };
-        if (g_fc_ring == 1 || g_fc_ring == 2) {
-            if (wgs(64) <= 256) { ring(integral_constant<int, 64>{}, integral_constant<int, 4>{}); return; }
-            if (wgs(96) <= 256) { ring(integral_constant<int, 96>{}, integral_constant<int, 4>{}); return; }
-            if (LAYER >= 4 && wgs(128) <= 256) { ring(integral_constant<int, 128>{}, integral_constant<int, 4>{}); return; }
-            if (LAYER >= 4) {
-                if (wgs(96) <= 512) ring(integral_constant<int, 96>{}, integral_constant<int, 2>{});
-                else ring(integral_constant<int, 128>{}, integral_constant<int, 2>{});
-                return;
-            }
-            // conv4 (K = 9 * cin): two workgroups per CU; cost = time of one round of BM-row tiles x (whole rounds + what the last, partly
-            // filled round costs: workgroups alone on their CU finish in ~0.6 of a shared round)
-            int best = 128; float best_cost = 1e30f;
-            for (int bm : {96, 128, 160, 192}) {
-                const int w = wgs(bm), full = w / 512, rem = w % 512;
-                const float cost = (10.f + 0.42f * (float)bm) * ((float)full + (rem == 0 ? 0.f : rem <= 256 ? 0.6f : 1.f));
-                if (cost < best_cost) { best_cost = cost; best = bm; }
-            }
-            switch (best) {
-                case 96: ring(integral_constant<int, 96>{}, integral_constant<int, 2>{}); break;
-                case 160: ring(integral_constant<int, 160>{}, integral_constant<int, 2>{}); break;
-                case 192: ring(integral_constant<int, 192>{}, integral_constant<int, 2>{}); break;
+        if (g_fc_ring == 2) {       // A/B: the tile picked on the HOST from its estimate of the row count (same rule)
+            const int m_typ = (rows_typ > 0 ? rows_typ : rows_hint) * d.rows_per_sample, ncol = d.N / GBN;
+            const bool conv = d.tap_w > 1;
+            const int ns = (m_typ + (conv ? 95 : 127)) / (conv ? 96 : 128) * ncol <= 256 ? 4 : 2;
+            switch (ring_pick_bm(m_typ, ncol, ns, conv) * 10 + ns) {
+                case 644: ring(integral_constant<int, 64>{}, integral_constant<int, 4>{}); break;
+                case 964: ring(integral_constant<int, 96>{}, integral_constant<int, 4>{}); break;
+                case 1284: ring(integral_constant<int, 128>{}, integral_constant<int, 4>{}); break;
+                case 962: ring(integral_constant<int, 96>{}, integral_constant<int, 2>{}); break;
+                case 1602: ring(integral_constant<int, 160>{}, integral_constant<int, 2>{}); break;
+                case 1922: ring(integral_constant<int, 192>{}, integral_constant<int, 2>{}); break;
                 default: ring(integral_constant<int, 128>{}, integral_constant<int, 2>{}); break;
             }
+            return;
+        }
+        if (g_fc_ring == 1) {
+            // the host picks the FAMILY from its estimate (NS = 4: one workgroup per CU, for grids of at most 256 tiles; the estimate
+            // + 15 %: a batch over the limit would pay a whole second round), the kernel picks the tile rows from the exact count
+            const int m_est = (int)((rows_typ > 0 ? (long long)rows_typ * 115 / 100 : (long long)rows_hint) * d.rows_per_sample), ncol = d.N / GBN;
+            const bool conv = d.tap_w > 1;
+            const bool one_per_cu = (m_est + (conv ? 95 : 127)) / (conv ? 96 : 128) * ncol <= 256;
+            const int bmin = one_per_cu ? 64 : 96;                                   // the grid covers the smallest tile of the family
+            const int mtb = ((rows_hint * d.rows_per_sample + bmin - 1) / bmin + 7) / 8 * 8;
+            if (one_per_cu) hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 4>), dim3(mtb * ncol), dim3(256), 0, s, d);
+            else hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 2>), dim3(mtb * ncol), dim3(256), 0, s, d);
             return;
         }
         hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);     // "fc_ring" = 3: the plain 128-row ring
@@ -1875,7 +1979,8 @@ void convnet_set_conv4_big(int v) { g_conv4_big = v; }
 void convnet_set_fc_ring(int v) { g_fc_ring = v; }
 void convnet_set_ring_max_tiles(int v) { g_ring_max_tiles = v; }
 void convnet_set_ring_tile(int layer, int tile) { if (layer >= 3 && layer <= 5) g_ring_tile[layer] = tile; }
-int g_conv2_table = 1;    // conv2 as nine gathered rows of the per-model U table (default kernel set only; "conv2_table"); 0 = MFMA GEMM
+int g_conv2_table = 1;    // conv2 as nine gathered rows of the per-model U table (default kernel set only; "conv2_table"): 1 channel slices per XCD
+                          // (k_conv2_table_x), 2 whole rows (k_conv2_table; bit-identical to 1); 0 = MFMA GEMM
 void convnet_set_conv2_table(int v) { g_conv2_table = v; }
 int g_conv1_table = 1;    // conv2 gathers its image from the conv1 table (default kernel set only); 0 = run k_conv1 into act1
 void convnet_set_conv1_table(int v) { g_conv1_table = v; }
@@ -1915,8 +2020,14 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;
     if (timed) (void)hipEventRecord(rec.e1, s);
     if (table2) {
-        const size_t blocks = std::min<size_t>(((size_t)rows_hint * 6 + 3) / 4, 256 * 8);   // one wave per (board, board row)
-        hipLaunchKernelGGL(k_conv2_table, dim3((unsigned)blocks), dim3(256), (size_t)9 * C * 2, s, eb, n->u2, n->bg[0], ws->act2, C);
+        if (g_conv2_table == 2) {
+            const size_t blocks = std::min<size_t>(((size_t)rows_hint * 6 + 3) / 4, 256 * 8);   // one wave per (board, board row)
+            hipLaunchKernelGGL(k_conv2_table, dim3((unsigned)blocks), dim3(256), (size_t)9 * C * 2, s, eb, n->u2, n->bg[0], ws->act2, C);
+        } else {
+            const size_t nsl = (size_t)C / 64;                                                  // one wave per (board, 64-channel slice)
+            const size_t blocks = std::min<size_t>(((size_t)rows_hint + 3) / 4, 256) * nsl;
+            hipLaunchKernelGGL(k_conv2_table_x, dim3((unsigned)blocks), dim3(256), 0, s, eb, n->u2, n->bg[0], ws->act2, C);
+        }
     } else {
         launch_gemm<1>(d, rows_hint, rows_typ, s);
     }

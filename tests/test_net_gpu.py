@@ -169,6 +169,13 @@ def test_net_parity_at_bench_scale(engine, oracle):
         assert np.array_equal(pi, tab_pi[:m]) and np.array_equal(v, tab_v[:m]), m
     pi, v = engine.predict_states(states[perm], 20)
     assert np.array_equal(pi, tab_pi[perm]) and np.array_equal(v, tab_v[perm])
+    try:                                                            # the gather as whole rows per wave (round 2's first kernel): same bits
+        engine.set_option("conv2_table", 2)
+        for m in (8192, 5003, 3):
+            pi, v = engine.predict_states(states[:m], 20)
+            assert np.array_equal(pi, tab_pi[:m]) and np.array_equal(v, tab_v[:m]), m
+    finally:
+        engine.set_option("conv2_table", 1)
     assert np.abs(tab_pi[:n] - rpi).max() <= 2e-3, np.abs(tab_pi[:n] - rpi).max()
     assert np.abs(tab_v[:n] - rv).max() <= 6e-3, np.abs(tab_v[:n] - rv).max()
     assert not np.array_equal(tab_pi, ref_pi)                       # (a different rounding, not a different function)
