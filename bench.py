@@ -341,7 +341,7 @@ def main():
                         "avg_launch_ms": st["net_conv3_ms"] / st["net_launches"], "avg_flop_per_launch": st["net_conv3_flops"] / st["net_launches"],
                         **common}
                 gb = st["net_conv2_bytes"] / (st["net_conv2_ms"] * 1e-3) / 1e9
-                line["conv2_table"] = {"bound": "hbm", "kernel": "k_conv2_table (conv1 + conv2 as nine gathered rows of the per-model U table per output "
+                line["conv2_table"] = {"bound": "hbm", "kernel": "k_conv2_table_x (conv1 + conv2 as nine gathered rows of the per-model U table per output "
                                                                  "position; 181 MB f16 table, served mostly from L2 / Infinity Cache)",
                                        "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
                                        "avg_launch_ms": st["net_conv2_ms"] / st["net_launches"],

@@ -116,10 +116,16 @@ const char* az_last_error(const az_engine* e);
 /* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
  * net uses (0 = 128x128 register-staged tiles for every layer, 1 / 2 = 256x256 LDS-DMA tiles, 3 = conv2 image-resident
  * in one 8-wave workgroup per CU, 5 = default, conv2 image-resident in two 4-wave workgroups per CU; 11-17 = timing
- * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 / 1 / 2 (auto). "profile_every" = n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and tree_ms
+ * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 (default: conv4 on the ring kernel) / 1 (256x256 kernel) / 2 (256x256 from
+ * 4096 rows). "conv3_pipe" = 1 (default: conv3 with the LDS-DMA issued from inline asm and a software-pipelined K-step) / 2 (the same
+ * without interleaving the fragment reads into the MFMA clusters) / 0 (round 1's kernel) / 3 (1 + clock stamps), all bit-identical;
+ * 11-15 = its timing ladder (WRONG results). "ring_tile" = layer * 10000 + rows * 10 + stages forces one ring tile for layer 3 (conv4) /
+ * 4 (fc1) / 5 (fc2), layer * 10000 = automatic again; bit-identical. "profile_every" = n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and tree_ms
  * sums then cover that sample of launches; every bracket costs a little GPU idle time between dependent kernels). "fused_search" = 1
  * (default): the stub / hash nets run a whole search in one launch, 0 = one launch per simulation like the conv net. "fc_ring" = 1
- * (default): LDS-DMA ring kernel for fc1 / fc2 / small-batch conv4, 0 = register-staged tiles. "conv2_table" = 1 (default): conv2 of the
+ * (default): LDS-DMA ring kernel for conv4 / fc1 / fc2 with 64..192-row tiles picked on the device from the batch's row count, 2 = the
+ * tile picked on the host from its estimate, 3 = always 128-row tiles, 0 = register-staged tiles. "conv2_table" = 1 (default; 2 = the
+ * same gather as whole rows per wave instead of one 64-channel slice per XCD, bit-identical): conv2 of the
  * default kernel set is nine gathered rows of a per-model table (conv2 is linear in conv1's output, which is one of 3^9 table rows
  * per position: csrc/az_net.hip) -- 198 of the net's 329 MFLOP per leaf are never executed; 0 = conv2 as the MFMA implicit GEMM
  * (same function, different rounding: each is batch-independent and within the stated tolerance of the fp32 reference).
