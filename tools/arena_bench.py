@@ -16,5 +16,5 @@ st = e.stats()
 print(json.dumps({"config": f"arena {games} paired games, {sims} sims/move, bf16 C=512 nets (seeds 1 vs 2), per-game tree pair",
                   "seconds": dt, "games_per_sec": games / dt, "wld_new": wld.tolist(), "simulations_per_sec": st["simulations"] / dt,
                   "node_expansions_per_sec": st["expansions"] / dt, "leaf_evals_per_sec": st["leaf_evals"] / dt,
-                  "conv2_tflops": st["net_conv2_flops"] / st["net_conv2_ms"] / 1e9,
+                  "conv3_tflops": st["net_conv3_flops"] / max(st["net_conv3_ms"], 1e-9) / 1e9,
                   "mfma_fraction_end_to_end": st["leaf_evals"] / dt * 328986624 / 2.5e15}))
