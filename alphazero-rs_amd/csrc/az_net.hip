@@ -451,11 +451,13 @@ __device__ __forceinline__ void lds_dma16(const void* sbase /*uniform*/, uint32_
 // fc1 (M = leaves, N = 1024, K = 3072) has 176 tiles at 2700 leaves and fc2 88: fewer workgroups than CUs, so k_gemm_mfma
 // runs one 4-wave workgroup per CU and every K-step exposes a full L2 / HBM round trip between its global loads and the
 // barrier that publishes them (~1 us per step, 48 steps: the kernel is latency-bound at 19 % of the MFMA peak).  Same tile,
-// same per-row K order (bit-identical), but the operands go global -> LDS with global_load_lds into a ring of NS stages
-// (32 KiB each, 128 KiB at NS = 4: the LDS an under-filled CU has to spare), NS-1 stages in flight, retired with a COUNTED
-// s_waitcnt (never 0 inside the loop) and one raw barrier per step.
-// BM = 128 or 64 rows per tile: the 64-row tile doubles the workgroups of a layer whose 128-row grid leaves CUs idle (fc1 / fc2 at
-// de-duplicated batch sizes: a CU fetches L2 -> LDS at ~19 B/clk whatever else it does, so idle CUs are idle fetch bandwidth).
+// same per-row K order (bit-identical), but the operands go global -> LDS by asm-issued LDS-DMA into a ring of NS stages
+// (BM x 128 B of A + 16 KiB of W each; 128 KiB at NS = 4, BM = 128: the LDS an under-filled CU has to spare), NS-1 stages in
+// flight, retired with a COUNTED s_waitcnt (never 0 inside the loop) and one raw barrier per step; both 32-deep halves' fragments
+// are requested up front and the second half's reads sit between the first half's MFMAs.
+// BM = 64 .. 192 rows per tile (k_gemm_ring_auto picks it on the device): a CU fetches its tiles L2 -> LDS at a bounded rate
+// (~19-27 B/clk) whatever else it does, so idle CUs are idle fetch bandwidth and a second, nearly empty round of workgroups is a
+// whole round of time -- the tile is the smallest whose grid still fits whole rounds of workgroup slots.
 template <int NS, int BM>
 __device__ __forceinline__ void gemm_ring_body(const GemmDesc& d, unsigned char* smem /*NS * (BM * 128 + 16384) bytes of LDS*/, const int M) {
     static_assert(BM % 32 == 0 && BM >= 64 && BM <= 192 && NS * (BM * 128 + 16384) <= 163840 && 2 * (BM / 32 + 4) <= 63, "tile");
