@@ -174,3 +174,14 @@ def test_rust_shim_matches_the_header():
     # the NNet / AsyncMcts surfaces the reference's callers use
     for needle in ("pub fn new<P: AsRef<Path>>", "pub fn predict(", "pub fn train(", "pub fn from_state(", "pub fn get_action_prob("):
         assert needle in src, needle
+
+
+def test_tools_and_examples_compile():
+    """Every measurement helper and example parses (they only run on the GPU box, so a syntax error would otherwise surface there)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "examples", "*.py")) +
+                   [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
+    assert len(files) > 20
+    for f in files:
+        compile(open(f).read(), f, "exec")
