@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event brackets (roofline = null)")
-    ap.add_argument("--profile-every", type=int, default=16, help="bracket every n-th simulation step with HIP events (each bracket idles the GPU a little)")
+    ap.add_argument("--profile-every", type=int, default=64, help="bracket every n-th simulation step with HIP events (each bracket idles the GPU a little)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary no-dedup and arena (config 3) measurements")
     ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
