@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
         if constexpr (ABLATE < 4) __builtin_amdgcn_s_barrier();
         AZ_PSB;
         AZ_PSTAMP(5);
-        if (ABLATE == 0 && sw && ncbi < ncb) {                                  // single image buffer: the switch is covered by the CU's other workgroup
+        if (ABLATE <= 0 && sw && ncbi < ncb) {                                  // single image buffer: the switch is covered by the CU's other workgroup
             AZ_PDMA_IMG(ncbi);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1495,23 +1495,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
 #undef AZ_PSB
 #undef AZ_PFENCE
 #undef AZ_PMIX
+    // Epilogue through LDS: a lane holds 4 consecutive channels of 32 (row tile, column tile) pairs -- stored directly that is 32
+    // eight-byte stores per lane in 32-byte pieces of 16 different rows each (7 % of the kernel at 3072 rows).  The image and weight
+    // buffers are dead now: the tile (+ bias, ReLU, bf16) goes to LDS as [240 rows][128 channels] with a 272-byte row stride
+    // (conflict-free for both directions), and leaves as whole 256-byte row segments, 16 bytes per lane.
+    constexpr int EP_STRIDE = NCOL * 2 + 16;
+    static_assert(OUT_ROWS * EP_STRIDE <= IMG_BYTES + NCOL * 128, "the output tile must fit the dead buffers");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                     // every wave is past its last fragment read (and the unused last DMA has landed)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
+        const int nl = wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n0 + nl);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int ml = wr * 128 + mt * 16 + frow;
-            const int m = b0 * OUT_PER + ml;
-            if (ml >= OUT_ROWS || m >= M) continue;
+            if (ml >= OUT_ROWS) continue;
             float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
                   r3 = acc[mt][nt][3] + bv.w;
             if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
             uint2 o;
             o.x = pack_bf16x2(r0, r1);
             o.y = pack_bf16x2(r2, r3);
-            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+            *(uint2*)(smem + ml * EP_STRIDE + nl * 2) = o;
         }
+    }
+    __syncthreads();
+    constexpr int EP_CHUNKS = OUT_ROWS * (NCOL / 8);        // 16-byte chunks of the tile
+#pragma unroll
+    for (int it = 0; it < (EP_CHUNKS + 255) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int ml = idx / (NCOL / 8), c = idx - ml * (NCOL / 8);
+        const int m = b0 * OUT_PER + ml;
+        if (idx >= EP_CHUNKS || m >= M) continue;
+        const uint4 v = *(const uint4*)(smem + ml * EP_STRIDE + c * 16);
+        if (ABLATE >= 0 || v.x == 0x12345678u) *(uint4*)(d.out + (size_t)m * d.N + n0 + c * 8) = v;      // ABLATE -1: the kernel without its stores
     }
 }
 
@@ -1844,6 +1862,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
             case 1: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 0, true>), g3, b3, 0, s, d); break;
             case 2: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 0, false>), g3, b3, 0, s, d); break;
             case 3: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, true, 0, true>), g3, b3, 0, s, d); break;
+            case 10: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, -1, true>), g3, b3, 0, s, d); break;
             case 11: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 1, true>), g3, b3, 0, s, d); break;
             case 12: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 2, true>), g3, b3, 0, s, d); break;
             case 13: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 3, true>), g3, b3, 0, s, d); break;
