@@ -556,22 +556,36 @@ __device__ __forceinline__ void gemm_ring_body(const GemmDesc& d, unsigned char*
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef AZ_RDMA
+    // epilogue through LDS (the ring is dead): + bias, ReLU, bf16 as [BM rows][128 channels] with a 272-byte row stride, then whole
+    // 256-byte row segments, 16 bytes per lane (instead of 8-byte stores in 32-byte pieces of 16 different rows)
+    constexpr int EP_STRIDE = 272;
+    static_assert(BM * EP_STRIDE <= NS * STAGE, "the output tile must fit the ring");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
+        const int nl = wc * 64 + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n0 + nl);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + wr * (BM / 2) + mt * 16 + frow;
-            if (m >= M) continue;
+            const int ml = wr * (BM / 2) + mt * 16 + frow;
             float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
                   r3 = acc[mt][nt][3] + bv.w;
             if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
             uint2 o;
             o.x = pack_bf16x2(r0, r1);
             o.y = pack_bf16x2(r2, r3);
-            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
+            *(uint2*)(smem + ml * EP_STRIDE + nl * 2) = o;
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < BM * 16 / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int ml = idx >> 4, c = idx & 15;
+        const int m = m0 + ml;
+        if (m >= M) continue;
+        *(uint4*)(d.out + (size_t)m * d.N + n0 + c * 8) = *(const uint4*)(smem + ml * EP_STRIDE + c * 16);
     }
 }
 
