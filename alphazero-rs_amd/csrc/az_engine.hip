@@ -194,6 +194,7 @@ struct az_engine {
     // leaf de-duplication + evaluation cache (az_set_option "eval_dedup", "eval_cache_log2", "eval_cache_max_stones",
     // "eval_cache_persist")
     int profile_every = 1;          // profile mode: bracket every n-th simulation step ("profile_every")
+    int dedup_stats = 1;            // "dedup_stats": the leaf-row accounting counters (requested / executed / hits / duplicates)
     uint64_t profile_tick = 0;
     int dedup_epoch_max = 0x7FFF;   // election-table epochs before the tables are cleared (15 bits; tests lower it: "dedup_epoch_max")
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
@@ -261,8 +262,8 @@ void ensure_cache(az_engine* e) {
     if (e->cache_alloc_log2 == e->eval_cache_log2) return;
     e->cache_mem.release();
     e->cache = EvalCache{};
-    e->cache.stat = e->cache_mem.alloc<unsigned long long>(DD_COUNT);
-    HIPCHK(hipMemset(e->cache.stat, 0, DD_COUNT * sizeof(unsigned long long)));
+    e->cache.stat = e->cache_mem.alloc<unsigned long long>((size_t)DD_REPLICAS * DD_STRIDE);
+    HIPCHK(hipMemset(e->cache.stat, 0, (size_t)DD_REPLICAS * DD_STRIDE * sizeof(unsigned long long)));
     if (e->eval_cache_log2 >= 3) {
         const size_t entries = (size_t)1 << e->eval_cache_log2;
         e->cache.key = e->cache_mem.alloc<unsigned long long>(entries);
@@ -293,6 +294,7 @@ EvalCache cache_for(az_engine* e, NetModel& net) {
     c = e->cache;
     c.max_stones = (uint32_t)e->eval_cache_max_stones;
     c.tag = (unsigned long long)net.cache_tag << 49;
+    if (!e->dedup_stats) c.stat = nullptr;
     return c;
 }
 // A tree arena for one call: a kept one of the same shape, or a new one (the oldest idle one makes room).
@@ -330,9 +332,11 @@ void acquire_trees(az_engine* e, TreeLease& lease, int G, uint64_t blocks, uint6
 // fold the device-side de-duplication counters into the engine stats (after a stream sync)
 void harvest_dedup(az_engine* e) {
     if (!e->cache.stat) return;
-    unsigned long long h[DD_COUNT];
-    HIPCHK(hipMemcpy(h, e->cache.stat, sizeof h, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(e->cache.stat, 0, sizeof h));
+    unsigned long long rep[DD_REPLICAS * DD_STRIDE], h[DD_COUNT] = {};
+    HIPCHK(hipMemcpy(rep, e->cache.stat, sizeof rep, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->cache.stat, 0, sizeof rep));
+    for (int r = 0; r < DD_REPLICAS; ++r)
+        for (int i = 0; i < DD_COUNT; ++i) h[i] += rep[r * DD_STRIDE + i];
     e->stats.leaf_rows_requested += h[DD_REQUESTED];
     e->stats.leaf_rows_executed += h[DD_EXECUTED];
     e->stats.eval_cache_hits += h[DD_CACHE_HITS];
@@ -534,6 +538,8 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = out;
         return AZ_OK;
     }
+    if (std::strcmp(key, "dedup_stats") == 0 && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }
+    if (std::strcmp(key, "tree_block4") == 0 && (value == 0 || value == 1)) { tree_set_block4((int)value); return AZ_OK; }
     if (std::strcmp(key, "profile_every") == 0 && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
     if (std::strcmp(key, "dedup_epoch_max") == 0 && value >= 3 && value <= 0x7FFF) { e->dedup_epoch_max = (int)value; return AZ_OK; }
     if (std::strcmp(key, "fused_search") == 0 && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
@@ -545,7 +551,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "ring_tile") == 0 && value >= 0 && value < 60000) { convnet_set_ring_tile((int)(value / 10000), (int)(value % 10000)); return AZ_OK; }
     if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv3_ring") == 0 && value >= 0 && value <= 2) { convnet_set_conv3_ring((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv3_pipe") == 0 && ((value >= 0 && value <= 3) || (value >= 10 && value <= 15))) { convnet_set_conv3_pipe((int)value); return AZ_OK; }
+    if (std::strcmp(key, "conv3_pipe") == 0 && ((value >= 0 && value <= 3) || (value >= 9 && value <= 15))) { convnet_set_conv3_pipe((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv2_table") == 0 && value >= 0 && value <= 2) { convnet_set_conv2_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv1_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv1_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {

@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
     AZ_PLDB(fbX, coffB0);
     AZ_PLDA(faX, 0, 0, 0);
     const int ncb = C / 64;
-    const int nk = ncb * 9;
+    const int nk = ABLATE == -2 ? 0 : ncb * 9;          // ABLATE -2: prologue + epilogue only
     int cb = 0, tap = 0, dt = 0;
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, t_begin = 0, r_begin = 0;
     if constexpr (STAMP) { t_begin = tprev = __builtin_amdgcn_s_memtime(); r_begin = __builtin_amdgcn_s_memrealtime(); }
@@ -1877,6 +1877,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
             case 2: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 0, false>), g3, b3, 0, s, d); break;
             case 3: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, true, 0, true>), g3, b3, 0, s, d); break;
             case 10: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, -1, true>), g3, b3, 0, s, d); break;
+            case 9: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, -2, true>), g3, b3, 0, s, d); break;
             case 11: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 1, true>), g3, b3, 0, s, d); break;
             case 12: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 2, true>), g3, b3, 0, s, d); break;
             case 13: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 3, true>), g3, b3, 0, s, d); break;

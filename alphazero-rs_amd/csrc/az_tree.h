@@ -105,9 +105,12 @@ struct EvalCache {
     uint32_t bmask;            // buckets - 1
     uint32_t max_stones;       // only states with at most this many stones are inserted
     unsigned long long tag;    // model tag, already shifted to bits 49..63
-    unsigned long long* stat;  // [DD_COUNT]
+    unsigned long long* stat;  // [DD_REPLICAS][DD_STRIDE]: every workgroup adds to replica blockIdx % DD_REPLICAS (its own 64-byte line)
 };
 enum DedupStat { DD_REQUESTED = 0, DD_EXECUTED, DD_CACHE_HITS, DD_BATCH_DUPS, DD_INSERTS, DD_COUNT };
+// One set of counters is one hot cache line for the ~1000 waves of a launch (their atomics serialise in one L2 channel: 5 % of the
+// bench); 256 replicas on lines of their own spread them over the channels, the host sums them once per call.
+constexpr int DD_REPLICAS = 256, DD_STRIDE = 8;
 
 struct SearchParams {
     uint32_t max_depth;
@@ -161,6 +164,7 @@ void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr 
 void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, const ulonglong2* root_states, hipStream_t s);
 void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s);
 // backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf requested in eb_next) in one launch
+void tree_set_block4(int v);
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s);
 // the whole search (root prepare + num_sims simulations + backups) in one launch for the device-function nets

@@ -226,11 +226,27 @@ AZ_D uint32_t leaf_request(const EvalBatch& eb, const EvalCache& ec, bool want, 
     }
     // rows of the batch: one atomicAdd per wave
     const unsigned long long wm = __ballot(take && sub == 0);
-    if (wm) {
+    uint32_t base = 0;
+    if (blockDim.x > 64) {
+        // four waves per workgroup (k_backup_select): ONE atomicAdd on the batch's row counter per workgroup -- the counter is a single
+        // hot address for the ~1000 waves of a launch.  Every wave of the workgroup gets here exactly once.
+        __shared__ uint32_t s_cnt[4], s_base;
+        const int w = (int)(threadIdx.x >> 6);
+        if (lane == 0) s_cnt[w] = (uint32_t)__popcll(wm);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            s_base = total ? atomicAdd(eb.n, total) : 0u;
+        }
+        __syncthreads();
+        base = s_base;
+        for (int i = 0; i < w; ++i) base += s_cnt[i];
+    } else if (wm) {
         const int leader = __ffsll((long long)wm) - 1;
-        uint32_t base = 0;
         if (lane == leader) base = atomicAdd(eb.n, (uint32_t)__popcll(wm));
         base = (uint32_t)__shfl((int)base, leader, 64);
+    }
+    if (wm) {
         if (take) {
             const int lane0 = lane & ~(GW - 1);
             const uint32_t row = base + (uint32_t)__popcll(wm & ((1ull << lane0) - 1ull));
@@ -244,10 +260,11 @@ AZ_D uint32_t leaf_request(const EvalBatch& eb, const EvalCache& ec, bool want, 
     if (ec.stat && eb.dedup) {
         const unsigned long long am = __ballot(want && sub == 0), hm = __ballot(hit && sub == 0), dm = __ballot(dup && want && sub == 0);
         if (am && lane == __ffsll((long long)am) - 1) {
-            atomicAdd(&ec.stat[DD_REQUESTED], (unsigned long long)__popcll(am));
-            if (wm) atomicAdd(&ec.stat[DD_EXECUTED], (unsigned long long)__popcll(wm));
-            if (hm) atomicAdd(&ec.stat[DD_CACHE_HITS], (unsigned long long)__popcll(hm));
-            if (dm) atomicAdd(&ec.stat[DD_BATCH_DUPS], (unsigned long long)__popcll(dm));
+            unsigned long long* st = ec.stat + (size_t)(blockIdx.x % DD_REPLICAS) * DD_STRIDE;
+            atomicAdd(&st[DD_REQUESTED], (unsigned long long)__popcll(am));
+            if (wm) atomicAdd(&st[DD_EXECUTED], (unsigned long long)__popcll(wm));
+            if (hm) atomicAdd(&st[DD_CACHE_HITS], (unsigned long long)__popcll(hm));
+            if (dm) atomicAdd(&st[DD_BATCH_DUPS], (unsigned long long)__popcll(dm));
         }
     }
     return src;
@@ -456,7 +473,8 @@ AZ_D void cache_claim_finish(const EvalCache& ec, CacheClaim c, float pv, int su
         }
     }
     const unsigned long long im = __ballot(inserted && sub == 0);
-    if (im && (int)(threadIdx.x & 63) == __ffsll((long long)im) - 1) atomicAdd(&ec.stat[DD_INSERTS], (unsigned long long)__popcll(im));
+    if (ec.stat && im && (int)(threadIdx.x & 63) == __ffsll((long long)im) - 1)
+        atomicAdd(&ec.stat[(size_t)(blockIdx.x % DD_REPLICAS) * DD_STRIDE + DD_INSERTS], (unsigned long long)__popcll(im));
 }
 
 // ---- mask/renormalise/store the prior (src/async_mcts.rs:317-353) + backup (:361-370) ----
@@ -613,10 +631,10 @@ __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCach
 // nothing else touches that tree in between.  The leaf of i+1 goes into the OTHER eval batch (eb_next; its count was
 // zeroed by the previous launch, this one zeroes eb_prev's), so the two ping-pong.
 template <class G>
-__global__ __launch_bounds__(64) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec,
-                                                      SearchParams sp, int apply_only) {
+__global__ __launch_bounds__(256) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec,
+                                                       SearchParams sp, int apply_only) {
     constexpr int GW = G::GROUP;
-    const int tid = blockIdx.x * 64 + threadIdx.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;      // 64 or 256 threads (256 only when every wave of the grid holds trees)
     const int g = tid / GW, sub = tid % GW;
     if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
     if (g >= t.G) return;
@@ -896,6 +914,8 @@ static_assert(game_ok<ConnectFour>() && game_ok<ConnectThree>(),
         else { using TG = ConnectFour; __VA_ARGS__; }               \
     } while (0)
 static inline int group_blocks(int G) { return (G * BLOCK_SLOTS + 63) / 64; }
+static int g_tree_block4 = 1;      // "tree_block4": k_backup_select as 4-wave workgroups (one row-counter atomic per workgroup), 0 = one wave per workgroup
+void tree_set_block4(int v) { g_tree_block4 = v; }
 
 void launch_init_heads(const TreeDev& t, hipStream_t s) {
     hipLaunchKernelGGL(k_init_heads, dim3((t.G + 255) / 256), dim3(256), 0, s, t);
@@ -914,7 +934,9 @@ void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, i
 }
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s) {
-    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_backup_select<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, apply_only));
+    const bool four = g_tree_block4 && (t.G * 8) % 256 == 0;     // whole 4-wave workgroups: one row-counter atomic per workgroup (leaf_request)
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_backup_select<TG>, dim3(four ? (unsigned)(t.G * 8 / 256) : group_blocks(t.G)), dim3(four ? 256 : 64), 0, s, t,
+                                            eb_prev, eb_next, ec, sp, apply_only));
 }
 void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind, uint64_t salt,
                            hipStream_t s) {
