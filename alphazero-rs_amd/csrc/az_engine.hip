@@ -540,6 +540,25 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     }
     if (std::strcmp(key, "dedup_stats") == 0 && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }
     if (std::strcmp(key, "tree_block4") == 0 && (value == 0 || value == 1)) { tree_set_block4((int)value); return AZ_OK; }
+    if (std::strcmp(key, "tree_stamps") == 0 && (value == 0 || value == 1)) { return tree_set_stamps((int)value) ? AZ_OK : fail(e, AZ_ERR_HIP, "tree_set_stamps"); }
+    if (std::strcmp(key, "print_tree_stamps") == 0) {
+        // diagnostic ("tree_stamps" = 1): cycles per phase of the last k_backup_select launch, median over its waves:
+        // load head+path | backup | wait for its stores | select | leaf request | store head+path | whole kernel
+        std::vector<unsigned long long> st(4096 * 8);
+        if (!tree_read_stamps(st.data())) return fail(e, AZ_ERR_BAD_ARGUMENT, "no stamps (set tree_stamps 1 and run a search first)");
+        std::string out;
+        for (int i = 0; i < 7; ++i) {
+            std::vector<unsigned long long> v;
+            for (int w = 0; w < 4096; ++w) if (st[(size_t)w * 8 + 6]) v.push_back(st[(size_t)w * 8 + i]);
+            if (v.empty()) return fail(e, AZ_ERR_BAD_ARGUMENT, "no stamps yet");
+            std::sort(v.begin(), v.end());
+            char buf[96];
+            std::snprintf(buf, sizeof buf, "%s%llu/%llu/%llu", i ? " " : "", v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10]);
+            out += buf;
+        }
+        e->err = out;
+        return AZ_OK;
+    }
     if (std::strcmp(key, "profile_every") == 0 && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
     if (std::strcmp(key, "dedup_epoch_max") == 0 && value >= 3 && value <= 0x7FFF) { e->dedup_epoch_max = (int)value; return AZ_OK; }
     if (std::strcmp(key, "fused_search") == 0 && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }

@@ -165,6 +165,8 @@ void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache&
 void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s);
 // backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf requested in eb_next) in one launch
 void tree_set_block4(int v);
+bool tree_set_stamps(int on);
+bool tree_read_stamps(unsigned long long* out /*[4096 * 8]*/);
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s);
 // the whole search (root prepare + num_sims simulations + backups) in one launch for the device-function nets

@@ -630,26 +630,43 @@ __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCach
 // backup of simulation i and select of simulation i+1 in one launch: both belong to the same 8 lanes of the same tree and
 // nothing else touches that tree in between.  The leaf of i+1 goes into the OTHER eval batch (eb_next; its count was
 // zeroed by the previous launch, this one zeroes eb_prev's), so the two ping-pong.
-template <class G>
+template <class G, bool STAMP = false>      // STAMP: diagnostic build, per-wave s_memtime stamps of the kernel's phases into dbg[wave][8]
 __global__ __launch_bounds__(256) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec,
-                                                       SearchParams sp, int apply_only) {
+                                                       SearchParams sp, int apply_only, unsigned long long* dbg) {
     constexpr int GW = G::GROUP;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;      // 64 or 256 threads (256 only when every wave of the grid holds trees)
     const int g = tid / GW, sub = tid % GW;
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
+#define AZ_TSTAMP(i_) if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[i_] = __builtin_amdgcn_s_memtime(); }
+    AZ_TSTAMP(0);
     if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     PathRegs pth = path_load(t, g, sub);
+    AZ_TSTAMP(1);
     backup_body<G>(t, h, pth, eb_prev, ec, apply_only, g, sub);
+    AZ_TSTAMP(2);
     // the counters this tree's other lanes just wrote are read by the selection below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    AZ_TSTAMP(3);
     const typename G::State leaf_s = select_body<G>(t, h, pth, sp, g, sub);
+    AZ_TSTAMP(4);
     const uint32_t src = leaf_request<G>(eb_next, ec, h.leaf_kind == LEAF_EVAL, leaf_s, sub);
+    AZ_TSTAMP(5);
     if (h.leaf_kind == LEAF_EVAL) h.src = src;
     if (sub == 0) head_store(t, g, h);
     path_store(t, g, sub, pth);
+    AZ_TSTAMP(6);
+#undef AZ_TSTAMP
+    if constexpr (STAMP) {
+        if (dbg && (threadIdx.x & 63) == 0 && h.active && h.leaf_kind == LEAF_EVAL) {      // a wave whose first tree searched and asked for a row
+            unsigned long long* o = dbg + (size_t)(tid >> 6) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = ts[i + 1] - ts[i];
+            o[6] = ts[6] - ts[0];
+        }
+    }
 }
 
 // ---- the whole get_action_prob search in ONE launch, for nets that are a pure function of the state on the device ----
@@ -916,6 +933,18 @@ static_assert(game_ok<ConnectFour>() && game_ok<ConnectThree>(),
 static inline int group_blocks(int G) { return (G * BLOCK_SLOTS + 63) / 64; }
 static int g_tree_block4 = 1;      // "tree_block4": k_backup_select as 4-wave workgroups (one row-counter atomic per workgroup), 0 = one wave per workgroup
 void tree_set_block4(int v) { g_tree_block4 = v; }
+// diagnostic: per-wave phase stamps of k_backup_select (tools/tree_probe.py)
+constexpr int TREE_DBG_WAVES = 4096;
+static unsigned long long* g_tree_dbg = nullptr;
+bool tree_set_stamps(int on) {
+    if (on && !g_tree_dbg) return hipMalloc((void**)&g_tree_dbg, (size_t)TREE_DBG_WAVES * 8 * sizeof(unsigned long long)) == hipSuccess &&
+                                  hipMemset(g_tree_dbg, 0, (size_t)TREE_DBG_WAVES * 8 * sizeof(unsigned long long)) == hipSuccess;
+    if (!on && g_tree_dbg) { (void)hipFree(g_tree_dbg); g_tree_dbg = nullptr; }
+    return true;
+}
+bool tree_read_stamps(unsigned long long* out /*[TREE_DBG_WAVES * 8]*/) {
+    return g_tree_dbg && hipMemcpy(out, g_tree_dbg, (size_t)TREE_DBG_WAVES * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+}
 
 void launch_init_heads(const TreeDev& t, hipStream_t s) {
     hipLaunchKernelGGL(k_init_heads, dim3((t.G + 255) / 256), dim3(256), 0, s, t);
@@ -935,8 +964,12 @@ void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, i
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s) {
     const bool four = g_tree_block4 && (t.G * 8) % 256 == 0;     // whole 4-wave workgroups: one row-counter atomic per workgroup (leaf_request)
-    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_backup_select<TG>, dim3(four ? (unsigned)(t.G * 8 / 256) : group_blocks(t.G)), dim3(four ? 256 : 64), 0, s, t,
-                                            eb_prev, eb_next, ec, sp, apply_only));
+    const dim3 grid(four ? (unsigned)(t.G * 8 / 256) : group_blocks(t.G)), block(four ? 256 : 64);
+    if (g_tree_dbg && t.G * 8 / 64 <= TREE_DBG_WAVES) {
+        AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, true>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, apply_only, g_tree_dbg));
+    } else {
+        AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, false>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, apply_only, nullptr));
+    }
 }
 void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind, uint64_t salt,
                            hipStream_t s) {
