@@ -339,3 +339,33 @@ def test_bench_scale_replay_parity_with_the_conv_net(engine, oracle):
     g = 17
     pi2, v2 = engine.predict_states(states[g, :256], 21)
     assert np.array_equal(pi2, pis[g, :256]) and np.array_equal(v2, vs[g, :256])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [256, 384])
+def test_other_channel_widths(oracle, channels):
+    """net_channels other than the two the suite lives on (3 column tiles of conv3 at 384; 4 / 6 table slices): one ragged call equals
+    the same rows in chunks, the table gather's two kernels agree bit for bit, the GEMM set stays within the table set's distance, and
+    the older kernels reproduce the GEMM set bit for bit."""
+    from alphazero_rs_amd import engine as azeng
+    e = azeng.Engine(device=0, max_batch=2048, net_channels=channels)
+    try:
+        e.net_init_random(0, seed=3)
+        st = random_states(oracle, 1201, seed=5)
+        ref = e.predict_states(st, 0)
+        parts = [e.predict_states(st[o:o + 250], 0) for o in range(0, 1201, 250)]
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), ref[0]) and np.array_equal(np.concatenate([p[1] for p in parts]), ref[1])
+        e.set_option("conv2_table", 2)
+        a = e.predict_states(st, 0)
+        assert np.array_equal(a[0], ref[0]) and np.array_equal(a[1], ref[1])
+        e.set_option("conv2_table", 0)
+        g = e.predict_states(st, 0)
+        assert np.abs(g[0] - ref[0]).max() <= 2e-4 and np.abs(g[1] - ref[1]).max() <= 1e-3
+        for key, val in (("conv3_pipe", 0), ("fc_ring", 0), ("gemm_variant", 0)):
+            e.set_option(key, val)
+            b = e.predict_states(st, 0)
+            assert np.array_equal(b[0], g[0]) and np.array_equal(b[1], g[1]), (key, val)
+    finally:
+        for key, val in (("gemm_variant", 5), ("fc_ring", 1), ("conv3_pipe", 1), ("conv2_table", 1)):
+            e.set_option(key, val)
+        e.close()
