@@ -570,6 +570,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "ring_tile") == 0 && value >= 0 && value < 60000) { convnet_set_ring_tile((int)(value / 10000), (int)(value % 10000)); return AZ_OK; }
     if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv3_ring") == 0 && value >= 0 && value <= 2) { convnet_set_conv3_ring((int)value); return AZ_OK; }
+    if (std::strcmp(key, "conv2_pipe") == 0 && (value == 0 || value == 1)) { convnet_set_conv2_pipe((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv3_pipe") == 0 && ((value >= 0 && value <= 3) || (value >= 9 && value <= 15))) { convnet_set_conv3_pipe((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv2_table") == 0 && value >= 0 && value <= 2) { convnet_set_conv2_table((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv1_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv1_table((int)value); return AZ_OK; }

@@ -68,6 +68,7 @@ void convnet_set_conv2_table(int v);
 void convnet_set_fc_ring(int v);
 void convnet_set_conv3_ring(int v);
 void convnet_set_conv3_pipe(int v);
+void convnet_set_conv2_pipe(int v);
 void convnet_set_ring_max_tiles(int v);
 void convnet_set_ring_tile(int layer, int tile);
 // diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop

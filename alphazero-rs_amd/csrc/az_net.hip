@@ -1165,6 +1165,202 @@ __global__ __launch_bounds__(256, 2) void k_conv_img2(const GemmDesc d) {
     }
 }
 
+// ---- k_conv_img2 with the LDS-DMA issued from inline asm and a software-pipelined K-step (conv2 as the MFMA GEMM, "conv2_table" = 0) --
+// Same tile, LDS layout, DMA maps and K order as k_conv_img2 (bit-identical).  What changes is what k_conv_valid_pipe changed for conv3:
+// the DMA is invisible to the compiler (its lgkmcnt waits are counted), fragment reads for the next cluster sit between this
+// cluster's MFMAs, and the step's first fragments are requested under the previous step's last cluster.  The two weight buffers
+// make ONE barrier per step enough: W(k+1) streams into the other buffer for the whole of step k (issued at its top), the barrier
+// behind cluster 3 says "W(k+1) has landed everywhere and nobody reads W(k) any more".
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr);
+template <int LAYER, bool TABLE = false>
+__global__ __launch_bounds__(256, 2) void k_conv_same_pipe(const GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32768];   // img | w[2] (16 KiB each)
+    const int n_boards = (int)(*d.n_dev);
+    const int M = n_boards * 42;
+    const int C = d.cin;
+    const int NT = d.N / HBN2_;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * IMG_NB, n0 = ntile * HBN2_;
+    if (b0 >= n_boards) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    if (tid < 8) *(uint4*)(smem + IMG_ZERO_ROW * 128 + tid * 16) = make_uint4(0, 0, 0, 0);
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    uint32_t i_ob[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int r = (q * 4 + wave) * 8 + lrow;
+        r = r < IMG_ROWS ? r : IMG_ROWS - 1;
+        int b = b0 + r / 42;
+        b = b < n_boards ? b : n_boards - 1;
+        const int p = r % 42, y = p / 7, x = p - y * 7;
+        if constexpr (TABLE) {
+            const ulonglong2 st = d.states[b];
+            i_ob[q] = (conv1_pattern(st.x, st.y, y, x) * (uint32_t)C + (uint32_t)chunk * 8u) * 2u;
+        } else {
+            i_ob[q] = (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8) * 2u;
+        }
+    }
+    const bool i_last_ok = (7 * 4 + wave) * 8 + lrow < IMG_ROWS;          // only piece 7 can run past row 251
+    const uint32_t w_ob = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
+    const size_t w_stride = (size_t)64 * d.K;                              // 32 weight rows, in bytes
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uint32_t lds_img = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
+    const uint32_t lds_w = (uint32_t)(uintptr_t)(lds_ptr)(smem + 32768 + wave * 1024);
+#define AZ_CDMA_W(kk_, buf_)                                                                                 \
+    {                                                                                                        \
+        const char* wbase = (const char*)(d.W + (kk_));                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) lds_dma16(wbase + q_ * w_stride, w_ob, lds_w + (buf_) * 16384 + q_ * 4096); \
+    }
+#define AZ_CDMA_IMG(cb_)                                                                                     \
+    {                                                                                                        \
+        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_) lds_dma16(ibase, i_ob[q_], lds_img + q_ * 4096);    \
+        if (i_last_ok) lds_dma16(ibase, i_ob[7], lds_img + 7 * 4096);                                        \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    uint32_t rowmask[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int ml = wr * 128 + mt * 16 + frow;
+        const int p = ml % 42, y = p / 7, x = p - y * 7;
+        uint32_t mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            if (ml < IMG_ROWS && iy >= 0 && iy < 6 && ix >= 0 && ix < 7) mask |= 1u << t;
+        }
+        rowmask[mt] = (uint32_t)ml | (mask << 16);
+    }
+    const int b_row0 = 32768 + (wc * 64 + frow) * 128;
+    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
+    // tap_: 0..8, its image-row offset dtv_ = (ky-1)*7 + (kx-1)
+#define AZ_CLDA(dst_, mt0_, ks_, tap_, dtv_)                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+        const uint32_t rm_ = rowmask[(mt0_) + i_];                                                           \
+        const int r_ = ((rm_ >> (16 + (tap_))) & 1u) ? (int)(rm_ & 0xFFFFu) + (dtv_) : IMG_ZERO_ROW;         \
+        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
+    }
+#define AZ_CLDB(dst_, buf_, coff_)                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        dst_[i_] = *(const bf16x8*)(smem + (buf_) * 16384 + b_row0 + i_ * 2048 + (coff_));
+#define AZ_CMMA(mt0_, fb_, fa_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+#define AZ_CSB __builtin_amdgcn_sched_barrier(0)
+#define AZ_CMIX(nmf_, rep_, tail_)                                                                           \
+    {                                                                                                        \
+        _Pragma("unroll") for (int g_ = 0; g_ < (rep_); ++g_) {                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, (nmf_), 0);                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+        }                                                                                                    \
+        if ((tail_) > 0) __builtin_amdgcn_sched_group_barrier(0x008, (tail_), 0);                            \
+    }
+    const int ncb = C / 64;
+    const int nk = ncb * 9;
+    AZ_CDMA_W(0, 0);
+    AZ_CDMA_IMG(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 fbX[4], fbY[4], faX[4], faY[4];
+    AZ_CLDB(fbX, 0, coffB0);
+    AZ_CLDA(faX, 0, 0, 0, -8);
+    int cb = 0, tap = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool sw = tap == 8;
+        const int ntap = sw ? 0 : tap + 1, ncbi = sw ? cb + 1 : cb;
+        const int ky = tap / 3, dt = (ky - 1) * 7 + (tap - ky * 3 - 1);
+        const int nky = ntap / 3, ndt = (nky - 1) * 7 + (ntap - nky * 3 - 1);
+        const int buf = kt & 1;
+        const int kk = kt + 1 < nk ? ntap * C + ncbi * 64 : 8 * C + cb * 64;      // last step: re-fetch its own tile (unused)
+        AZ_CDMA_W(kk, buf ^ 1);                                  // the other buffer: nobody has read it since the last barrier
+        AZ_CLDB(fbY, buf, coffB1);
+        AZ_CLDA(faY, 4, 0, tap, dt);
+        AZ_CMMA(0, fbX, faX);
+        AZ_CMIX(1, 8, 8);
+        AZ_CSB;
+        AZ_CLDA(faX, 0, 1, tap, dt);
+        AZ_CMMA(4, fbX, faY);
+        AZ_CMIX(2, 4, 8);
+        AZ_CSB;
+        AZ_CLDA(faY, 4, 1, tap, dt);
+        AZ_CMMA(0, fbY, faX);
+        AZ_CMIX(2, 4, 8);
+        AZ_CSB;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // my reads of W(k) and of this step's image rows are done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // W(k+1) has landed
+        __builtin_amdgcn_s_barrier();
+        AZ_CSB;
+        if (sw && ncbi < ncb) {                                  // single image buffer: the switch is covered by the CU's other workgroup
+            AZ_CDMA_IMG(ncbi);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        AZ_CSB;
+        AZ_CLDB(fbX, buf ^ 1, coffB0);                           // next step's first fragments, under this step's last cluster
+        AZ_CLDA(faX, 0, 0, ntap, ndt);
+        AZ_CMMA(4, fbY, faY);
+        AZ_CMIX(1, 8, 8);
+        AZ_CSB;
+        tap = ntap; cb = ncbi;
+    }
+#undef AZ_CDMA_W
+#undef AZ_CDMA_IMG
+#undef AZ_CLDA
+#undef AZ_CLDB
+#undef AZ_CMMA
+#undef AZ_CSB
+#undef AZ_CMIX
+    // epilogue through LDS in two halves of 128 rows (the buffers are dead; [128][128] bf16 with a 272-byte row stride = 34 KiB):
+    // whole 256-byte row segments, 16 bytes per lane, instead of 8-byte stores in 32-byte pieces of 16 different rows
+    constexpr int EP_STRIDE = 272;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wr == half) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int nl = wc * 64 + nt * 16 + fq * 4;
+                const float4 bv = *(const float4*)(d.bias + n0 + nl);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int rl = mt * 16 + frow;                       // row inside the half
+                    float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                          r3 = acc[mt][nt][3] + bv.w;
+                    if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+                    uint2 o;
+                    o.x = pack_bf16x2(r0, r1);
+                    o.y = pack_bf16x2(r2, r3);
+                    *(uint2*)(smem + rl * EP_STRIDE + nl * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 128 * 16 / 256; ++it) {
+            const int idx = it * 256 + tid;
+            const int rl = idx >> 4, c = idx & 15;
+            const int ml = half * 128 + rl;
+            const int m = b0 * 42 + ml;
+            if (ml >= IMG_ROWS || m >= M) continue;
+            *(uint4*)(d.out + (size_t)m * d.N + n0 + c * 8) = *(const uint4*)(smem + rl * EP_STRIDE + c * 16);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- 'valid' 3x3 convs (conv3: [6][7][C] -> [4][5][C], conv4: [4][5][C] -> [2][3][C]) image-resident, two 4-wave
 // workgroups per CU ---------------------------------------------------------------------------------------------------
 // The lockstep argument of k_conv_img2 for the 'valid' convs.  Tile = NB boards (NB*OH*OW output rows, padded to 128 or
@@ -1835,11 +2031,13 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants
                           // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
                           // split, cross-step fragment prefetch, weights straight into registers.
 int g_conv3_ring = 0;
+int g_conv2_pipe = 1;       // conv2 as a GEMM ("conv2_table" = 0): 1 k_conv_same_pipe, 0 k_conv_img2 (round 1); bit-identical ("conv2_pipe")
 int g_conv3_pipe = 1;       // conv3: 1 (default) k_conv_valid_pipe, fragment reads interleaved into the MFMA clusters; 2 the same without the interleave;
                             // 0 k_conv_valid_img2 (round 1); all bit-identical.  3: 1 with per-segment clock stamps (tools/seg_probe.py); 11-15: the
                             // timing ladder of 1 (WRONG results): no image switch, + no wait for the weight DMA, + no weight DMA, + no barriers, + no fragment reads
 void convnet_set_conv3_ring(int v) { g_conv3_ring = v; }
 void convnet_set_conv3_pipe(int v) { g_conv3_pipe = v; }
+void convnet_set_conv2_pipe(int v) { g_conv2_pipe = v; }
 int g_fc_ring = 1;        // 128x128 LDS-DMA ring kernel for under-filled grids (az_set_option "fc_ring"); bit-identical
 int g_ring64_max_tiles = 512;   // ... 64-row tiles for the FCs when twice the 128-row tile count is at most this ("fc_ring" = 3: never)
 int g_ring_max_tiles = 256;   // ... when the layer has at most this many tiles ("ring_max_tiles")
@@ -1854,7 +2052,9 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     if ((v == 3 || v == 5) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
         const int t8 = (tiles + 7) / 8 * 8;
-        if (v == 5 && d.states) hipLaunchKernelGGL((k_conv_img2<LAYER, true>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+        if (v == 5 && g_conv2_pipe && d.states) hipLaunchKernelGGL((k_conv_same_pipe<LAYER, true>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+        else if (v == 5 && g_conv2_pipe) hipLaunchKernelGGL((k_conv_same_pipe<LAYER>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+        else if (v == 5 && d.states) hipLaunchKernelGGL((k_conv_img2<LAYER, true>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
         else if (v == 5) hipLaunchKernelGGL((k_conv_img2<LAYER>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
         return;

@@ -349,7 +349,7 @@ def main():
                                        "note": "achieved counts the table rows gathered + activation rows written per launch; above the HBM peak means cache hits"}
             else:
                 ach = st["net_conv2_flops"] / (st["net_conv2_ms"] * 1e-3) / 1e12
-                traffic, src = pmc_traffic("k_conv_img2<1", st["net_conv2_flops"], 2.0 * 42 * 512 * 4608)
+                traffic, src = pmc_traffic("k_conv_same_pipe<1", st["net_conv2_flops"], 2.0 * 42 * 512 * 4608)
                 roof = {"bound": "mfma", "kernel": "k_conv_img2<1, true> (conv2: 3x3 same, 512->512, image-resident implicit GEMM on MFMA, two 4-wave "
                                                    "workgroups per CU, input image gathered from the conv1 pattern table)",
                         "achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -442,7 +442,7 @@ def main():
                                       "conv2_tflops": sa["net_conv2_flops"] / (sa["net_conv2_ms"] * 1e-3) / 1e12 if sa["net_conv2_ms"] else None,
                                       "conv2_frac_of_mfma_peak": sa["net_conv2_flops"] / (sa["net_conv2_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if sa["net_conv2_ms"] else None,
                                       "conv2_avg_launch_ms": sa["net_conv2_ms"] / max(1, sa["net_launches"]),
-                                      "note": "one episode batch of --games episodes (no refill), conv2_table = 0: k_conv_img2<1,true> on the matrix cores"}
+                                      "note": "one episode batch of --games episodes (no refill), conv2_table = 0: k_conv_same_pipe<1,true> on the matrix cores"}
             except Exception as ex:
                 line["mfma_conv2"] = {"error": repr(ex)}
             finally:

@@ -98,7 +98,7 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
         conv_engine.set_option("conv4_big", 0)
         ring_tiles = tuple(layer * 10000 + t for layer in (3, 4, 5) for t in (642, 644, 962, 964, 1282, 1284, 1602, 1922)) + (30000, 40000, 50000)
         for key, vals in (("fc_ring", (0, 2, 3, 1)), ("conv3_ring", (1, 2, 0)), ("conv1_table", (0, 1)),   # the LDS-DMA ring GEMM on fc1 /
-                          ("conv3_pipe", (0, 2, 3, 1)), ("ring_tile", ring_tiles)):   # fc2 / conv4 / conv3, conv1 as a kernel, the conv3 kernels, every ring tile
+                          ("conv3_pipe", (0, 2, 3, 1)), ("conv2_pipe", (0, 1)), ("ring_tile", ring_tiles)):   # fc2 / conv4 / conv3, conv1 as a kernel, the conv3 kernels, every ring tile
             for val in vals:
                 conv_engine.set_option(key, val)
                 pi, v = conv_engine.predict_states(states, 5)
@@ -110,6 +110,7 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
         conv_engine.set_option("conv4_big", 0)
         conv_engine.set_option("conv2_table", 1)
         conv_engine.set_option("conv3_pipe", 1)
+        conv_engine.set_option("conv2_pipe", 1)
         for layer in (3, 4, 5):
             conv_engine.set_option("ring_tile", layer * 10000)
         conv_engine.set_option("fc_ring", 1)
