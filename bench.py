@@ -350,7 +350,7 @@ def main():
             else:
                 ach = st["net_conv2_flops"] / (st["net_conv2_ms"] * 1e-3) / 1e12
                 traffic, src = pmc_traffic("k_conv_same_pipe<1", st["net_conv2_flops"], 2.0 * 42 * 512 * 4608)
-                roof = {"bound": "mfma", "kernel": "k_conv_img2<1, true> (conv2: 3x3 same, 512->512, image-resident implicit GEMM on MFMA, two 4-wave "
+                roof = {"bound": "mfma", "kernel": "k_conv_same_pipe<1, true> (conv2: 3x3 same, 512->512, image-resident implicit GEMM on MFMA, two 4-wave "
                                                    "workgroups per CU, input image gathered from the conv1 pattern table)",
                         "achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{src})",
