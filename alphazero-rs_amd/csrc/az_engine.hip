@@ -569,7 +569,8 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (std::strcmp(key, "fc_ring") == 0 && value >= 0 && value <= 3) { convnet_set_fc_ring((int)value); return AZ_OK; }
     if (std::strcmp(key, "ring_tile") == 0 && value >= 0 && value < 60000) { convnet_set_ring_tile((int)(value / 10000), (int)(value % 10000)); return AZ_OK; }
     if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv3_ring") == 0 && value >= 0 && value <= 2) { convnet_set_conv3_ring((int)value); return AZ_OK; }
+    if (std::strcmp(key, "conv3_small") == 0 && (value == 0 || value == 1)) { convnet_set_conv3_small((int)value); return AZ_OK; }
+    if (std::strcmp(key, "conv3_ring") == 0 && value >= 0 && value <= 3) { convnet_set_conv3_ring((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv2_pipe") == 0 && (value == 0 || value == 1)) { convnet_set_conv2_pipe((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv3_pipe") == 0 && ((value >= 0 && value <= 3) || (value >= 9 && value <= 15))) { convnet_set_conv3_pipe((int)value); return AZ_OK; }
     if (std::strcmp(key, "conv2_table") == 0 && value >= 0 && value <= 2) { convnet_set_conv2_table((int)value); return AZ_OK; }
@@ -1207,13 +1208,14 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         ad.player = mem.alloc<int8_t>(G);
         ad.alive = mem.alloc<uint8_t>(G);
         ad.results = mem.alloc<int8_t>(G);
-        ad.counters = mem.alloc<uint32_t>(2);
+        ad.counters = mem.alloc<uint32_t>(4);          // [2], [3]: the largest leaf batch of the ply, per model (tile / kernel choice of the next ply)
         HIPCHK(hipMemset(ad.state, 0, (size_t)G * 16));
         HIPCHK(hipMemset(ad.player, 1, G));
         HIPCHK(hipMemset(ad.alive, 1, G));
         HIPCHK(hipMemset(ad.results, 0, G));
-        uint32_t ctr[2] = {(uint32_t)G, 0u};
+        uint32_t ctr[4] = {(uint32_t)G, 0u, 0u, 0u};
         HIPCHK(hipMemcpy(ad.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
+        int typ_new = 0, typ_old = 0;                   // expected rows per leaf batch (0 = unknown: assume every running game)
         launch_reset_trees(tn.d, nullptr, s);
         launch_reset_trees(to.d, nullptr, s);
         if (!e->eval_cache_persist) clear_cache(e, s);
@@ -1239,19 +1241,22 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
             if (overlap) {
                 HIPCHK(hipEventRecord(side.fork, s));
                 HIPCHK(hipStreamWaitEvent(side.s2, side.fork, 0));
-                run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0], side.s2);
-                run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0], s);
+                run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0], side.s2, typ_old, ad.counters + 3);
+                run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0], s, typ_new, ad.counters + 2);
                 HIPCHK(hipEventRecord(side.join, side.s2));
                 HIPCHK(hipStreamWaitEvent(s, side.join, 0));
             } else {
-                run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0]);
-                run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0]);
+                run_search(e, tn, ad.state, p->num_sims, sp, *net_new, (int)ctr[0], nullptr, typ_new, ad.counters + 2);
+                run_search(e, to, ad.state, p->num_sims, sp, *net_old, (int)ctr[0], nullptr, typ_old, ad.counters + 3);
             }
             launch_arena_move(tn.d, ad, p->seed, s);
             launch_arena_move(to.d, ad, p->seed, s);
             HIPCHK(hipMemcpyAsync(ctr, ad.counters, sizeof ctr, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             resolve_profile(e);
+            typ_new = (int)std::min<uint32_t>(ctr[2], (uint32_t)G);
+            typ_old = (int)std::min<uint32_t>(ctr[3], (uint32_t)G);
+            HIPCHK(hipMemsetAsync(ad.counters + 2, 0, 2 * sizeof(uint32_t), s));
             if (ctr[1]) { result = fail(e, AZ_ERR_INVALID_MOVE, "arena: action is not valid (src/arena.rs:31-35)"); break; }
             if (ctr[0] == 0) break;
         }

@@ -67,6 +67,7 @@ void convnet_set_conv1_table(int v);
 void convnet_set_conv2_table(int v);
 void convnet_set_fc_ring(int v);
 void convnet_set_conv3_ring(int v);
+void convnet_set_conv3_small(int v);
 void convnet_set_conv3_pipe(int v);
 void convnet_set_conv2_pipe(int v);
 void convnet_set_ring_max_tiles(int v);

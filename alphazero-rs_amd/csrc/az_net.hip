@@ -2031,11 +2031,13 @@ int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants
                           // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
                           // split, cross-step fragment prefetch, weights straight into registers.
 int g_conv3_ring = 0;
+int g_conv3_small = 1;      // "conv3_small": conv3 of a small expected batch on the 4-stage ring (see launch_gemm); bit-identical
 int g_conv2_pipe = 1;       // conv2 as a GEMM ("conv2_table" = 0): 1 k_conv_same_pipe, 0 k_conv_img2 (round 1); bit-identical ("conv2_pipe")
 int g_conv3_pipe = 1;       // conv3: 1 (default) k_conv_valid_pipe, fragment reads interleaved into the MFMA clusters; 2 the same without the interleave;
                             // 0 k_conv_valid_img2 (round 1); all bit-identical.  3: 1 with per-segment clock stamps (tools/seg_probe.py); 11-15: the
                             // timing ladder of 1 (WRONG results): no image switch, + no wait for the weight DMA, + no weight DMA, + no barriers, + no fragment reads
 void convnet_set_conv3_ring(int v) { g_conv3_ring = v; }
+void convnet_set_conv3_small(int v) { g_conv3_small = v; }
 void convnet_set_conv3_pipe(int v) { g_conv3_pipe = v; }
 void convnet_set_conv2_pipe(int v) { g_conv2_pipe = v; }
 int g_fc_ring = 1;        // 128x128 LDS-DMA ring kernel for under-filled grids (az_set_option "fc_ring"); bit-identical
@@ -2061,10 +2063,17 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     }
     const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && !g_ring_tile[3] && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_typ >= 4096)))) &&
                      d.N % HBN_ == 0;
-    if constexpr (LAYER == 2) if (v == 5 && g_conv3_ring) {      // experiment: conv3 on the 128x128 LDS-DMA ring (im2col from act2)
+    // Small batches (the arena, the drain of a self-play call, single-tree calls): the image-resident kernel is a chain of 72 K-steps of
+    // ~0.8 us for a workgroup alone on its CU (70 us whatever the rows); the ring with 4 stages in flight walks the same K in ~32 us up to
+    // 128 rows and 49 us at 384 (tools/rows_sweep.py, OPT=conv3_ring=3).  Taken when the expected rows fit one workgroup per CU.
+    const bool small3 = LAYER == 2 && g_conv3_small && !g_conv3_ring && rows_typ > 0 && (long long)rows_typ * 115 / 100 * d.rows_per_sample <= 8192;
+    if constexpr (LAYER == 2) if (v == 5 && (g_conv3_ring || small3)) {      // conv3 on the LDS-DMA ring (im2col from act2): 1 / 2 = 128-row tiles with 2 / 4 stages, 3 = device-picked tile, 4 stages
         const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
         const int mt8 = (mt + 7) / 8 * 8;
-        if (g_conv3_ring == 2) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
+        if (g_conv3_ring == 3 || small3) {
+            const int mtb = ((rows_hint * d.rows_per_sample + 63) / 64 + 7) / 8 * 8;
+            hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 4>), dim3(mtb * (d.N / GBN)), dim3(256), 0, s, d);
+        } else if (g_conv3_ring == 2) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
         return;
     }
