@@ -119,7 +119,10 @@ const char* az_last_error(const az_engine* e);
  * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 (default: conv4 on the ring kernel) / 1 (256x256 kernel) / 2 (256x256 from
  * 4096 rows). "conv3_pipe" = 1 (default: conv3 with the LDS-DMA issued from inline asm and a software-pipelined K-step) / 2 (the same
  * without interleaving the fragment reads into the MFMA clusters) / 0 (round 1's kernel) / 3 (1 + clock stamps), all bit-identical;
- * 11-15 = its timing ladder (WRONG results). "ring_tile" = layer * 10000 + rows * 10 + stages forces one ring tile for layer 3 (conv4) /
+ * 9-15 = its timing ladder (WRONG results). "conv3_small" = 1 (default): conv3 of a small expected batch (at most 356 rows) runs on the
+ * 4-stage LDS-DMA ring (half the latency of the image-resident kernel there), 0 = never; "conv3_ring" = 1 / 2 / 3 forces conv3 onto the
+ * ring (128-row tiles with 2 / 4 stages, device-picked tile); bit-identical. "conv2_pipe" = 1 (default) / 0: the conv2 GEMM kernel
+ * ("conv2_table" = 0) with / without this round's pipeline; bit-identical. "ring_tile" = layer * 10000 + rows * 10 + stages forces one ring tile for layer 3 (conv4) /
  * 4 (fc1) / 5 (fc2), layer * 10000 = automatic again; bit-identical. "profile_every" = n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and tree_ms
  * sums then cover that sample of launches; every bracket costs a little GPU idle time between dependent kernels). "fused_search" = 1
  * (default): the stub / hash nets run a whole search in one launch, 0 = one launch per simulation like the conv net. "fc_ring" = 1

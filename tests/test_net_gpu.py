@@ -103,6 +103,13 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
                 conv_engine.set_option(key, val)
                 pi, v = conv_engine.predict_states(states, 5)
                 assert np.array_equal(pi, outs[0][0]) and np.array_equal(v, outs[0][1]), (key, val)
+        small = states[:100]                                  # a small expected batch: conv3 on the 4-stage ring ("conv3_small"), bit-identical too
+        ref_small = conv_engine.predict_states(small, 5)
+        assert np.array_equal(ref_small[0], outs[0][0][:100]) and np.array_equal(ref_small[1], outs[0][1][:100])
+        for key, val in (("conv3_small", 0), ("conv3_ring", 3), ("conv3_ring", 0), ("conv3_small", 1)):
+            conv_engine.set_option(key, val)
+            pi, v = conv_engine.predict_states(small, 5)
+            assert np.array_equal(pi, ref_small[0]) and np.array_equal(v, ref_small[1]), (key, val)
         with pytest.raises(Exception):
             conv_engine.set_option("gemm_variant", 4)         # removed variants are refused, not silently mapped
     finally:
