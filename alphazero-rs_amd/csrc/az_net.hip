@@ -2066,7 +2066,8 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     // Small batches (the arena, the drain of a self-play call, single-tree calls): the image-resident kernel is a chain of 72 K-steps of
     // ~0.8 us for a workgroup alone on its CU (70 us whatever the rows); the ring with 4 stages in flight walks the same K in ~32 us up to
     // 128 rows and 49 us at 384 (tools/rows_sweep.py, OPT=conv3_ring=3).  Taken when the expected rows fit one workgroup per CU.
-    const bool small3 = LAYER == 2 && g_conv3_small && !g_conv3_ring && rows_typ > 0 && (long long)rows_typ * 115 / 100 * d.rows_per_sample <= 8192;
+    const bool small3 = LAYER == 2 && g_conv3_small && !g_conv3_ring &&
+                        (rows_typ > 0 ? (long long)rows_typ * 115 / 100 : (long long)rows_hint) * d.rows_per_sample <= 8192;      // no estimate: the bound itself
     if constexpr (LAYER == 2) if (v == 5 && (g_conv3_ring || small3)) {      // conv3 on the LDS-DMA ring (im2col from act2): 1 / 2 = 128-row tiles with 2 / 4 stages, 3 = device-picked tile, 4 stages
         const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
         const int mt8 = (mt + 7) / 8 * 8;
