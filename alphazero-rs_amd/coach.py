@@ -42,8 +42,9 @@ class Coach:
         self = object.__new__(cls)
         if num_sims % inference_batch_size != 0:                      # assert!, src/coach.rs:83
             raise ValueError("num_sims % inference_batch_size != 0")
-        if num_sim_threads != 1:
-            raise ValueError("the engine runs one simulation per tree at a time (num_sim_threads = 1)")
+        if num_sim_threads < 1 or num_sims % num_sim_threads != 0:    # assert!, src/async_mcts.rs:192
+            raise ValueError("num_sims % num_sim_threads != 0")
+        self.num_sim_threads = num_sim_threads    # > 1: several simulations in flight per tree (the engine's lock-step schedule)
         self.engine, self.trainer, self.group, self.log = engine, trainer, group, log
         self.dir = str(checkpoint_directory)
         self.mcts_reserve_size, self.update_threshold, self.temp_threshold = mcts_reserve_size, update_threshold, temp_threshold
@@ -91,7 +92,8 @@ class Coach:
             r = self.engine.selfplay(n_games=hi - lo, num_sims=self.num_sims, model_id=model_id, seed=seed,
                                      first_game_id=first + lo, concurrent=min(self.num_episode_threads, hi - lo),
                                      temp_threshold=self.temp_threshold, max_depth=self.max_depth, cpuct=self.cpuct,
-                                     reserve=self.mcts_reserve_size, symmetries=False, want_boards=False)
+                                     reserve=self.mcts_reserve_size, symmetries=False, want_boards=False,
+                                     num_sim_threads=self.num_sim_threads)
             states, pis, zs = r["states"], r["pis"], r["zs"]
         else:
             states, pis, zs = np.zeros((0, 2), np.uint64), np.zeros((0, 7), np.float32), np.zeros(0, np.float32)
@@ -175,7 +177,8 @@ class Coach:
                 if hi > lo:
                     wld, _ = self.engine.arena(hi - lo, self.num_sims, new_model_id=model_id + 1, old_model_id=model_id,
                                                seed=a_seed, max_depth=self.max_depth, cpuct=self.cpuct,
-                                               reserve=self.mcts_reserve_size, first_game=lo, total_games=total)
+                                               reserve=self.mcts_reserve_size, first_game=lo, total_games=total,
+                                               num_sim_threads=self.num_sim_threads)
                 dev = torch.device("cuda", torch.cuda.current_device()) if tdist.get_backend(self.group) == "nccl" else torch.device("cpu")
                 t = torch.tensor([int(x) for x in wld], dtype=torch.int64, device=dev)
                 tdist.all_reduce(t, group=self.group)
@@ -183,7 +186,7 @@ class Coach:
             else:
                 wld, _ = self.engine.arena(self.num_arena_games, self.num_sims, new_model_id=model_id + 1, old_model_id=model_id,
                                            seed=a_seed, max_depth=self.max_depth, cpuct=self.cpuct,
-                                           reserve=self.mcts_reserve_size)
+                                           reserve=self.mcts_reserve_size, num_sim_threads=self.num_sim_threads)
             t_arena = time.perf_counter() - t0
             nwins, pwins, draws = int(wld[0]), int(wld[1]), int(wld[2])
             self.log(f"NEW/PREV WINS : {nwins} / {pwins}; DRAWS : {draws}")            # :381

@@ -18,11 +18,14 @@ constexpr int PATH_CAP = 48;          // node_path entries per simulation (a Con
 
 // ---- node meta word (the record itself: az_tree.h) ----------------------------
 // bits 0-2 a (src/node.rs:19) | 3-5 nchild | 6 expanded (mu.s is Some) | 7-8 ecode (e, src/node.rs:20) | 9 has_prior (mu.p is Some)
+// | 10 locked (the slot's AtomicBool, src/node.rs:130, :328-341: set from the upgrade of a placeholder until its prior is stored;
+//   only ever observed with several simulations in flight per tree)
 constexpr uint32_t META_A_MASK = 7u;
 constexpr uint32_t META_NCHILD_SHIFT = 3;
 constexpr uint32_t META_EXPANDED = 1u << 6;
 constexpr uint32_t META_ECODE_SHIFT = 7;
 constexpr uint32_t META_HAS_PRIOR = 1u << 9;
+constexpr uint32_t META_LOCKED = 1u << 10;
 
 // ecode <-> e (C9: e = -get_game_ended(1) of the canonical state)
 constexpr uint32_t E_NONE = 0, E_PLUS1 = 1, E_MINUS1 = 2, E_DRAW = 3;

@@ -4,6 +4,9 @@
 // There is NO CPU fallback: every entry point runs the HIP kernels or fails with a status.
 #include "../../include/az_engine.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is dlopen'ed by az_comm_* (a host that never shards never loads it)
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -79,6 +82,69 @@ struct Profiler {
     ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
 
+// RCCL entry points, resolved at the first az_comm_* call.  Not a link-time dependency: a process that also hosts another copy
+// of RCCL (PyTorch bundles one) must not have two sets of ncclXxx symbols bound into one namespace.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string* why) {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { *why = std::string("cannot load librccl: ") + dlerror(); return false; }
+        bool ok = true;
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) { ok = false; *why = std::string("librccl lacks ") + n; } return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { dlclose(lib); lib = nullptr; }
+        return ok;
+    }
+};
+Rccl g_rccl;      // function table only (no per-engine state)
+
+// (s, pi, z) as one 48-byte tuple: the unit of the episode-batch gather (symmetries are regenerated at the destination)
+struct PackedSample { unsigned long long s0, s1; float pi[7]; float z; };
+static_assert(sizeof(PackedSample) == 48, "48-byte tuples");
+__global__ void k_pack_samples(const ulonglong2* st, const float* pi, const float* z, PackedSample* out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PackedSample p;
+    const ulonglong2 s = st[i];
+    p.s0 = s.x; p.s1 = s.y;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) p.pi[a] = pi[i * 7 + a];
+    p.z = z[i];
+    out[i] = p;
+}
+__global__ void k_unpack_samples(const PackedSample* in, ulonglong2* st, float* pi, float* z, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PackedSample p = in[i];
+    st[i] = make_ulonglong2(p.s0, p.s1);
+#pragma unroll
+    for (int a = 0; a < 7; ++a) pi[i * 7 + a] = p.pi[a];
+    z[i] = p.z;
+}
+
 inline uint32_t next_pow2_u32(uint64_t x) {
     uint64_t p = 1;
     while (p < x) p <<= 1;
@@ -96,47 +162,52 @@ struct TreeHost {
     // blocks = child blocks the trees can use (each holds the <= 7 children of one expansion, or a root);
     // reserve_nodes = reserve_space (src/node.rs:146) clamped to what is reachable
     // allocation key (the engine keeps finished calls' arenas for the next call of the same shape)
-    int k_G = 0, k_log = 0; uint64_t k_blocks = 0; uint32_t k_H = 0;
+    int k_G = 0, k_T = 1; uint64_t k_blocks = 0; uint32_t k_H = 0;
     bool in_use = false;
-    bool fits(int G, uint64_t blocks, uint32_t H, int log_cap) const { return G == k_G && blocks == k_blocks && H == k_H && log_cap == k_log; }
+    bool fits(int G, uint64_t blocks, uint32_t H, int T) const { return G == k_G && blocks == k_blocks && H == k_H && T == k_T; }
     // make a kept arena look freshly created (the trees themselves are rebuilt by launch_reset_trees)
     void recycle(uint64_t reserve_nodes, hipStream_t s) {
         d.reserve_nodes = (uint32_t)reserve_nodes;
         HIPCHK(hipMemsetAsync(d.err, 0, ERR_COUNT * sizeof(uint32_t), s));
-        HIPCHK(hipMemsetAsync(d_totals, 0, ST_COUNT * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(d_totals, 0, ST_TOTALS * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(eb.n, 0, sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(eb2.n, 0, sizeof(uint32_t), s));
+        if (d.thr) HIPCHK(hipMemsetAsync(d.thr, 0, (size_t)d.G * d.T * sizeof(TreeLine), s));
         launch_init_heads(d, s);
     }
-    void create(int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int log_cap, int game) {
-        k_G = G; k_blocks = blocks; k_H = H; k_log = log_cap;
+    // T = simulations in flight per tree (1: the single-simulation kernels; > 1: per-thread lines + T rows per tree in a leaf batch)
+    void create(int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int T, int game) {
+        k_G = G; k_blocks = blocks; k_H = H; k_T = T;
         d.game = game;
+        d.T = T;
         d.G = G; d.R = (uint32_t)(blocks * BLOCK_SLOTS); d.H = H; d.reserve_nodes = (uint32_t)reserve_nodes;
         size_t slots = (size_t)G * d.R;
         d.node = mem.alloc<uint4>(slots * 2);
         d.hash = mem.alloc<uint32_t>((size_t)G * H);
         d.head = mem.alloc<TreeLine>(G);
-        d.path = mem.alloc<uint32_t>((size_t)G * PATH_CAP);
+        d.path = mem.alloc<uint32_t>((size_t)G * T * PATH_CAP);
         d.err = mem.alloc<uint32_t>(ERR_COUNT);
-        d.log_cap = log_cap;
-        d.log_state = mem.alloc<ulonglong2>((size_t)G * std::max(log_cap, 0));
-        d.log_pi = mem.alloc<float>((size_t)G * std::max(log_cap, 0) * 7);
-        d.log_v = mem.alloc<float>((size_t)G * std::max(log_cap, 0));
-        d_totals = mem.alloc<unsigned long long>(ST_COUNT);
+        d.log_cap = 0;
+        if (T > 1) {
+            d.thr = mem.alloc<TreeLine>((size_t)G * T);
+            HIPCHK(hipMemset(d.thr, 0, (size_t)G * T * sizeof(TreeLine)));
+        }
+        d_totals = mem.alloc<unsigned long long>(ST_TOTALS);
         d_counts = mem.alloc<uint32_t>(G);
         HIPCHK(hipMemset(d.err, 0, ERR_COUNT * sizeof(uint32_t)));
-        HIPCHK(hipMemset(d_totals, 0, ST_COUNT * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(d_totals, 0, ST_TOTALS * sizeof(unsigned long long)));
         launch_init_heads(d, nullptr);
         HIPCHK(hipDeviceSynchronize());
         for (EvalBatch* b : {&eb, &eb2}) {
-            b->cap = G;
+            const size_t rows = (size_t)G * T;
+            b->cap = (int32_t)rows;
             b->n = mem.alloc<uint32_t>(1);
-            b->state = mem.alloc<ulonglong2>(G);
-            b->pi = mem.alloc<float>((size_t)G * 8);
-            b->v = mem.alloc<float>(G);
+            b->state = mem.alloc<ulonglong2>(rows);
+            b->pi = mem.alloc<float>(rows * 8);
+            b->v = mem.alloc<float>(rows);
             HIPCHK(hipMemset(b->n, 0, sizeof(uint32_t)));
             // election table of the leaf de-duplication (used when the engine's "eval_dedup" applies to a search's net)
-            const uint32_t tsize = next_pow2_u32(4ull * (uint64_t)std::max(G, 16));
+            const uint32_t tsize = next_pow2_u32(4ull * (uint64_t)std::max<size_t>(rows, 16));
             b->tkey = mem.alloc<unsigned long long>(tsize);
             b->tuniq = mem.alloc<uint32_t>(tsize);
             b->tmask = tsize - 1;
@@ -175,6 +246,8 @@ struct az_engine {
     az_stats stats{};
     Profiler prof;
     NetProfile netprof;
+    NetOptions netopt;              // kernel-set switches of the conv net: this engine's, passed down with every forward
+    int tree_block4 = 1;            // "tree_block4": k_backup_select as 4-wave workgroups
     // activation workspaces of the conv net: [0] the engine stream, [1] a second concurrent stream (az_arena's old-model
     // search); created on first use, shared by every model id
     NetWorkspace* ws[2] = {nullptr, nullptr};
@@ -183,6 +256,10 @@ struct az_engine {
     std::vector<uint64_t> sp_log_states;
     std::vector<float> sp_log_pi, sp_log_v;
     int sp_log_cap = 0;
+    // eval logs of the last az_arena with record_evals: [0] the new model's trees, [1] the old model's
+    struct EvalLog { std::vector<int32_t> count; std::vector<uint64_t> states; std::vector<float> pi, v; };
+    EvalLog ar_log[2];
+    int ar_log_cap = 0, ar_log_games = 0;
     // NNet::train
     Trainer* trainer = nullptr;
     bool train_open = false;
@@ -202,14 +279,19 @@ struct az_engine {
     int eval_cache_log2 = 27;       // entries = 2^log2 (40 B each: 5.4 GB); 0 = no cache, in-batch de-duplication only
     int eval_cache_max_stones = 42;
     int eval_cache_persist = 0;     // 0: az_selfplay / az_arena / az_tree_get_action_prob start from an empty cache
-    DeviceMem cache_mem;
-    EvalCache cache{};              // key == nullptr until first use
+    DeviceMem cache_mem;            // the accounting counters
+    EvalCache cache{};              // the view the current call uses (prepare_cache); key == nullptr: no cache
+    unsigned long long* cache_keys = nullptr;       // the allocation: 2^cache_alloc_log2 entries
+    float* cache_pv = nullptr;
     int cache_alloc_log2 = -1;
     uint64_t next_cache_tag = 1;    // 15 bits; wrapping clears the cache
     // tree arenas of finished az_selfplay / az_arena calls, reused by the next call of the same shape (9.7 GB at 8192 x 100:
     // no hipMalloc / hipFree per call); at most three are kept (self-play + the arena's pair)
     std::vector<std::unique_ptr<TreeHost>> tree_pool;
     uint64_t tree_pool_allocs = 0;  // arenas created (a second call of the same shape must not add to it)
+    // communicator of the sharded Coach loop (az_comm_init): RCCL on the engine's stream
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
 };
 
 struct az_tree {
@@ -247,7 +329,7 @@ NetWorkspace* workspace_for(az_engine* e, hipStream_t s) {
 
 void net_forward(az_engine* e, const NetModel& net, const EvalBatch& eb, int rows_hint, hipStream_t s, int rows_typ = 0, bool timed = true) {
     if (net.kind == AZ_NET_CONV) {
-        convnet_forward(net.conv, workspace_for(e, s), eb, rows_hint, rows_typ, s, (e->prof.on && timed) ? &e->netprof : nullptr);
+        convnet_forward(net.conv, workspace_for(e, s), eb, rows_hint, rows_typ, s, (e->prof.on && timed) ? &e->netprof : nullptr, e->netopt);
     } else {
         launch_net_fixture(eb, net.kind, net.salt, s);
     }
@@ -257,29 +339,46 @@ bool dedup_applies(const az_engine* e, const NetModel& net) {
     return e->eval_dedup == 2 || (e->eval_dedup == 1 && net.kind == AZ_NET_CONV);
 }
 
-// The engine's evaluation cache, allocated on first use; (re)sized by "eval_cache_log2".
-void ensure_cache(az_engine* e) {
-    if (e->cache_alloc_log2 == e->eval_cache_log2) return;
-    e->cache_mem.release();
-    e->cache = EvalCache{};
-    e->cache.stat = e->cache_mem.alloc<unsigned long long>((size_t)DD_REPLICAS * DD_STRIDE);
-    HIPCHK(hipMemset(e->cache.stat, 0, (size_t)DD_REPLICAS * DD_STRIDE * sizeof(unsigned long long)));
-    if (e->eval_cache_log2 >= 3) {
-        const size_t entries = (size_t)1 << e->eval_cache_log2;
-        e->cache.key = e->cache_mem.alloc<unsigned long long>(entries);
-        e->cache.pv = e->cache_mem.alloc<float>(entries * 8);
-        e->cache.bmask = (uint32_t)(entries / 8 - 1);
-        HIPCHK(hipMemset(e->cache.key, 0, entries * 8));
+// The engine's evaluation cache.  Sized FROM THE CALL: a search call can insert at most `inserts_bound` distinct states (trees x
+// get_action_prob calls x (sims + 1)), so it gets the smallest power of two >= 4 x that bound (8-way buckets stay sparse), at most
+// 2^"eval_cache_log2" entries (40 bytes each; 5.4 GB at the default 27, which only a bench-sized call reaches) -- a 1-tree, 25-sim
+// call allocates and clears 40 KB.  The allocation only grows; a smaller call uses (and clears) a prefix of it.  With
+// "eval_cache_persist" entries must stay findable across calls, so the cache then has its full configured size from the start.
+void prepare_cache(az_engine* e, bool wanted, uint64_t inserts_bound, hipStream_t s) {
+    if (!e->cache.stat) {
+        e->cache.stat = e->cache_mem.alloc<unsigned long long>((size_t)DD_REPLICAS * DD_STRIDE);
+        HIPCHK(hipMemset(e->cache.stat, 0, (size_t)DD_REPLICAS * DD_STRIDE * sizeof(unsigned long long)));
     }
-    e->cache_alloc_log2 = e->eval_cache_log2;
-}
-void clear_cache(az_engine* e, hipStream_t s) {
-    if (e->cache.key) HIPCHK(hipMemsetAsync(e->cache.key, 0, ((size_t)e->cache.bmask + 1) * 64, s));
+    if (!wanted || e->eval_cache_log2 < 3) { e->cache.key = nullptr; e->cache.pv = nullptr; e->cache.bmask = 0; return; }
+    int want = e->eval_cache_log2;
+    if (!e->eval_cache_persist) {
+        int need = 10;
+        while (need < want && (1ull << need) < 4ull * inserts_bound) ++need;
+        want = need;
+    }
+    if (e->cache_alloc_log2 < want) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (e->cache_keys) { (void)hipFree(e->cache_keys); e->cache_keys = nullptr; }
+        if (e->cache_pv) { (void)hipFree(e->cache_pv); e->cache_pv = nullptr; }
+        e->cache_alloc_log2 = -1;
+        const size_t entries = (size_t)1 << want;
+        HIPCHK(hipMalloc((void**)&e->cache_keys, entries * 8));
+        HIPCHK(hipMalloc((void**)&e->cache_pv, entries * 8 * sizeof(float)));
+        HIPCHK(hipMemset(e->cache_keys, 0, entries * 8));
+        e->cache_alloc_log2 = want;
+        for (auto& kv : e->nets) kv.second.cache_tag = 0;       // a new allocation holds nobody's entries
+        e->next_cache_tag = 1;
+    }
+    const int view = want;          // persist: the configured size, the same for every call
+    e->cache.key = e->cache_keys;
+    e->cache.pv = e->cache_pv;
+    e->cache.bmask = (uint32_t)(((size_t)1 << view) / 8 - 1);
+    if (!e->eval_cache_persist) HIPCHK(hipMemsetAsync(e->cache.key, 0, ((size_t)e->cache.bmask + 1) * 64, s));      // this call's part only
 }
 // a new tag for a model's new weights: its old entries can never match again
 void retag_model(az_engine* e, NetModel& m) {
     if (e->next_cache_tag > 0x7FFFull) {
-        if (e->cache.key) HIPCHK(hipMemset(e->cache.key, 0, ((size_t)e->cache.bmask + 1) * 64));
+        if (e->cache_keys) HIPCHK(hipMemset(e->cache_keys, 0, ((size_t)1 << e->cache_alloc_log2) * 8));
         for (auto& kv : e->nets) kv.second.cache_tag = 0;
         e->next_cache_tag = 1;
     }
@@ -289,7 +388,6 @@ void retag_model(az_engine* e, NetModel& m) {
 EvalCache cache_for(az_engine* e, NetModel& net) {
     EvalCache c{};
     if (!dedup_applies(e, net)) return c;
-    ensure_cache(e);
     if (net.cache_tag == 0) retag_model(e, net);
     c = e->cache;
     c.max_stones = (uint32_t)e->eval_cache_max_stones;
@@ -304,9 +402,9 @@ struct TreeLease {
     TreeHost* operator->() const { return th; }
     TreeHost& operator*() const { return *th; }
 };
-void acquire_trees(az_engine* e, TreeLease& lease, int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int log_cap, hipStream_t s) {
+void acquire_trees(az_engine* e, TreeLease& lease, int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int T, hipStream_t s) {
     for (auto& p : e->tree_pool)
-        if (!p->in_use && p->fits(G, blocks, H, log_cap)) {
+        if (!p->in_use && p->fits(G, blocks, H, T)) {
             p->in_use = true;
             lease.th = p.get();
             p->recycle(reserve_nodes, s);
@@ -314,7 +412,7 @@ void acquire_trees(az_engine* e, TreeLease& lease, int G, uint64_t blocks, uint6
         }
     // drop idle arenas of other shapes before allocating (two shapes of 10 GB each should not pile up)
     for (size_t i = 0; i < e->tree_pool.size();) {
-        if (!e->tree_pool[i]->in_use && (e->tree_pool.size() >= 3 || !e->tree_pool[i]->fits(G, blocks, H, log_cap))) {
+        if (!e->tree_pool[i]->in_use && (e->tree_pool.size() >= 3 || !e->tree_pool[i]->fits(G, blocks, H, T))) {
             HIPCHK(hipStreamSynchronize(s));
             e->tree_pool.erase(e->tree_pool.begin() + (long)i);
         } else {
@@ -322,12 +420,37 @@ void acquire_trees(az_engine* e, TreeLease& lease, int G, uint64_t blocks, uint6
         }
     }
     std::unique_ptr<TreeHost> th(new TreeHost());
-    th->create(G, blocks, reserve_nodes, H, log_cap, e->cfg.game);
+    th->create(G, blocks, reserve_nodes, H, T, e->cfg.game);
     th->in_use = true;
     lease.th = th.get();
     e->tree_pool.push_back(std::move(th));
     e->tree_pool_allocs += 1;
 }
+
+// Eval log of one call (replay parity): rows * cap records in device memory, attached to a tree arena for the call's duration.
+struct ScopedEvalLog {
+    TreeHost* th = nullptr;
+    DeviceMem mem;
+    size_t rows = 0;
+    int cap = 0;
+    void attach(TreeHost& t, size_t rows_, int cap_, const int32_t* log_row) {
+        th = &t; rows = rows_; cap = cap_;
+        t.d.log_cap = cap;
+        t.d.log_state = mem.alloc<ulonglong2>(rows * (size_t)cap);
+        t.d.log_pi = mem.alloc<float>(rows * (size_t)cap * 7);
+        t.d.log_v = mem.alloc<float>(rows * (size_t)cap);
+        t.d.log_row = log_row;
+    }
+    void copy_out(std::vector<uint64_t>& states, std::vector<float>& pi, std::vector<float>& v) const {
+        states.resize(rows * cap * 2); pi.resize(rows * cap * 7); v.resize(rows * cap);
+        HIPCHK(hipMemcpy(states.data(), th->d.log_state, states.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pi.data(), th->d.log_pi, pi.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(v.data(), th->d.log_v, v.size() * 4, hipMemcpyDeviceToHost));
+    }
+    ~ScopedEvalLog() {          // the arena goes back to the pool without the call's log
+        if (th) { th->d.log_cap = 0; th->d.log_state = nullptr; th->d.log_pi = nullptr; th->d.log_v = nullptr; th->d.log_row = nullptr; }
+    }
+};
 
 // fold the device-side de-duplication counters into the engine stats (after a stream sync)
 void harvest_dedup(az_engine* e) {
@@ -350,9 +473,12 @@ void harvest_dedup(az_engine* e) {
 void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int num_sims, SearchParams sp,
                 NetModel& net, int rows_hint, hipStream_t s = nullptr, int rows_typ = 0, uint32_t* d_max_rows = nullptr) {
     if (!s) s = e->stream;
+    th.d.block4 = e->tree_block4;
+    const int T = th.d.T;
     if (rows_hint <= 0 || rows_hint > th.d.G) rows_hint = th.d.G;
+    rows_hint *= T;                              // up to T leaves per tree and step
     const bool dedup = dedup_applies(e, net);
-    if (net.kind != AZ_NET_CONV && !dedup && e->fused_search) {
+    if (net.kind != AZ_NET_CONV && !dedup && e->fused_search && T == 1) {
         // stub / hash nets are device functions of the state: the whole search is one launch
         hipEvent_t t0 = nullptr;
         if (e->prof.on) t0 = e->prof.begin(s);
@@ -382,6 +508,22 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
     B[0].epoch = next_epoch();
     launch_root_prepare(th.d, B[0], ec, d_root_states, s);
     net_forward(e, net, B[0], rows_hint, s, rows_typ, false);
+    if (T > 1) {
+        // num_sims / T lock-step steps of T simulations per tree (src/async_mcts.rs:191-217; num_sims % T == 0, :192)
+        const int steps = num_sims / T;
+        for (int i = 0; i < steps; ++i) {
+            const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
+            hipEvent_t t0 = nullptr;
+            if (timed) t0 = e->prof.begin(s);
+            B[(i + 1) & 1].epoch = next_epoch();
+            launch_step_mt(th.d, B[i & 1], B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, 0, s);
+            if (timed) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
+            e->stats.tree_launches += 1;
+            net_forward(e, net, B[(i + 1) & 1], rows_hint, s, rows_typ, timed);
+        }
+        launch_step_mt(th.d, B[steps & 1], B[(steps + 1) & 1], ec, sp, steps == 0 ? 1 : 0, 1, s);
+        return;
+    }
     for (int i = 0; i < num_sims; ++i) {
         const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
         hipEvent_t t0 = nullptr;
@@ -408,7 +550,7 @@ void harvest_stats(az_engine* e, TreeHost& th, const NetModel& net) {
     harvest_dedup(e);
     const bool dedup = dedup_applies(e, net);
     launch_harvest(th.d, th.d_totals, th.d_counts, e->stream);
-    unsigned long long h[ST_COUNT];
+    unsigned long long h[ST_TOTALS];
     HIPCHK(hipMemcpyAsync(h, th.d_totals, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemsetAsync(th.d_totals, 0, sizeof h, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -419,6 +561,7 @@ void harvest_stats(az_engine* e, TreeHost& th, const NetModel& net) {
     e->stats.link_hits += h[ST_LINK_HITS];
     e->stats.terminal_hits += h[ST_TERMINAL_HITS];
     e->stats.depth_sum += h[ST_DEPTH_SUM];
+    e->stats.abandoned_sims += h[ST_ABANDONED];
     // algorithmic tree bytes per simulation, SURVEY.md 8(d): 128 per selection level + 356 per expansion
     e->stats.tree_bytes += 128.0 * (double)h[ST_DEPTH_SUM] + 356.0 * (double)h[ST_SIMS];
 }
@@ -490,6 +633,9 @@ void az_destroy(az_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->nets) if (kv.second.conv) convnet_destroy(kv.second.conv);
     for (NetWorkspace* w : e->ws) netws_destroy(w);
+    if (e->cache_keys) (void)hipFree(e->cache_keys);
+    if (e->cache_pv) (void)hipFree(e->cache_pv);
+    if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; }
     e->tree_pool.clear();
     trainer_destroy(e->trainer);
     { double ms[RG_COUNT] = {0, 0}; e->prof.resolve(ms); }
@@ -501,13 +647,41 @@ const char* az_last_error(const az_engine* e) { return e ? e->err.c_str() : "nul
 
 az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (!e || !key) return AZ_ERR_BAD_ARGUMENT;
-    if (std::strcmp(key, "gemm_variant") == 0 &&
-        (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || (value >= 11 && value <= 17))) {
-        convnet_set_variant((int)value);
-        return AZ_OK;
-    }
-    if (std::strcmp(key, "print_clock_stamps") == 0) {
-        // diagnostic (gemm_variant 13): median in-kernel clock of conv2's K loop for model `value`
+    auto is = [&](const char* k) { return std::strcmp(key, k) == 0; };
+    // ---- options of the shipped library: every one of them lives in THIS engine ----
+    if (is("conv2_table") && (value == 0 || value == 1)) { e->netopt.conv2_table = (int)value; return AZ_OK; }
+    if (is("conv3_small") && (value == 0 || value == 1)) { e->netopt.conv3_small = (int)value; return AZ_OK; }
+    if (is("tree_block4") && (value == 0 || value == 1)) { e->tree_block4 = (int)value; return AZ_OK; }
+    if (is("dedup_stats") && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }
+    if (is("profile_every") && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
+    if (is("dedup_epoch_max") && value >= 3 && value <= 0x7FFF) { e->dedup_epoch_max = (int)value; return AZ_OK; }
+    if (is("fused_search") && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
+    if (is("eval_dedup") && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
+    if (is("eval_cache_log2") && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
+    if (is("eval_cache_max_stones") && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
+    if (is("eval_cache_persist") && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
+    // NNet::train hyper-parameters (defaults = connect_four_net.py:13-15, :21)
+    if (is("train_epochs") && value >= 1 && value <= 100000) { e->train_epochs = (int)value; return AZ_OK; }
+    if (is("train_batch") && value >= 2 && value <= TRAIN_MAX_BATCH) { e->train_batch = (int)value; return AZ_OK; }
+    if (is("train_seed")) { e->train_seed = (uint64_t)value; return AZ_OK; }
+    if (is("train_graph") && (value == 0 || value == 1)) { e->train_graph = (int)value; if (e->trainer) trainer_set_graph(e->trainer, value != 0); return AZ_OK; }
+    if (is("train_lr_e9") && value > 0) { e->hyper.lr = (float)((double)value * 1e-9); return AZ_OK; }
+    if (is("train_dropout_e6") && value >= 0 && value < 1000000) { e->hyper.dropout = (float)((double)value * 1e-6); return AZ_OK; }
+#ifdef AZ_DIAG
+    // ---- libaz_engine_diag.so only: superseded kernel generations, forced tiles, clock-stamp builds, timing ablations (WRONG results) ----
+    NetOptions& o = e->netopt;
+    if (is("conv2_table") && value == 2) { o.conv2_table = 2; return AZ_OK; }
+    if (is("gemm_variant") && (value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || (value >= 11 && value <= 17))) { o.gemm_variant = (int)value; return AZ_OK; }
+    if (is("fc_ring") && value >= 0 && value <= 3) { o.fc_ring = (int)value; return AZ_OK; }
+    if (is("ring_tile") && value >= 0 && value < 60000) { const int l = (int)(value / 10000); if (l >= 3 && l <= 5) o.ring_tile[l] = (int)(value % 10000); return AZ_OK; }
+    if (is("conv3_ring") && value >= 0 && value <= 3) { o.conv3_ring = (int)value; return AZ_OK; }
+    if (is("conv2_pipe") && (value == 0 || value == 1)) { o.conv2_pipe = (int)value; return AZ_OK; }
+    if (is("conv3_pipe") && ((value >= 0 && value <= 3) || (value >= 9 && value <= 15))) { o.conv3_pipe = (int)value; return AZ_OK; }
+    if (is("conv1_table") && (value == 0 || value == 1)) { o.conv1_table = (int)value; return AZ_OK; }
+    if (is("conv4_big") && value >= 0 && value <= 2) { o.conv4_big = (int)value; return AZ_OK; }
+    if (is("tree_stamps") && (value == 0 || value == 1)) { return tree_set_stamps((int)value) ? AZ_OK : fail(e, AZ_ERR_HIP, "tree_set_stamps"); }
+    if (is("print_clock_stamps")) {
+        // gemm_variant 13: median in-kernel clock of conv2's K loop for model `value`
         auto it = e->nets.find((int)value);
         std::vector<unsigned long long> st(2048);
         if (it == e->nets.end() || !it->second.conv || !netws_read_clock_stamps(e->ws[0], st.data()))
@@ -521,8 +695,8 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = buf;       // returned through az_last_error
         return AZ_OK;
     }
-    if (std::strcmp(key, "print_seg_stamps") == 0) {
-        // diagnostic (conv3_pipe 3): per-segment cycle sums of wave 0 of the first 128 workgroups of the last conv3 launch, median over blocks
+    if (is("print_seg_stamps")) {
+        // conv3_pipe 3: per-segment cycle sums of wave 0 of the first 128 workgroups of the last conv3 launch, median over blocks
         std::vector<unsigned long long> st(2048);
         if (!e->ws[0] || !netws_read_clock_stamps(e->ws[0], st.data())) return fail(e, AZ_ERR_BAD_ARGUMENT, "no workspace");
         std::string out;
@@ -538,11 +712,8 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = out;
         return AZ_OK;
     }
-    if (std::strcmp(key, "dedup_stats") == 0 && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "tree_block4") == 0 && (value == 0 || value == 1)) { tree_set_block4((int)value); return AZ_OK; }
-    if (std::strcmp(key, "tree_stamps") == 0 && (value == 0 || value == 1)) { return tree_set_stamps((int)value) ? AZ_OK : fail(e, AZ_ERR_HIP, "tree_set_stamps"); }
-    if (std::strcmp(key, "print_tree_stamps") == 0) {
-        // diagnostic ("tree_stamps" = 1): cycles per phase of the last k_backup_select launch, median over its waves:
+    if (is("print_tree_stamps")) {
+        // "tree_stamps" = 1: cycles per phase of the last k_backup_select launch, median over its waves:
         // load head+path | backup | wait for its stores | select | leaf request | store head+path | whole kernel
         std::vector<unsigned long long> st(4096 * 8);
         if (!tree_read_stamps(st.data())) return fail(e, AZ_ERR_BAD_ARGUMENT, "no stamps (set tree_stamps 1 and run a search first)");
@@ -559,33 +730,17 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = out;
         return AZ_OK;
     }
-    if (std::strcmp(key, "profile_every") == 0 && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "dedup_epoch_max") == 0 && value >= 3 && value <= 0x7FFF) { e->dedup_epoch_max = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "fused_search") == 0 && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "eval_dedup") == 0 && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "eval_cache_log2") == 0 && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "eval_cache_max_stones") == 0 && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "eval_cache_persist") == 0 && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "fc_ring") == 0 && value >= 0 && value <= 3) { convnet_set_fc_ring((int)value); return AZ_OK; }
-    if (std::strcmp(key, "ring_tile") == 0 && value >= 0 && value < 60000) { convnet_set_ring_tile((int)(value / 10000), (int)(value % 10000)); return AZ_OK; }
-    if (std::strcmp(key, "ring_max_tiles") == 0 && value >= 0 && value <= 100000) { convnet_set_ring_max_tiles((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv3_small") == 0 && (value == 0 || value == 1)) { convnet_set_conv3_small((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv3_ring") == 0 && value >= 0 && value <= 3) { convnet_set_conv3_ring((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv2_pipe") == 0 && (value == 0 || value == 1)) { convnet_set_conv2_pipe((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv3_pipe") == 0 && ((value >= 0 && value <= 3) || (value >= 9 && value <= 15))) { convnet_set_conv3_pipe((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv2_table") == 0 && value >= 0 && value <= 2) { convnet_set_conv2_table((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv1_table") == 0 && (value == 0 || value == 1)) { convnet_set_conv1_table((int)value); return AZ_OK; }
-    if (std::strcmp(key, "conv4_big") == 0 && value >= 0 && value <= 2) {
-        convnet_set_conv4_big((int)value);
-        return AZ_OK;
-    }
-    // NNet::train hyper-parameters (defaults = connect_four_net.py:13-15, :21)
-    if (std::strcmp(key, "train_epochs") == 0 && value >= 1 && value <= 100000) { e->train_epochs = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "train_batch") == 0 && value >= 2 && value <= TRAIN_MAX_BATCH) { e->train_batch = (int)value; return AZ_OK; }
-    if (std::strcmp(key, "train_seed") == 0) { e->train_seed = (uint64_t)value; return AZ_OK; }
-    if (std::strcmp(key, "train_graph") == 0 && (value == 0 || value == 1)) { e->train_graph = (int)value; if (e->trainer) trainer_set_graph(e->trainer, value != 0); return AZ_OK; }
-    if (std::strcmp(key, "train_lr_e9") == 0 && value > 0) { e->hyper.lr = (float)((double)value * 1e-9); return AZ_OK; }
-    if (std::strcmp(key, "train_dropout_e6") == 0 && value >= 0 && value < 1000000) { e->hyper.dropout = (float)((double)value * 1e-6); return AZ_OK; }
+#else
+    // the diagnostic keys exist in libaz_engine_diag.so only; their DEFAULT value is accepted here so that a caller resetting them is not an error
+    static const struct { const char* k; int64_t dflt; } diag_keys[] = {{"gemm_variant", 5}, {"fc_ring", 1}, {"conv3_ring", 0}, {"conv2_pipe", 1},
+                                                                         {"conv3_pipe", 1}, {"conv1_table", 1}, {"conv4_big", 0}, {"tree_stamps", 0}};
+    bool diag_key = is("print_clock_stamps") || is("print_seg_stamps") || is("print_tree_stamps") || (is("conv2_table") && value == 2);
+    if (is("ring_tile")) { if (value >= 30000 && value < 60000 && value % 10000 == 0) return AZ_OK; diag_key = true; }
+    for (const auto& dk : diag_keys)
+        if (is(dk.k)) { if (value == dk.dflt) return AZ_OK; diag_key = true; }
+    if (diag_key)
+        return fail(e, AZ_ERR_BAD_ARGUMENT, std::string(key) + ": diagnostic option or value (superseded kernels, timing ablations and clock stamps live in libaz_engine_diag.so)");
+#endif
     return fail(e, AZ_ERR_BAD_ARGUMENT, std::string("unknown option or value: ") + key);
 }
 
@@ -600,6 +755,11 @@ az_status az_get_stats(az_engine* e, az_stats* out) {
     out->net_conv3_ms = e->netprof.conv3_ms;
     out->net_conv3_flops = e->netprof.conv3_flops;
     out->net_conv2_bytes = e->netprof.conv2_bytes;
+    out->net_conv4_ms = e->netprof.conv4_ms;
+    out->net_conv4_flops = e->netprof.conv4_flops;
+    out->net_fc_ms = e->netprof.fc_ms;
+    out->net_fc_flops = e->netprof.fc_flops;
+    out->net_rows_timed = e->netprof.rows;
     out->tree_arena_allocs = e->tree_pool_allocs;
     return AZ_OK;
 }
@@ -878,10 +1038,19 @@ int32_t az_net_train_history(const az_engine* e, float* out, int32_t cap_epochs)
 }
 
 // ---- AsyncMcts -------------------------------------------------------------------------------
-az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_t num_sims, int32_t max_depth,
+// num_sims % num_threads == 0 (assert!, src/async_mcts.rs:192); 0 means 1
+static az_status check_threads(az_engine* e, int num_sims, int* num_threads) {
+    if (*num_threads == 0) *num_threads = 1;
+    if (*num_threads < 1 || *num_threads > MAX_SIM_THREADS) return fail(e, AZ_ERR_BAD_ARGUMENT, "num_threads must be in [1, 8]");
+    if (num_sims % *num_threads != 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "num_sims % num_threads != 0 (src/async_mcts.rs:192)");
+    return AZ_OK;
+}
+
+az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_t num_sims, int32_t num_threads, int32_t max_depth,
                          int32_t model_id, int32_t cpuct, az_tree** out) {
     if (!e || !out || n_games <= 0 || num_sims <= 0 || reserve < 8 || max_depth < 0)
         return fail(e, AZ_ERR_BAD_ARGUMENT, "az_tree_create: bad argument");
+    if (az_status st = check_threads(e, num_sims, &num_threads)) return st;
     if (n_games > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_tree_create: at most 65536 trees per batch");
     *out = nullptr;
     try {
@@ -890,7 +1059,7 @@ az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_
         t->e = e;
         t->num_sims = num_sims; t->max_depth = max_depth; t->model_id = model_id; t->cpuct = cpuct;
         const uint64_t nodes = std::min<uint64_t>(reserve, reachable_slots(num_sims, AZ_MAX_PLIES));
-        t->th.create(n_games, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(num_sims, AZ_MAX_PLIES), 0, e->cfg.game);
+        t->th.create(n_games, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(num_sims, AZ_MAX_PLIES), num_threads, e->cfg.game);
         t->d_root_states = t->mem.alloc<ulonglong2>(n_games);
         t->d_pi = t->mem.alloc<float>((size_t)n_games * 7);
         t->d_counts = t->mem.alloc<uint16_t>((size_t)n_games * 7);
@@ -921,7 +1090,7 @@ az_status az_tree_reset(az_tree* t, const uint64_t* root_states) {
         }
         launch_reset_trees(t->th.d, nullptr, e->stream, roots);
         launch_harvest(t->th.d, t->th.d_totals, nullptr, e->stream);          // forget the old trees' counters
-        HIPCHK(hipMemsetAsync(t->th.d_totals, 0, ST_COUNT * sizeof(unsigned long long), e->stream));
+        HIPCHK(hipMemsetAsync(t->th.d_totals, 0, ST_TOTALS * sizeof(unsigned long long), e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
@@ -982,7 +1151,7 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
     NetModel* net;
     az_status st = find_net(e, t->model_id, &net);
     if (st) return st;
-    st = check_batch(e, *net, t->th.d.G);
+    st = check_batch(e, *net, t->th.d.G * t->th.d.T);
     if (st) return st;
     ScopedTimer timer{e};
     try {
@@ -992,7 +1161,7 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
         HIPCHK(hipMemcpyAsync(t->d_root_states, states, (size_t)G * 16, hipMemcpyDefault, e->stream));
         launch_set_active(d, 1u, e->stream);
         SearchParams sp{(uint32_t)t->max_depth, (float)t->cpuct};
-        if (!e->eval_cache_persist) clear_cache(e, e->stream);
+        prepare_cache(e, dedup_applies(e, *net), (uint64_t)G * ((uint64_t)t->num_sims + 1), e->stream);
         run_search(e, t->th, t->d_root_states, t->num_sims, sp, *net, G);
         launch_root_policy(d, temp, seed, first_game_id, t->d_pi, t->d_counts, t->d_q, e->stream);
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -1021,7 +1190,10 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
     NetModel* net;
     az_status st = find_net(e, p->model_id, &net);
     if (st) return st;
-    st = check_batch(e, *net, C);
+    int T = p->num_sim_threads;
+    st = check_threads(e, p->num_sims, &T);
+    if (st) return st;
+    st = check_batch(e, *net, C * T);
     if (st) return st;
     ScopedTimer timer{e};
     try {
@@ -1029,10 +1201,10 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         hipStream_t s = e->stream;
         const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
         TreeLease lease;
-        acquire_trees(e, lease, C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES),
-                      p->record_evals, s);
+        acquire_trees(e, lease, C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES), T, s);
         TreeHost& th = *lease;
         DeviceMem mem;
+        ScopedEvalLog evlog;
         GamesDev gd{};
         gd.C = C;
         gd.n_games = n_games;
@@ -1050,6 +1222,12 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         gd.g_result = mem.alloc<float>(n_games);
         gd.g_final_player = mem.alloc<int8_t>(n_games);
         gd.counters = mem.alloc<uint32_t>(4);
+        if (p->record_evals > 0) {
+            // per-EPISODE logs (row = the slot's current episode id), so they survive slot refills
+            gd.g_log_len = mem.alloc<int32_t>(n_games);
+            HIPCHK(hipMemset(gd.g_log_len, 0, n_games * sizeof(int32_t)));
+            evlog.attach(th, (size_t)n_games, p->record_evals, gd.gid);
+        }
         {
             std::vector<int32_t> gid(C);
             std::vector<int8_t> pl(C, 1);
@@ -1064,12 +1242,8 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
             uint32_t ctr[4] = {(uint32_t)C, 0u, (uint32_t)C, 0u};
             HIPCHK(hipMemcpy(gd.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
         }
-        // per-episode eval logs survive slot refills: they are copied out when the slot's episode ends.
-        // (record_evals is a test facility; it requires concurrent == n_games so that slot == episode.)
-        if (p->record_evals > 0 && C != n_games)
-            return fail(e, AZ_ERR_BAD_ARGUMENT, "record_evals needs concurrent == n_games");
         launch_reset_trees(th.d, nullptr, s);
-        if (!e->eval_cache_persist) clear_cache(e, s);
+        prepare_cache(e, dedup_applies(e, *net), (uint64_t)n_games * AZ_MAX_PLIES * ((uint64_t)p->num_sims + 1), s);
         SearchParams sp{(uint32_t)p->max_depth, (float)p->cpuct};
         SelfplayMoveParams mp{p->seed, p->first_game_id, p->temp_threshold, C < n_games ? 1 : 0};
         uint32_t* h_ctr = nullptr;
@@ -1091,7 +1265,7 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
             resolve_profile(e);
             ++moves;
             active = (int)h_ctr[2];
-            rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)C) : 0;      // this move's largest batch
+            rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)(C * T)) : 0;      // this move's largest batch
             HIPCHK(hipMemsetAsync(gd.counters + 3, 0, sizeof(uint32_t), s));
             if (h_ctr[1] >= (uint32_t)n_games) break;
             if ((iter & 7) == 7 || h_ctr[2] == 0) {
@@ -1138,17 +1312,8 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
             const int cap = p->record_evals;
             e->sp_log_cap = cap;
             e->sp_log_count.resize(n_games);
-            e->sp_log_states.resize((size_t)n_games * cap * 2);
-            e->sp_log_pi.resize((size_t)n_games * cap * 7);
-            e->sp_log_v.resize((size_t)n_games * cap);
-            {
-                std::vector<TreeLine> heads(n_games);
-                HIPCHK(hipMemcpy(heads.data(), th.d.head, (size_t)n_games * sizeof(TreeLine), hipMemcpyDeviceToHost));
-                for (int g = 0; g < n_games; ++g) e->sp_log_count[g] = (int32_t)heads[g].head.log_len;
-            }
-            HIPCHK(hipMemcpy(e->sp_log_states.data(), th.d.log_state, e->sp_log_states.size() * 8, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(e->sp_log_pi.data(), th.d.log_pi, e->sp_log_pi.size() * 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(e->sp_log_v.data(), th.d.log_v, e->sp_log_v.size() * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(e->sp_log_count.data(), gd.g_log_len, (size_t)n_games * sizeof(int32_t), hipMemcpyDeviceToHost));
+            evlog.copy_out(e->sp_log_states, e->sp_log_pi, e->sp_log_v);
         }
         (void)moves;
         return AZ_OK;
@@ -1178,16 +1343,42 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
     const int G = sharded ? p->num_games : 2 * half;
     const int first = sharded ? p->first_game : 0;
     out_wld[0] = out_wld[1] = out_wld[2] = 0;
-    if (G == 0) return AZ_OK;
+    if (G == 0) {      // an empty shard still takes part in the tally's all-reduce
+        if (sharded && p->allreduce_wld && e->comm) return az_allreduce_u64(e, out_wld, 3);
+        return AZ_OK;
+    }
     if (G > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: at most 65536 games");
+    if (p->record_evals < 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: negative record_evals");
+    if (p->use_start_board) {
+        const uint64_t a = p->start_board[0], b = p->start_board[1];
+        if ((a & b) || ((a | b) & ~C4_FULL)) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: start_board is not a pair of disjoint 7x6 bitboards");
+        // play_game's loop condition (src/arena.rs:18) fails at once on a finished board: result = cur_player * round(ended(cur_player)), :51
+        const ulonglong2 s0 = make_ulonglong2(a, b);
+        const uint32_t ec = e->cfg.game == 1 ? ConnectThree::ended_code(s0) : ConnectFour::ended_code(s0);
+        if (ec != E_NONE) {
+            const int8_t r = ec == E_MINUS1 ? 1 : (ec == E_PLUS1 ? -1 : 0);
+            std::vector<int8_t> res((size_t)G, r);
+            for (int g = 0; g < G; ++g) {
+                const int win_cond = first + g < half ? 1 : -1;
+                if (r == win_cond) out_wld[0]++; else if (r == -win_cond) out_wld[1]++; else out_wld[2]++;
+            }
+            if (results && hipMemcpy(results, res.data(), (size_t)G, hipMemcpyDefault) != hipSuccess) return fail(e, AZ_ERR_HIP, "az_arena: results copy");
+            e->stats.games += (uint64_t)G;
+            e->ar_log_cap = 0;
+            return AZ_OK;
+        }
+    }
     NetModel *net_new, *net_old;
     az_status st = find_net(e, p->new_model_id, &net_new);
     if (st) return st;
     st = find_net(e, p->old_model_id, &net_old);
     if (st) return st;
-    st = check_batch(e, *net_new, G);
+    int T = p->num_sim_threads;
+    st = check_threads(e, p->num_sims, &T);
     if (st) return st;
-    st = check_batch(e, *net_old, G);
+    st = check_batch(e, *net_new, G * T);
+    if (st) return st;
+    st = check_batch(e, *net_old, G * T);
     if (st) return st;
     ScopedTimer timer{e};
     try {
@@ -1198,8 +1389,8 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         const int calls = AZ_MAX_PLIES / 2 + 1;
         const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, calls));
         TreeLease lease_n, lease_o;
-        acquire_trees(e, lease_n, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0, s);
-        acquire_trees(e, lease_o, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), 0, s);
+        acquire_trees(e, lease_n, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), T, s);
+        acquire_trees(e, lease_o, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), T, s);
         TreeHost &tn = *lease_n, &to = *lease_o;
         DeviceMem mem;
         ArenaDev ad{};
@@ -1209,16 +1400,27 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         ad.alive = mem.alloc<uint8_t>(G);
         ad.results = mem.alloc<int8_t>(G);
         ad.counters = mem.alloc<uint32_t>(4);          // [2], [3]: the largest leaf batch of the ply, per model (tile / kernel choice of the next ply)
-        HIPCHK(hipMemset(ad.state, 0, (size_t)G * 16));
+        {
+            // play_games' `board` (src/arena.rs:62-67): None = the initial board
+            std::vector<uint64_t> st0((size_t)G * 2, 0ull);
+            if (p->use_start_board)
+                for (int g = 0; g < G; ++g) { st0[2 * (size_t)g] = p->start_board[0]; st0[2 * (size_t)g + 1] = p->start_board[1]; }
+            HIPCHK(hipMemcpy(ad.state, st0.data(), st0.size() * 8, hipMemcpyHostToDevice));
+        }
         HIPCHK(hipMemset(ad.player, 1, G));
         HIPCHK(hipMemset(ad.alive, 1, G));
         HIPCHK(hipMemset(ad.results, 0, G));
         uint32_t ctr[4] = {(uint32_t)G, 0u, 0u, 0u};
         HIPCHK(hipMemcpy(ad.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
         int typ_new = 0, typ_old = 0;                   // expected rows per leaf batch (0 = unknown: assume every running game)
+        ScopedEvalLog log_n, log_o;
+        if (p->record_evals > 0) {
+            log_n.attach(tn, (size_t)G, p->record_evals, nullptr);
+            log_o.attach(to, (size_t)G, p->record_evals, nullptr);
+        }
         launch_reset_trees(tn.d, nullptr, s);
         launch_reset_trees(to.d, nullptr, s);
-        if (!e->eval_cache_persist) clear_cache(e, s);
+        prepare_cache(e, dedup_applies(e, *net_new) || dedup_applies(e, *net_old), (uint64_t)G * AZ_MAX_PLIES * ((uint64_t)p->num_sims + 1), s);
         // both models' tags are fixed before the two streams fork (retagging may clear the cache)
         (void)cache_for(e, *net_new);
         (void)cache_for(e, *net_old);
@@ -1254,8 +1456,8 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
             HIPCHK(hipMemcpyAsync(ctr, ad.counters, sizeof ctr, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             resolve_profile(e);
-            typ_new = (int)std::min<uint32_t>(ctr[2], (uint32_t)G);
-            typ_old = (int)std::min<uint32_t>(ctr[3], (uint32_t)G);
+            typ_new = (int)std::min<uint32_t>(ctr[2], (uint32_t)(G * T));
+            typ_old = (int)std::min<uint32_t>(ctr[3], (uint32_t)(G * T));
             HIPCHK(hipMemsetAsync(ad.counters + 2, 0, 2 * sizeof(uint32_t), s));
             if (ctr[1]) { result = fail(e, AZ_ERR_INVALID_MOVE, "arena: action is not valid (src/arena.rs:31-35)"); break; }
             if (ctr[0] == 0) break;
@@ -1276,6 +1478,159 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         }
         if (results) HIPCHK(hipMemcpy(results, res.data(), G, hipMemcpyDefault));
         e->stats.games += (uint64_t)G;
+        if (sharded && p->allreduce_wld && e->comm) {       // every rank returns the whole arena's tally (one 3-counter all-reduce)
+            az_status rs = az_allreduce_u64(e, out_wld, 3);
+            if (rs) return rs;
+        }
+        e->ar_log_cap = 0;
+        if (p->record_evals > 0) {
+            TreeHost* ths[2] = {&tn, &to};
+            const ScopedEvalLog* logs[2] = {&log_n, &log_o};
+            for (int w = 0; w < 2; ++w) {
+                std::vector<TreeLine> heads(G);
+                HIPCHK(hipMemcpy(heads.data(), ths[w]->d.head, (size_t)G * sizeof(TreeLine), hipMemcpyDeviceToHost));
+                e->ar_log[w].count.resize(G);
+                for (int g = 0; g < G; ++g) e->ar_log[w].count[g] = (int32_t)heads[g].head.log_len;
+                logs[w]->copy_out(e->ar_log[w].states, e->ar_log[w].pi, e->ar_log[w].v);
+            }
+            e->ar_log_cap = p->record_evals;
+            e->ar_log_games = G;
+        }
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_arena_get_evals(az_engine* e, int32_t which, int32_t* rec_count, uint64_t* states, float* pis, float* vs) {
+    if (!e || which < 0 || which > 1 || e->ar_log_cap <= 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "no eval log (run az_arena with record_evals > 0)");
+    const az_engine::EvalLog& l = e->ar_log[which];
+    if (rec_count) std::memcpy(rec_count, l.count.data(), l.count.size() * sizeof(int32_t));
+    if (states) std::memcpy(states, l.states.data(), l.states.size() * 8);
+    if (pis) std::memcpy(pis, l.pi.data(), l.pi.size() * 4);
+    if (vs) std::memcpy(vs, l.v.data(), l.v.size() * 4);
+    return AZ_OK;
+}
+
+// ---- the collective of the sharded Coach loop ---------------------------------------------------------------------------------
+#define NCCLCHK(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) return fail(e, AZ_ERR_HIP, std::string("RCCL: ") + g_rccl.GetErrorString(_r) + " at " #expr); } while (0)
+
+az_status az_comm_unique_id(az_engine* e, uint8_t id[AZ_COMM_ID_BYTES]) {
+    if (!e || !id) return AZ_ERR_BAD_ARGUMENT;
+    static_assert(sizeof(ncclUniqueId) == AZ_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    std::string why;
+    if (!g_rccl.load(&why)) return fail(e, AZ_ERR_UNSUPPORTED, why);
+    ncclUniqueId u;
+    NCCLCHK(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return AZ_OK;
+}
+
+az_status az_comm_init(az_engine* e, int32_t rank, int32_t world, const uint8_t id[AZ_COMM_ID_BYTES]) {
+    if (!e || !id || world < 1 || rank < 0 || rank >= world) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_comm_init: bad rank / world");
+    if (e->comm) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_comm_init: the engine already has a communicator (az_comm_destroy first)");
+    std::string why;
+    if (!g_rccl.load(&why)) return fail(e, AZ_ERR_UNSUPPORTED, why);
+    try { HIPCHK(hipSetDevice(e->device)); } catch (const HipFail& f) { return fail_hip(e, f); }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    NCCLCHK(g_rccl.CommInitRank(&e->comm, world, u, rank));
+    e->comm_rank = rank;
+    e->comm_world = world;
+    return AZ_OK;
+}
+
+az_status az_comm_destroy(az_engine* e) {
+    if (!e) return AZ_ERR_BAD_ARGUMENT;
+    if (e->comm) {
+        (void)hipSetDevice(e->device);
+        (void)hipStreamSynchronize(e->stream);
+        NCCLCHK(g_rccl.CommDestroy(e->comm));
+        e->comm = nullptr;
+        e->comm_rank = 0; e->comm_world = 1;
+    }
+    return AZ_OK;
+}
+
+az_status az_allreduce_u64(az_engine* e, uint64_t* values, int32_t n) {
+    if (!e || !values || n < 0 || n > 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_allreduce_u64: bad argument");
+    if (!e->comm) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_allreduce_u64: no communicator (az_comm_init)");
+    if (n == 0) return AZ_OK;
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        DeviceMem mem;
+        unsigned long long* d = mem.alloc<unsigned long long>((size_t)n);
+        HIPCHK(hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+        NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, ncclUint64, ncclSum, e->comm, e->stream));
+        HIPCHK(hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_gather_samples(az_engine* e, const az_samples* local, int32_t dst_rank, az_samples* gathered, int64_t* counts_out) {
+    if (!e || !local) return AZ_ERR_BAD_ARGUMENT;
+    if (!e->comm) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: no communicator (az_comm_init)");
+    const int world = e->comm_world, rank = e->comm_rank;
+    if (dst_rank < -1 || dst_rank >= world) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: dst_rank outside the communicator");
+    const bool receiver = dst_rank < 0 || rank == dst_rank;         // dst_rank = -1: every rank receives (all-gather)
+    const long long n = local->count;
+    if (n < 0 || (n > 0 && (!local->states || !local->pis || !local->zs)))
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: local needs states, pis and zs");
+    if (receiver && (!gathered || !gathered->states || !gathered->pis || !gathered->zs))
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: a receiving rank needs states, pis and zs to receive into");
+    try {
+        HIPCHK(hipSetDevice(e->device));
+        hipStream_t s = e->stream;
+        DeviceMem mem;
+        // 1. all-gather of the per-rank tuple counts
+        long long* d_counts = mem.alloc<long long>((size_t)world + 1);
+        HIPCHK(hipMemcpyAsync(d_counts + world, &n, sizeof n, hipMemcpyHostToDevice, s));
+        NCCLCHK(g_rccl.AllGather(d_counts + world, d_counts, 1, ncclInt64, e->comm, s));
+        std::vector<long long> counts((size_t)world);
+        HIPCHK(hipMemcpyAsync(counts.data(), d_counts, (size_t)world * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        long long total = 0;
+        for (int r = 0; r < world; ++r) { if (counts_out) counts_out[r] = counts[r]; total += counts[r]; }
+        if (receiver && gathered->capacity < total) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: gathered buffers too small");
+        // 2. pack this rank's tuples (inputs may be host or device memory)
+        ulonglong2* d_st = mem.alloc<ulonglong2>((size_t)n);
+        float* d_pi = mem.alloc<float>((size_t)n * 7);
+        float* d_z = mem.alloc<float>((size_t)n);
+        PackedSample* d_mine = mem.alloc<PackedSample>((size_t)n);
+        if (n > 0) {
+            HIPCHK(hipMemcpyAsync(d_st, local->states, (size_t)n * 16, hipMemcpyDefault, s));
+            HIPCHK(hipMemcpyAsync(d_pi, local->pis, (size_t)n * 28, hipMemcpyDefault, s));
+            HIPCHK(hipMemcpyAsync(d_z, local->zs, (size_t)n * 4, hipMemcpyDefault, s));
+            hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_st, d_pi, d_z, d_mine, n);
+        }
+        // 3. ONE exchange (a grouped gatherv): a receiving rank posts a receive per peer, a sending rank one send per receiver
+        PackedSample* d_all = receiver ? mem.alloc<PackedSample>((size_t)total) : nullptr;
+        NCCLCHK(g_rccl.GroupStart());
+        long long off = 0;
+        for (int r = 0; r < world; ++r) {
+            if (receiver) {
+                if (r != rank && counts[r] > 0) NCCLCHK(g_rccl.Recv(d_all + off, (size_t)counts[r] * sizeof(PackedSample), ncclUint8, r, e->comm, s));
+                if (r == rank && n > 0) HIPCHK(hipMemcpyAsync(d_all + off, d_mine, (size_t)n * sizeof(PackedSample), hipMemcpyDeviceToDevice, s));
+            }
+            if (r != rank && n > 0 && (dst_rank < 0 || r == dst_rank)) NCCLCHK(g_rccl.Send(d_mine, (size_t)n * sizeof(PackedSample), ncclUint8, r, e->comm, s));
+            off += counts[r];
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+        if (receiver) {
+            ulonglong2* o_st = mem.alloc<ulonglong2>((size_t)total);
+            float* o_pi = mem.alloc<float>((size_t)total * 7);
+            float* o_z = mem.alloc<float>((size_t)total);
+            if (total > 0) hipLaunchKernelGGL(k_unpack_samples, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_all, o_st, o_pi, o_z, total);
+            HIPCHK(hipStreamSynchronize(s));
+            if (total > 0) {
+                HIPCHK(hipMemcpy(gathered->states, o_st, (size_t)total * 16, hipMemcpyDefault));
+                HIPCHK(hipMemcpy(gathered->pis, o_pi, (size_t)total * 28, hipMemcpyDefault));
+                HIPCHK(hipMemcpy(gathered->zs, o_z, (size_t)total * 4, hipMemcpyDefault));
+            }
+            gathered->count = total;
+        } else {
+            HIPCHK(hipStreamSynchronize(s));
+            if (gathered) gathered->count = 0;
+        }
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }

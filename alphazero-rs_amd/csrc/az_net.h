@@ -39,6 +39,9 @@ struct Layout {
 struct NetProfile {          // filled when profiling is on; flops = what the matrix cores were asked to do (a layer that
     double conv2_ms = 0, conv2_flops = 0, total_ms = 0, total_flops = 0;   // runs as a table lookup contributes time, not flops)
     double conv3_ms = 0, conv3_flops = 0;
+    double conv4_ms = 0, conv4_flops = 0;      // conv4 alone
+    double fc_ms = 0, fc_flops = 0;            // fc1 + fc2 + heads
+    double rows = 0;                           // executed rows of the timed forwards
     double conv2_bytes = 0;  // conv2 as a table: table rows gathered + activation rows written (algorithmic bytes)
     uint64_t launches = 0;
 };
@@ -60,23 +63,31 @@ bool convnet_get_params(const ConvNet* n, float* host_params, int64_t count);
 void convnet_init_random(ConvNet* n, uint64_t seed);
 // fold finished profile records into *prof (call after the workspace's stream has been synchronised)
 void netws_resolve_profile(NetWorkspace* ws, NetProfile* prof);
-// kernel-variant switches for A/B measurements (az_set_option "gemm_variant", "conv4_big", "conv1_table")
-void convnet_set_variant(int v);
-void convnet_set_conv4_big(int v);
-void convnet_set_conv1_table(int v);
-void convnet_set_conv2_table(int v);
-void convnet_set_fc_ring(int v);
-void convnet_set_conv3_ring(int v);
-void convnet_set_conv3_small(int v);
-void convnet_set_conv3_pipe(int v);
-void convnet_set_conv2_pipe(int v);
-void convnet_set_ring_max_tiles(int v);
-void convnet_set_ring_tile(int layer, int tile);
+// Kernel-set switches of the conv net (az_set_option).  They live in the az_engine that was handed to az_set_option and are passed
+// down with every forward: one engine's option never changes another engine's results.  The shipped library (built without
+// -DAZ_DIAG) only honours conv2_table 0 / 1 and conv3_small 0 / 1; everything else selects superseded kernel generations, forced tiles,
+// clock-stamp builds or timing ablations that compute WRONG results, which are compiled into libaz_engine_diag.so only (tools/).
+struct NetOptions {
+    int conv2_table = 1;    // 1: conv1 + conv2 as table gathers (k_conv2_table_x); 0: conv2 as the MFMA implicit GEMM (same function, other rounding)
+    int conv3_small = 1;    // conv3 of a small expected batch on the 4-stage LDS-DMA ring (bit-identical)
+    // ---- diagnostic library only ----
+    int gemm_variant = 5;   // 0 128x128 register-staged tiles everywhere; 1 / 2 256x256 LDS-DMA tiles; 3 conv2 image-resident, one 8-wave
+                            // workgroup per CU; 5 the shipped set; 11-17 timing ablations of variant 2 (WRONG results)
+    int conv1_table = 1;    // conv2 as a GEMM gathers its image from the conv1 table (1) / runs k_conv1 into act1 (0)
+    int conv2_pipe = 1;     // conv2 as a GEMM: k_conv_same_pipe (1) / round 1's k_conv_img2 (0)
+    int conv3_pipe = 1;     // conv3: 1 k_conv_valid_pipe with interleaved fragment reads; 2 without; 0 round 1's kernel; 3 clock stamps;
+                            // 9-15 its timing ladder (WRONG results)
+    int conv3_ring = 0;     // force conv3 onto the ring (1 / 2: 128-row tiles with 2 / 4 stages, 3: device-picked tile)
+    int conv4_big = 0;      // conv4 on the 256x256 kernel (1 always, 2 from 4096 rows)
+    int fc_ring = 1;        // 1 ring with the tile picked on the device; 2 picked on the host; 3 plain 128-row ring; 0 register-staged tiles
+    int ring_tile[6] = {0, 0, 0, 0, 0, 0};   // per layer: forced BM * 10 + NS
+};
 // diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop
 bool netws_read_clock_stamps(NetWorkspace* ws, unsigned long long* out2048);
 // forward for rows [0, *eb.n) of model n in workspace ws; n_rows_hint = host-side upper bound used to size the grids.
 // If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
 // n_rows_typ = expected row count (kernel / tile choice only; 0 = n_rows_hint).
-void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int n_rows_hint, int n_rows_typ, hipStream_t s, NetProfile* prof);
+void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int n_rows_hint, int n_rows_typ, hipStream_t s, NetProfile* prof,
+                     const NetOptions& opt);
 
 }  // namespace az

@@ -187,58 +187,6 @@ __global__ __launch_bounds__(64) void k_conv1_table(const float* __restrict__ w 
 // One wave per (board, board row): lanes 0..20 compute the patterns of the three rows of neighbours, then the wave walks the
 // row's 7 output positions; a lane owns 8 channels (16-byte f16 loads, one 16-byte bf16 store).  The rows of pattern 0 (an
 // empty neighbourhood -- the most frequent one by far) are staged in LDS once per block.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void k_conv2_table(const EvalBatch eb, const uint16_t* __restrict__ U /*[19683][9][C] f16*/,
-                                                     const float* __restrict__ bias /*[C]*/, uint16_t* __restrict__ out /*[n][42][C] bf16*/,
-                                                     int C) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char u0_lds[];       // U[0][0..8][C] f16
-    for (int i = threadIdx.x; i < 9 * C / 8; i += blockDim.x) ((uint4*)u0_lds)[i] = ((const uint4*)U)[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint32_t items = *eb.n * 6u;
-    const uint32_t wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
-    const int cg = C / 8;
-    for (uint32_t it = wave0; it < items; it += nwaves) {
-        const uint32_t b = it / 6u;
-        const int y = (int)(it - b * 6u);
-        const ulonglong2 sv = eb.state[b];
-        const int ly = y - 1 + (lane < 21 ? lane / 7 : 0), lx = lane < 21 ? lane % 7 : 0;
-        const uint32_t mypat = (ly >= 0 && ly < 6) ? conv1_pattern(sv.x, sv.y, ly, lx) : 0u;
-        for (int x = 0; x < 7; ++x) {
-            uint32_t row[9];                       // table row (pattern * 9 + tap) of every in-board tap, else ~0
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ky = t / 3, qy = y + ky - 1, qx = x + t % 3 - 1;
-                const bool in = qy >= 0 && qy < 6 && qx >= 0 && qx < 7;
-                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)mypat, in ? ky * 7 + qx : 0);
-                row[t] = in ? pq * 9u + (uint32_t)t : 0xFFFFFFFFu;
-            }
-            for (int c8 = lane; c8 < cg; c8 += 64) {
-                f16x8 u[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    if (row[t] == 0xFFFFFFFFu) continue;
-                    if (row[t] < 9u) u[t] = *(const f16x8*)(u0_lds + ((size_t)row[t] * C + (size_t)c8 * 8) * 2);
-                    else u[t] = *(const f16x8*)(U + ((size_t)row[t] * C + (size_t)c8 * 8));
-                }
-                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 9; ++t)                 // taps in (ky, kx) order: the fixed summation order of a row
-                    if (row[t] != 0xFFFFFFFFu) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] += (float)u[t][i];
-                    }
-                const float4 b0 = *(const float4*)(bias + c8 * 8), b1 = *(const float4*)(bias + c8 * 8 + 4);
-                uint4 o;
-                o.x = pack_bf16x2(fmaxf(acc[0] + b0.x, 0.f), fmaxf(acc[1] + b0.y, 0.f));
-                o.y = pack_bf16x2(fmaxf(acc[2] + b0.z, 0.f), fmaxf(acc[3] + b0.w, 0.f));
-                o.z = pack_bf16x2(fmaxf(acc[4] + b1.x, 0.f), fmaxf(acc[5] + b1.y, 0.f));
-                o.w = pack_bf16x2(fmaxf(acc[6] + b1.z, 0.f), fmaxf(acc[7] + b1.w, 0.f));
-                *(uint4*)(out + ((size_t)b * 42 + (size_t)(y * 7 + x)) * C + (size_t)c8 * 8) = o;
-            }
-        }
-    }
-}
 
 // The same gather with the CHANNELS split over the XCDs.  The 181 MB table does not fit the 8 x 4 MiB of L2, and in k_conv2_table
 // every XCD gathers whole 1-KiB rows, so each L2 holds a random eighth of the hot rows and half of the gathered bytes come from
@@ -589,11 +537,6 @@ __device__ __forceinline__ void gemm_ring_body(const GemmDesc& d, unsigned char*
     }
 }
 
-template <int LAYER, int NS, int BM = 128>
-__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BM * 128 + 16384)];
-    gemm_ring_body<NS, BM>(d, smem, (int)(*d.n_dev) * d.rows_per_sample);
-}
 
 // Tile rows chosen ON THE DEVICE from the batch's row count (the host only knows an estimate when it launches).  A workgroup's time
 // grows with its tile, a launch's with its ROUNDS of workgroup slots (NS = 4: one workgroup per CU, 256 slots; NS = 2: two, 512), so
@@ -638,190 +581,9 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring_auto(const
 // writes 1 KiB = 8 tile rows x 128 B linearly, so the XOR swizzle (chunk c of row r at slot c ^ (r&7)) is applied
 // to the per-lane SOURCE address and again on the fragment reads.  Two 64 KiB LDS buffers; the next K-step's DMA is
 // issued before this K-step's MFMAs and retired by vmcnt(0) + barrier at the end of the step.
-constexpr int HBM_ = 256, HBN_ = 256;
+[[maybe_unused]] constexpr int HBM_ = 256;
+constexpr int HBN_ = 256;
 
-// ABLATE != 0 are timing experiments (WRONG results; tools/net_bench.py, profiles/README.md): 1 no DMA in the loop, 2 no MFMA,
-// 3 clock stamps, 4 no DMA + no fragment reads, 5 = 4 without the barrier, 6 DMA never waited for, 7 loads to registers
-template <int LAYER, int PIPE, int ABLATE = 0>
-__global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (HBM_ + HBN_) * 128];
-    const int M = (int)(*d.n_dev) * d.rows_per_sample;
-    const int ntaps = d.K / d.cin;
-    const int NT = d.N / HBN_;
-    // XCD-aware order (blocks b and b+8 share an XCD): the NT column tiles of a row tile run back to back on one XCD
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
-    if (m0 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    // DMA map: instruction q of wave w fills tile rows (q*8+w)*8 .. +7; lane -> row (lane>>3), slot (lane&7)
-    const int lrow = lane >> 3;
-    const int chunk = (lane & 7) ^ lrow;
-    auto row_off = [&](int q) -> uint32_t {
-        int m = m0 + (q * 8 + wave) * 8 + lrow;
-        m = m < M ? m : M - 1;
-        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
-        const int y = r / d.out_w, x = r - y * d.out_w;
-        return (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8);
-    };
-    const uint32_t a_off0 = row_off(0), a_off1 = row_off(1), a_off2 = row_off(2), a_off3 = row_off(3);
-    const uint32_t b_off0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8);
-    const uint32_t b_step = 64u * (uint32_t)d.K;
-    const uint32_t a_ob0 = a_off0 * 2u, a_ob1 = a_off1 * 2u, a_ob2 = a_off2 * 2u, a_ob3 = a_off3 * 2u;     // bytes
-    const uint32_t b_ob0 = b_off0 * 2u, b_ob1 = (b_off0 + b_step) * 2u, b_ob2 = (b_off0 + 2u * b_step) * 2u,
-                   b_ob3 = (b_off0 + 3u * b_step) * 2u;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-    // K-step walker (channel block outer, tap inner) kept in scalars and advanced with adds and compares only: the
-    // straightforward kt -> (cb, tap, ky, kx) needs two runtime integer divisions per K-step per wave, which showed
-    // up as 10x SQ_ACTIVE_INST_SCA (257 cycles per wave per K-step) in the PMC profile.
-    int ks_tap = 0, ks_kx = 0;
-    uint32_t ks_c0 = 0, ks_toff = 0, ks_kk = 0;
-#define AZ_KSTEP_ADVANCE()                                                                              \
-    {                                                                                                   \
-        ++ks_tap; ++ks_kx; ks_toff += (uint32_t)d.in_c; ks_kk += (uint32_t)d.cin;                       \
-        if (ks_kx == d.tap_w) { ks_kx = 0; ks_toff += (uint32_t)((d.in_w - d.tap_w) * d.in_c); }        \
-        if (ks_tap == ntaps) { ks_tap = 0; ks_kx = 0; ks_c0 += GBK; ks_toff = ks_c0; ks_kk = ks_c0; }   \
-    }
-    // DMA of the K-step the walker points at, into LDS buffer buf_; then advance the walker
-#define AZ_DMA(kt_, buf_)                                                                               \
-    {                                                                                                   \
-        /* wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: the saddr form, no 64-bit VALU adds */ \
-        const char* abase = (const char*)(d.A + ks_toff);                                               \
-        const char* wbase = (const char*)(d.W + ks_kk);                                                 \
-        unsigned char* la = smem + (buf_) * 65536 + wave * 1024;                                        \
-        unsigned char* lb = la + 32768;                                                                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob0), (lds_ptr)(la), 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob1), (lds_ptr)(la + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob2), (lds_ptr)(la + 16384), 16, 0, 0);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(abase + a_ob3), (lds_ptr)(la + 24576), 16, 0, 0);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, 0);    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, 0);    \
-        AZ_KSTEP_ADVANCE();                                                                             \
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = d.K / GBK;
-    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
-    AZ_DMA(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned long long st0 = 0, sr0 = 0;
-    if constexpr (ABLATE == 3) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-    // LDS byte offsets of this lane's fragment rows (row-major 128-B rows, XOR-swizzled 16-B slots)
-    const int a_row0 = (wr * 128 + frow) * 128, b_row0 = 32768 + (wc * 64 + frow) * 128;
-    const int coff0 = ((0 + fq) ^ fsw) << 4, coff1 = ((4 + fq) ^ fsw) << 4;
-#define AZ_LDA(dst_, base_, mt0_, coff_)                                                     \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
-        if constexpr (ABLATE == 4 || ABLATE == 5) { asm volatile("" : "+v"(dst_[i_])); }      \
-        else dst_[i_] = *(const bf16x8*)((base_) + a_row0 + ((mt0_) + i_) * 2048 + (coff_)); \
-    }
-#define AZ_LDB(dst_, base_, coff_)                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
-        if constexpr (ABLATE == 4 || ABLATE == 5) { asm volatile("" : "+v"(dst_[i_])); }      \
-        else dst_[i_] = *(const bf16x8*)((base_) + b_row0 + i_ * 2048 + (coff_));            \
-    }
-#define AZ_MMA(mt0_, fb_, fa_)                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                   \
-            if constexpr (ABLATE == 2) { asm volatile("" :: "v"(fb_[j_]), "v"(fa_[i_])); }   \
-            else acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0); \
-        }
-    for (int kt = 0; kt < nk; ++kt) {
-        if (ABLATE != 1 && ABLATE != 4 && ABLATE != 5 && ABLATE != 7 && kt + 1 < nk) AZ_DMA(kt + 1, (kt + 1) & 1);
-        if constexpr (ABLATE == 7) {
-            if (kt + 1 < nk) {      // same addresses and widths, destination = registers (no LDS write)
-                const uint32_t toff = ks_toff, kk = ks_kk;
-                AZ_KSTEP_ADVANCE();
-                uint4 r0 = *(const uint4*)(d.A + a_off0 + toff), r1 = *(const uint4*)(d.A + a_off1 + toff),
-                      r2 = *(const uint4*)(d.A + a_off2 + toff), r3 = *(const uint4*)(d.A + a_off3 + toff),
-                      r4 = *(const uint4*)(d.W + b_off0 + kk), r5 = *(const uint4*)(d.W + b_off0 + b_step + kk),
-                      r6 = *(const uint4*)(d.W + b_off0 + 2 * b_step + kk), r7 = *(const uint4*)(d.W + b_off0 + 3 * b_step + kk);
-                asm volatile("" :: "v"(r0.x ^ r0.y ^ r0.z ^ r0.w), "v"(r1.x ^ r1.y ^ r1.z ^ r1.w), "v"(r2.x ^ r2.y ^ r2.z ^ r2.w),
-                             "v"(r3.x ^ r3.y ^ r3.z ^ r3.w), "v"(r4.x ^ r4.y ^ r4.z ^ r4.w), "v"(r5.x ^ r5.y ^ r5.z ^ r5.w),
-                             "v"(r6.x ^ r6.y ^ r6.z ^ r6.w), "v"(r7.x ^ r7.y ^ r7.z ^ r7.w));
-            }
-        }
-        const unsigned char* sA = smem + (kt & 1) * 65536;
-        if constexpr (PIPE == 0) {
-            const unsigned char* sB = sA + 32768;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int coff = ((ks * 4 + fq) ^ fsw) << 4;
-                bf16x8 fa[8], fb[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff);
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) fa[mt] = *(const bf16x8*)(sA + (wr * 128 + mt * 16 + frow) * 128 + coff);
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
-            }
-        } else {
-            // 4 phases of 16 MFMAs; the fragments of phase p+1 are requested before the MFMAs of phase p issue,
-            // so an LDS round trip is exposed once per K-step (after the barrier) instead of eight times.
-            bf16x8 fbX[4] = {}, fbY[4] = {}, faX[4] = {}, faY[4] = {};
-            AZ_LDB(fbX, sA, coff0);
-            AZ_LDA(faX, sA, 0, coff0);
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_LDA(faY, sA, 4, coff0);
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_MMA(0, fbX, faX);
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_LDB(fbY, sA, coff1);
-            AZ_LDA(faX, sA, 0, coff1);
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_MMA(4, fbX, faY);
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_LDA(faY, sA, 4, coff1);
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_MMA(0, fbY, faX);
-            __builtin_amdgcn_sched_barrier(0);
-            AZ_MMA(4, fbY, faY);
-        }
-        if constexpr (ABLATE != 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (ABLATE == 6) __builtin_amdgcn_s_barrier();
-        else if constexpr (ABLATE != 5) __syncthreads();
-    }
-#undef AZ_LDA
-#undef AZ_LDB
-#undef AZ_MMA
-    if constexpr (ABLATE == 3) {
-        // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6);
-        // the stamps go to a debug buffer nothing else reads
-        const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0 && d.dbg && blockIdx.x < 1024) { d.dbg[2 * blockIdx.x] = st1 - st0; d.dbg[2 * blockIdx.x + 1] = sr1 - sr0; }
-    }
-#undef AZ_DMA
-#undef AZ_KSTEP_ADVANCE
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = m0 + wr * 128 + mt * 16 + frow;
-            if (m >= M) continue;
-            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
-                  r3 = acc[mt][nt][3] + bv.w;
-            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-            uint2 o;
-            o.x = pack_bf16x2(r0, r1);
-            o.y = pack_bf16x2(r2, r3);
-            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
-        }
-    }
-}
 
 // ---- conv2 as an IMAGE-RESIDENT implicit GEMM ----------------------------------------------------------------
 // The 9 filter taps of one 64-channel block read overlapping shifted windows of the same activations.  With an M tile
@@ -832,164 +594,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const GemmDesc d) {
 // K-step.  Same K order (channel block outer, tap inner) and per-row accumulation order as the other kernels.
 constexpr int IMG_NB = 6, IMG_ROWS = IMG_NB * 42, IMG_ZERO_ROW = 252;
 
-template <int LAYER>
-__global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32768];   // img[2] | w[2]
-    const int n_boards = (int)(*d.n_dev);
-    const int M = n_boards * 42;
-    const int C = d.cin;
-    const int NT = d.N / HBN_;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int b0 = mtile * IMG_NB, n0 = ntile * HBN_;
-    if (b0 >= n_boards) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    if (tid < 16) *(uint4*)(smem + (tid >> 3) * 32768 + IMG_ZERO_ROW * 128 + (tid & 7) * 16) = make_uint4(0, 0, 0, 0);
-    // image DMA map: item q of this thread = LDS row q*64 + wave*8 + (lane>>3), slot lane&7 (rows >= 252 are not loaded)
-    const int lrow = lane >> 3;
-    const int chunk = (lane & 7) ^ lrow;
-    auto img_off = [&](int q) -> uint32_t {         // byte offset of this lane's 16 bytes of image row q*64 + wave*8 + lrow
-        int r = q * 64 + wave * 8 + lrow;
-        r = r < IMG_ROWS ? r : IMG_ROWS - 1;
-        int b = b0 + r / 42;
-        b = b < n_boards ? b : n_boards - 1;
-        const int p = r % 42, y = p / 7, x = p - y * 7;
-        return (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8) * 2u;
-    };
-    const uint32_t i_ob0 = img_off(0), i_ob1 = img_off(1), i_ob2 = img_off(2), i_ob3 = img_off(3);
-    const bool i_row3 = 192 + wave * 8 + lrow < IMG_ROWS;
-    const uint32_t b_ob0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
-    const uint32_t b_stepb = 128u * (uint32_t)d.K;                       // 64 weight rows, in bytes
-    const uint32_t b_ob1 = b_ob0 + b_stepb, b_ob2 = b_ob0 + 2u * b_stepb, b_ob3 = b_ob0 + 3u * b_stepb;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-    // wave-uniform base + 32-bit per-lane byte offset (the saddr form of global_load_lds)
-#define AZ_IDMA_W(kk_, buf_)                                                                                 \
-    {                                                                                                        \
-        unsigned char* lb = smem + 65536 + (buf_) * 32768 + wave * 1024;                                     \
-        const char* wbase = (const char*)(d.W + (kk_));                                                      \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 8192), 16, 0, 0);          \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 16384), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 24576), 16, 0, 0);         \
-    }
-#define AZ_IDMA_IMG(cb_)                                                                                     \
-    {                                                                                                        \
-        unsigned char* la = smem + ((cb_) & 1) * 32768 + wave * 1024;                                        \
-        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob0), (lds_ptr)(la), 16, 0, 0);                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob1), (lds_ptr)(la + 8192), 16, 0, 0);          \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob2), (lds_ptr)(la + 16384), 16, 0, 0);         \
-        if (i_row3) __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob3), (lds_ptr)(la + 24576), 16, 0, 0); \
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
-    // per-lane fragment rows: low 16 bits = output row inside the tile, bits 16..24 = tap validity ('same' padding)
-    uint32_t rowmask[8];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int ml = wr * 128 + mt * 16 + frow;
-        const int p = ml % 42, y = p / 7, x = p - y * 7;
-        uint32_t mask = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            if (ml < IMG_ROWS && iy >= 0 && iy < 6 && ix >= 0 && ix < 7) mask |= 1u << t;
-        }
-        rowmask[mt] = (uint32_t)ml | (mask << 16);
-    }
-    const int b_row0 = 65536 + (wc * 64 + frow) * 128;
-    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
-    // A fragment (mt, ks) of the current tap: LDS row = m + dt if the tap is inside the board, else the zero row
-#define AZ_ILDA(dst_, img_, mt0_, ks_)                                                                       \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
-        const uint32_t rm_ = rowmask[(mt0_) + i_];                                                           \
-        const int r_ = ((rm_ >> tapbit) & 1u) ? (int)(rm_ & 0xFFFFu) + dt : IMG_ZERO_ROW;                    \
-        dst_[i_] = *(const bf16x8*)((img_) + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));               \
-    }
-#define AZ_ILDB(dst_, wb_, coff_)                                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
-        dst_[i_] = *(const bf16x8*)((wb_) + b_row0 + i_ * 2048 + (coff_));
-#define AZ_IMMA(mt0_, fb_, fa_)                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
-            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
-    const int ncb = C / 64;
-    const int nk = ncb * 9;
-    AZ_IDMA_W(0, 0);
-    AZ_IDMA_IMG(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cb = 0, tap = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool new_img = tap == 0 && cb + 1 < ncb;
-        if (kt + 1 < nk) {
-            const int ntap = tap == 8 ? 0 : tap + 1, ncbi = tap == 8 ? cb + 1 : cb;
-            AZ_IDMA_W(ntap * C + ncbi * 64, (kt + 1) & 1);
-        }
-        if (new_img) AZ_IDMA_IMG(cb + 1);       // issued after the weights: stays in flight over this step's wait
-        const unsigned char* sI = smem + (cb & 1) * 32768;
-        const unsigned char* sW = smem + (kt & 1) * 32768;       // b_row0 already carries the 64 KiB image offset
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int dt = (ky - 1) * 7 + (kx - 1);
-        const int tapbit = 16 + tap;
-        // 4 clusters of 16 MFMAs; the fragments of the next cluster are requested before the current one issues
-        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
-        AZ_ILDB(fbX, sW, coffB0);
-        AZ_ILDA(faX, sI, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_ILDA(faY, sI, 4, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(0, fbX, faX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_ILDB(fbY, sW, coffB1);
-        AZ_ILDA(faX, sI, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(4, fbX, faY);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_ILDA(faY, sI, 4, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(0, fbY, faX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_IMMA(4, fbY, faY);
-        // counted wait: the next weight tile must have landed; the next image (issued after it) may stay in flight
-        if (new_img) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                    // raw: __syncthreads() would drain vmcnt to 0
-        __builtin_amdgcn_sched_barrier(0);
-        if (++tap == 9) { tap = 0; ++cb; }
-    }
-#undef AZ_IDMA_W
-#undef AZ_IDMA_IMG
-#undef AZ_ILDA
-#undef AZ_ILDB
-#undef AZ_IMMA
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int ml = wr * 128 + mt * 16 + frow;
-            const int m = b0 * 42 + ml;
-            if (ml >= IMG_ROWS || m >= M) continue;
-            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
-                  r3 = acc[mt][nt][3] + bv.w;
-            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-            uint2 o;
-            o.x = pack_bf16x2(r0, r1);
-            o.y = pack_bf16x2(r2, r3);
-            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
-        }
-    }
-}
 
 // ---- conv2 image-resident, TWO independent workgroups per CU ---------------------------------------------------------
 // k_conv_img's 8 waves share one barrier, so the two waves of every SIMD run in lockstep: both in their MFMA clusters
@@ -1001,169 +605,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_img(const GemmDesc d) {
 // exposed inside a workgroup and covered by the other one).  Same K order: bit-identical.
 constexpr int HBN2_ = 128;
 
-// TABLE: the image rows are gathered from the conv1 table (d.A) by pattern index instead of read from act1.
-template <int LAYER, bool TABLE = false>
-__global__ __launch_bounds__(256, 2) void k_conv_img2(const GemmDesc d) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32768];   // img | w[2] (16 KiB each)
-    const int n_boards = (int)(*d.n_dev);
-    const int M = n_boards * 42;
-    const int C = d.cin;
-    const int NT = d.N / HBN2_;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int b0 = mtile * IMG_NB, n0 = ntile * HBN2_;
-    if (b0 >= n_boards) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    if (tid < 8) *(uint4*)(smem + IMG_ZERO_ROW * 128 + tid * 16) = make_uint4(0, 0, 0, 0);
-    const int lrow = lane >> 3;
-    const int chunk = (lane & 7) ^ lrow;
-    // image DMA map: piece q (0..7) of wave w = LDS rows (q*4 + w)*8 + lrow; rows >= 252 are not loaded
-    uint32_t i_ob[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        int r = (q * 4 + wave) * 8 + lrow;
-        r = r < IMG_ROWS ? r : IMG_ROWS - 1;
-        int b = b0 + r / 42;
-        b = b < n_boards ? b : n_boards - 1;
-        const int p = r % 42, y = p / 7, x = p - y * 7;
-        if constexpr (TABLE) {
-            const ulonglong2 st = d.states[b];
-            i_ob[q] = (conv1_pattern(st.x, st.y, y, x) * (uint32_t)C + (uint32_t)chunk * 8u) * 2u;
-        } else {
-            i_ob[q] = (uint32_t)(((b * 8 + y + 1) * 9 + x + 1) * C + chunk * 8) * 2u;
-        }
-    }
-    const bool i_last_ok = (7 * 4 + wave) * 8 + lrow < IMG_ROWS;          // only piece 7 can run past row 251
-    // weight DMA map: piece q (0..3) of wave w = tile rows (q*4 + w)*8 + lrow
-    const uint32_t b_ob0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
-    const uint32_t b_stepb = 64u * (uint32_t)d.K;                        // 32 weight rows, in bytes
-    const uint32_t b_ob1 = b_ob0 + b_stepb, b_ob2 = b_ob0 + 2u * b_stepb, b_ob3 = b_ob0 + 3u * b_stepb;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-#define AZ_2DMA_W(kk_, buf_)                                                                                 \
-    {                                                                                                        \
-        unsigned char* lb = smem + 32768 + (buf_) * 16384 + wave * 1024;                                     \
-        const char* wbase = (const char*)(d.W + (kk_));                                                      \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0), (lds_ptr)(lb), 16, 0, 0);                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob1), (lds_ptr)(lb + 4096), 16, 0, 0);          \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob2), (lds_ptr)(lb + 8192), 16, 0, 0);          \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob3), (lds_ptr)(lb + 12288), 16, 0, 0);         \
-    }
-#define AZ_2DMA_IMG(cb_)                                                                                     \
-    {                                                                                                        \
-        unsigned char* la = smem + wave * 1024;                                                              \
-        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_)                                                     \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
-        if (i_last_ok) __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[7]), (lds_ptr)(la + 7 * 4096), 16, 0, 0); \
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
-    uint32_t rowmask[8];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int ml = wr * 128 + mt * 16 + frow;
-        const int p = ml % 42, y = p / 7, x = p - y * 7;
-        uint32_t mask = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            if (ml < IMG_ROWS && iy >= 0 && iy < 6 && ix >= 0 && ix < 7) mask |= 1u << t;
-        }
-        rowmask[mt] = (uint32_t)ml | (mask << 16);
-    }
-    const int b_row0 = 32768 + (wc * 64 + frow) * 128;
-    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
-#define AZ_2LDA(dst_, mt0_, ks_)                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
-        const uint32_t rm_ = rowmask[(mt0_) + i_];                                                           \
-        const int r_ = ((rm_ >> tapbit) & 1u) ? (int)(rm_ & 0xFFFFu) + dt : IMG_ZERO_ROW;                    \
-        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
-    }
-#define AZ_2LDB(dst_, wb_, coff_)                                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
-        dst_[i_] = *(const bf16x8*)((wb_) + b_row0 + i_ * 2048 + (coff_));
-#define AZ_2MMA(mt0_, fb_, fa_)                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
-            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
-    const int ncb = C / 64;
-    const int nk = ncb * 9;
-    AZ_2DMA_W(0, 0);
-    AZ_2DMA_IMG(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cb = 0, tap = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            const int ntap = tap == 8 ? 0 : tap + 1, ncbi = tap == 8 ? cb + 1 : cb;
-            AZ_2DMA_W(ntap * C + ncbi * 64, (kt + 1) & 1);
-        }
-        const unsigned char* sW = smem + (kt & 1) * 16384;       // b_row0 already carries the 32 KiB image offset
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int dt = (ky - 1) * 7 + (kx - 1);
-        const int tapbit = 16 + tap;
-        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
-        AZ_2LDB(fbX, sW, coffB0);
-        AZ_2LDA(faX, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_2LDA(faY, 4, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_2MMA(0, fbX, faX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_2LDB(fbY, sW, coffB1);
-        AZ_2LDA(faX, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_2MMA(4, fbX, faY);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_2LDA(faY, 4, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_2MMA(0, fbY, faX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_2MMA(4, fbY, faY);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (++tap == 9) {
-            tap = 0;
-            ++cb;
-            if (cb < ncb) {                    // image switch: everybody is past the barrier, i.e. done with image cb-1
-                AZ_2DMA_IMG(cb);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-        }
-    }
-#undef AZ_2DMA_W
-#undef AZ_2DMA_IMG
-#undef AZ_2LDA
-#undef AZ_2LDB
-#undef AZ_2MMA
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int ml = wr * 128 + mt * 16 + frow;
-            const int m = b0 * 42 + ml;
-            if (ml >= IMG_ROWS || m >= M) continue;
-            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
-                  r3 = acc[mt][nt][3] + bv.w;
-            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-            uint2 o;
-            o.x = pack_bf16x2(r0, r1);
-            o.y = pack_bf16x2(r2, r3);
-            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
-        }
-    }
-}
 
 // ---- k_conv_img2 with the LDS-DMA issued from inline asm and a software-pipelined K-step (conv2 as the MFMA GEMM, "conv2_table" = 0) --
 // Same tile, LDS layout, DMA maps and K order as k_conv_img2 (bit-identical).  What changes is what k_conv_valid_pipe changed for conv3:
@@ -1371,159 +812,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_same_pipe(const GemmDesc d) {
 // fragments are read into registers first, a barrier behind those reads frees the buffer, and the next weight tile is
 // DMA'd under the rest of the step.  A 'valid' conv needs no padding logic: output (y, x) of a board reads image row
 // (y+ky)*IW + (x+kx).  Same K order: bit-identical.
-template <int LAYER, int NB, int IH, int IW, int WN>
-__global__ __launch_bounds__(256, 2) void k_conv_valid_img2(const GemmDesc d) {
-    constexpr int OH = IH - 2, OW = IW - 2, OUT_PER = OH * OW, IN_PER = IH * IW;
-    constexpr int OUT_ROWS = NB * OUT_PER, IMG_R = NB * IN_PER;
-    constexpr int NCOL = WN == 4 ? 256 : 128;
-    constexpr int IMG_BYTES = (IMG_R * 128 + 1023) / 1024 * 1024;
-    constexpr int IPIECES = (IMG_R + 31) / 32, WPIECES = NCOL / 32;       // 1 KiB DMA pieces per wave
-    static_assert(IMG_BYTES + NCOL * 128 <= 81920, "two workgroups must fit a CU's 160 KiB");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[IMG_BYTES + NCOL * 128];   // img | w
-    const int n_boards = (int)(*d.n_dev);
-    const int M = n_boards * OUT_PER;
-    const int C = d.cin;
-    const int NT = d.N / NCOL;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int b0 = mtile * NB, n0 = ntile * NCOL;
-    if (b0 >= n_boards) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = WN == 4 ? 0 : wave >> 1, wc = WN == 4 ? wave : wave & 1;
-    const int lrow = lane >> 3;
-    const int chunk = (lane & 7) ^ lrow;
-    // image DMA: piece q of wave w = LDS rows (q*4 + w)*8 + lrow of the NB boards' IN_PER input rows each
-    uint32_t i_ob[IPIECES];
-#pragma unroll
-    for (int q = 0; q < IPIECES; ++q) {
-        int r = (q * 4 + wave) * 8 + lrow;
-        r = r < IMG_R ? r : IMG_R - 1;
-        int g = b0 * IN_PER + r;
-        g = g < n_boards * IN_PER ? g : n_boards * IN_PER - 1;
-        i_ob[q] = (uint32_t)(g * C + chunk * 8) * 2u;
-    }
-    // weight DMA: piece q of wave w = tile rows (q*4 + w)*8 + lrow
-    const uint32_t b_ob0 = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
-    const uint32_t b_stepb = 64u * (uint32_t)d.K;                        // 32 weight rows, in bytes
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-#define AZ_3DMA_W(kk_)                                                                                       \
-    {                                                                                                        \
-        unsigned char* lb = smem + IMG_BYTES + wave * 1024;                                                  \
-        const char* wbase = (const char*)(d.W + (kk_));                                                      \
-        _Pragma("unroll") for (int q_ = 0; q_ < WPIECES; ++q_)                                               \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(wbase + b_ob0 + (uint32_t)q_ * b_stepb), (lds_ptr)(lb + q_ * 4096), 16, 0, 0); \
-    }
-#define AZ_3DMA_IMG(cb_)                                                                                     \
-    {                                                                                                        \
-        unsigned char* la = smem + wave * 1024;                                                              \
-        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < IPIECES; ++q_)                                               \
-            if ((q_ * 4 + wave) * 8 + lrow < IMG_R)                                                          \
-                __builtin_amdgcn_global_load_lds((gbl_ptr)(ibase + i_ob[q_]), (lds_ptr)(la + q_ * 4096), 16, 0, 0); \
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
-    int rbase[8];                       // image row of tap (0,0) for this lane's row of each of the 8 row tiles
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        int ml = wr * 128 + mt * 16 + frow;
-        ml = ml < OUT_ROWS ? ml : 0;
-        const int bl = ml / OUT_PER, p = ml - bl * OUT_PER, y = p / OW, x = p - y * OW;
-        rbase[mt] = bl * IN_PER + y * IW + x;
-    }
-    const int b_row0 = IMG_BYTES + (wc * 64 + frow) * 128;
-    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
-#define AZ_3LDA(dst_, mt0_, ks_)                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
-        const int r_ = rbase[(mt0_) + i_] + dt;                                                              \
-        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
-    }
-#define AZ_3LDB(dst_, coff_)                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
-        dst_[i_] = *(const bf16x8*)(smem + b_row0 + i_ * 2048 + (coff_));
-#define AZ_3MMA(mt0_, fb_, fa_)                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                     \
-            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
-    const int ncb = C / 64;
-    const int nk = ncb * 9;
-    AZ_3DMA_W(0);
-    AZ_3DMA_IMG(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cb = 0, tap = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int dt = ky * IW + kx;
-        bf16x8 fbX[4], fbY[4], faX[4], faY[4];
-        AZ_3LDB(fbX, coffB0);
-        AZ_3LDB(fbY, coffB1);
-        AZ_3LDA(faX, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the step's weight fragments are in registers: free the buffer
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            const int ntap = tap == 8 ? 0 : tap + 1, ncbi = tap == 8 ? cb + 1 : cb;
-            AZ_3DMA_W(ntap * C + ncbi * 64);
-        }
-        AZ_3LDA(faY, 4, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_3MMA(0, fbX, faX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_3LDA(faX, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_3MMA(4, fbX, faY);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_3LDA(faY, 4, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_3MMA(0, fbY, faX);
-        __builtin_amdgcn_sched_barrier(0);
-        AZ_3MMA(4, fbY, faY);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (++tap == 9) {
-            tap = 0;
-            ++cb;
-            if (cb < ncb) {                    // image switch (single buffer): covered by the CU's other workgroup
-                AZ_3DMA_IMG(cb);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-        }
-    }
-#undef AZ_3DMA_W
-#undef AZ_3DMA_IMG
-#undef AZ_3LDA
-#undef AZ_3LDB
-#undef AZ_3MMA
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 bv = *(const float4*)(d.bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int ml = wr * 128 + mt * 16 + frow;
-            const int m = b0 * OUT_PER + ml;
-            if (ml >= OUT_ROWS || m >= M) continue;
-            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
-                  r3 = acc[mt][nt][3] + bv.w;
-            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
-            uint2 o;
-            o.x = pack_bf16x2(r0, r1);
-            o.y = pack_bf16x2(r2, r3);
-            *(uint2*)(d.out + (size_t)m * d.N + n) = o;
-        }
-    }
-}
 constexpr int C3_NB = 12;     // (conv4 as <L, 19, 4, 5, 4> is bit-identical too and was measured neutral: it stays on k_gemm256)
 
 // ---- the same tile with the LDS-DMA issued from inline asm and a software-pipelined K-step ---------------------------
@@ -1743,6 +1031,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
     }
 }
 
+#ifdef AZ_DIAG
+#include "az_net_diag.inc"
+#endif
+
 // ---- heads: pi = softmax(x W_pi + b), v = tanh(x w_v + b) (connect_four_net.py:93-95) ---------------------
 // one wave per sample; lane holds 8 of the 512 inputs.
 __global__ __launch_bounds__(256) void k_heads(const EvalBatch eb, const uint16_t* __restrict__ x /*[n][512] bf16*/,
@@ -1818,7 +1110,7 @@ struct NetWorkspace {
     std::vector<void*> dev;
     uint16_t *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *fc1o = nullptr, *fc2o = nullptr;
     // profiling: event quads per forward + pinned copies of the batch size
-    struct Rec { hipEvent_t e0, e1, e2, e2b, e3; uint32_t* n; int table2; };   // e1..e2 conv2, e2..e2b conv3
+    struct Rec { hipEvent_t e0, e1, e2, e2b, e2c, e3; uint32_t* n; int table2; };   // e1..e2 conv2, e2..e2b conv3, e2b..e2c conv4, e2c..e3 fc1 + fc2 + heads
     std::vector<Rec> open;
     std::vector<hipEvent_t> ev_pool;
     uint32_t* pinned_n = nullptr;          // host copy of d_nlog (one copy per resolve, not one per forward)
@@ -1907,7 +1199,7 @@ static bool netws_need_act1(NetWorkspace* n) {
 void netws_destroy(NetWorkspace* n) {
     if (!n) return;
     for (void* p : n->dev) (void)hipFree(p);
-    for (auto& r : n->open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); (void)hipEventDestroy(r.e2b); (void)hipEventDestroy(r.e3); }
+    for (auto& r : n->open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); (void)hipEventDestroy(r.e2b); (void)hipEventDestroy(r.e2c); (void)hipEventDestroy(r.e3); }
     for (auto e : n->ev_pool) (void)hipEventDestroy(e);
     if (n->pinned_n) (void)hipHostFree(n->pinned_n);
     delete n;
@@ -2021,69 +1313,76 @@ void convnet_init_random(ConvNet* net, uint64_t seed) {
     convnet_set_params(net, p.data(), L.total);
 }
 
-int g_gemm_variant = 5;   // A/B switch (az_set_option "gemm_variant"); variants 0, 1, 2, 3, 5 are bit-identical:
-                          // 0: 128x128 register-staged tiles everywhere; 1: 256x256 LDS-DMA tiles for conv2/conv3(/conv4);
-                          // 2: + hand-phased fragment prefetch; 3: conv2 image-resident, one 8-wave workgroup per CU
-                          // (k_conv_img), rest as 2; 5 (default): conv2 and conv3 image-resident, two 4-wave workgroups per
-                          // CU (k_conv_img2, k_conv3_img2), rest as 2; 11-17: timing ablations / clock stamps of variant 2 (WRONG results,
-                          // tools/ only).  Rejected and removed after measurement (numbers in profiles/README.md, code in
-                          // git history): 4-stage ring, XCD column remap, third weight buffer, late / spread DMA issue, mid
-                          // barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail
-                          // split, cross-step fragment prefetch, weights straight into registers.
-int g_conv3_ring = 0;
-int g_conv3_small = 1;      // "conv3_small": conv3 of a small expected batch on the 4-stage ring (see launch_gemm); bit-identical
-int g_conv2_pipe = 1;       // conv2 as a GEMM ("conv2_table" = 0): 1 k_conv_same_pipe, 0 k_conv_img2 (round 1); bit-identical ("conv2_pipe")
-int g_conv3_pipe = 1;       // conv3: 1 (default) k_conv_valid_pipe, fragment reads interleaved into the MFMA clusters; 2 the same without the interleave;
-                            // 0 k_conv_valid_img2 (round 1); all bit-identical.  3: 1 with per-segment clock stamps (tools/seg_probe.py); 11-15: the
-                            // timing ladder of 1 (WRONG results): no image switch, + no wait for the weight DMA, + no weight DMA, + no barriers, + no fragment reads
-void convnet_set_conv3_ring(int v) { g_conv3_ring = v; }
-void convnet_set_conv3_small(int v) { g_conv3_small = v; }
-void convnet_set_conv3_pipe(int v) { g_conv3_pipe = v; }
-void convnet_set_conv2_pipe(int v) { g_conv2_pipe = v; }
-int g_fc_ring = 1;        // 128x128 LDS-DMA ring kernel for under-filled grids (az_set_option "fc_ring"); bit-identical
-int g_ring64_max_tiles = 512;   // ... 64-row tiles for the FCs when twice the 128-row tile count is at most this ("fc_ring" = 3: never)
-int g_ring_max_tiles = 256;   // ... when the layer has at most this many tiles ("ring_max_tiles")
-int g_ring_tile[6] = {0, 0, 0, 0, 0, 0};   // per layer: 0 = automatic, else BM * 10 + NS forced ("ring_tile" = layer * 10000 + BM * 10 + NS; measurement)
-int g_conv4_big = 0;      // conv4 on the 256x256 LDS-DMA kernel: 0 (default) never -- the ring tiles are faster at every batch size --, 1 always, 2 when the batch bound >= 4096
-
-template <int LAYER>
+// ---- kernel choice per layer ----------------------------------------------------------------------------------------------------
 // rows_hint = upper bound on the batch (the grids must cover it: tiles past the device-side count exit at once);
-// rows_typ = what the batch is expected to hold (picks the kernel / tile shape; any value is correct, a good one is fast)
-static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStream_t s) {
-    const int v = g_gemm_variant;
+// rows_typ = what the batch is expected to hold (picks the kernel / tile family; any value is correct, a good one is fast).
+// Rejected and removed after measurement (numbers in profiles/README.md, code in git history): XCD column remap, third weight buffer,
+// late / spread DMA issue, mid barrier, 32x32x16 MFMA shape, non-temporal cache policy, wave stagger, persistent tiles, tail split,
+// cross-step fragment prefetch, weights straight into registers, a double-buffered conv3 image, one wave per SIMD.
+
+// Small batches (the arena, the drain of a self-play call, single-tree calls): the image-resident conv3 kernel is a chain of 72 K-steps of
+// ~0.8 us for a workgroup alone on its CU (70 us whatever the rows); the ring with 4 stages in flight walks the same K in ~32 us up to
+// 128 rows and 49 us at 384 (tools/rows_sweep.py).  Taken when the expected rows fit one workgroup per CU.
+static bool conv3_is_small(const GemmDesc& d, int rows_hint, int rows_typ) {
+    return (rows_typ > 0 ? (long long)rows_typ * 115 / 100 : (long long)rows_hint) * d.rows_per_sample <= 8192;      // no estimate: the bound itself
+}
+// conv2 as a GEMM ("conv2_table" = 0), image-resident
+template <bool TABLE>
+static void launch_conv2_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
+    const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
+    const int t8 = (tiles + 7) / 8 * 8;
+    hipLaunchKernelGGL((k_conv_same_pipe<1, TABLE>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+}
+static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s) {
+    const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
+    const int t8 = (tiles + 7) / 8 * 8;
+    hipLaunchKernelGGL((k_conv_valid_pipe<2, C3_NB, 6, 7, false, 0, true>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
+}
+// The LDS-DMA ring with the tile rows picked on the device.  The host picks the FAMILY from its estimate (NS = 4: one workgroup per CU,
+// for grids of at most 256 tiles; the estimate + 15 %: a batch over the limit would pay a whole second round), the kernel picks the
+// tile rows from the exact count (measured: tools/ring_tiles.py, profiles/README.md).
+template <int LAYER>
+static void launch_ring_auto(const GemmDesc& d, int rows_hint, int rows_typ, hipStream_t s, bool force_one_per_cu = false) {
+    const int m_est = (int)((rows_typ > 0 ? (long long)rows_typ * 115 / 100 : (long long)rows_hint) * d.rows_per_sample), ncol = d.N / GBN;
+    const bool conv = d.tap_w > 1;
+    const bool one_per_cu = force_one_per_cu || (m_est + (conv ? 95 : 127)) / (conv ? 96 : 128) * ncol <= 256;
+    const int bmin = one_per_cu ? 64 : 96;                                   // the grid covers the smallest tile of the family
+    const int mtb = ((rows_hint * d.rows_per_sample + bmin - 1) / bmin + 7) / 8 * 8;
+    if (one_per_cu) hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 4>), dim3(mtb * ncol), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 2>), dim3(mtb * ncol), dim3(256), 0, s, d);
+}
+
+#ifdef AZ_DIAG
+// The diagnostic library's launcher: every kernel generation and forced tile behind the NetOptions switches.  Returns false when the
+// options ask for nothing special, i.e. the shipped choice below applies.
+template <int LAYER>
+static bool launch_gemm_diag(const GemmDesc& d, int rows_hint, int rows_typ, hipStream_t s, const NetOptions& o) {
+    const int v = o.gemm_variant;
     if ((v == 3 || v == 5) && LAYER == 1 && d.N % HBN_ == 0 && d.cin % 64 == 0) {
         const int tiles = (rows_hint + IMG_NB - 1) / IMG_NB;
         const int t8 = (tiles + 7) / 8 * 8;
-        if (v == 5 && g_conv2_pipe && d.states) hipLaunchKernelGGL((k_conv_same_pipe<LAYER, true>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
-        else if (v == 5 && g_conv2_pipe) hipLaunchKernelGGL((k_conv_same_pipe<LAYER>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
-        else if (v == 5 && d.states) hipLaunchKernelGGL((k_conv_img2<LAYER, true>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
+        if (v == 5 && o.conv2_pipe) return false;
+        if (v == 5 && d.states) hipLaunchKernelGGL((k_conv_img2<LAYER, true>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
         else if (v == 5) hipLaunchKernelGGL((k_conv_img2<LAYER>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL((k_conv_img<LAYER>), dim3(t8 * (d.N / HBN_)), dim3(512), 0, s, d);
-        return;
+        return true;
     }
-    const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && !g_ring_tile[3] && (g_conv4_big == 1 || (g_conv4_big == 2 && rows_typ >= 4096)))) &&
+    const bool big = v >= 1 && (LAYER == 1 || LAYER == 2 || (LAYER == 3 && !o.ring_tile[3] && (o.conv4_big == 1 || (o.conv4_big == 2 && rows_typ >= 4096)))) &&
                      d.N % HBN_ == 0;
-    // Small batches (the arena, the drain of a self-play call, single-tree calls): the image-resident kernel is a chain of 72 K-steps of
-    // ~0.8 us for a workgroup alone on its CU (70 us whatever the rows); the ring with 4 stages in flight walks the same K in ~32 us up to
-    // 128 rows and 49 us at 384 (tools/rows_sweep.py, OPT=conv3_ring=3).  Taken when the expected rows fit one workgroup per CU.
-    const bool small3 = LAYER == 2 && g_conv3_small && !g_conv3_ring &&
-                        (rows_typ > 0 ? (long long)rows_typ * 115 / 100 : (long long)rows_hint) * d.rows_per_sample <= 8192;      // no estimate: the bound itself
-    if constexpr (LAYER == 2) if (v == 5 && (g_conv3_ring || small3)) {      // conv3 on the LDS-DMA ring (im2col from act2): 1 / 2 = 128-row tiles with 2 / 4 stages, 3 = device-picked tile, 4 stages
+    if constexpr (LAYER == 2) if (v == 5 && o.conv3_ring) {      // conv3 forced onto the ring (im2col from act2): 1 / 2 = 128-row tiles with 2 / 4 stages, 3 = device-picked tile
         const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
         const int mt8 = (mt + 7) / 8 * 8;
-        if (g_conv3_ring == 3 || small3) {
-            const int mtb = ((rows_hint * d.rows_per_sample + 63) / 64 + 7) / 8 * 8;
-            hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 4>), dim3(mtb * (d.N / GBN)), dim3(256), 0, s, d);
-        } else if (g_conv3_ring == 2) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
+        if (o.conv3_ring == 3) launch_ring_auto<LAYER>(d, rows_hint, rows_typ, s, true);
+        else if (o.conv3_ring == 2) hipLaunchKernelGGL((k_gemm_ring<LAYER, 4>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(mt8 * (d.N / GBN)), dim3(256), 0, s, d);
-        return;
+        return true;
     }
-    if constexpr (LAYER == 2) if (v == 5 && d.N % 128 == 0 && d.cin % 64 == 0 && d.rows_per_sample == 20) {   // conv3 image-resident
+    if constexpr (LAYER == 2) if (v == 5 && d.rows_per_sample == 20) {   // conv3 image-resident (or, for a small expected batch, the shipped ring choice)
+        if ((o.conv3_small && conv3_is_small(d, rows_hint, rows_typ)) || o.conv3_pipe == 1) return false;
         const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
         const int t8 = (tiles + 7) / 8 * 8;
         const dim3 g3(t8 * (d.N / 128)), b3(256);
-        switch (g_conv3_pipe) {
-            case 1: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 0, true>), g3, b3, 0, s, d); break;
+        switch (o.conv3_pipe) {
             case 2: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 0, false>), g3, b3, 0, s, d); break;
             case 3: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, true, 0, true>), g3, b3, 0, s, d); break;
             case 10: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, -1, true>), g3, b3, 0, s, d); break;
@@ -2095,8 +1394,9 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
             case 15: hipLaunchKernelGGL((k_conv_valid_pipe<LAYER, C3_NB, 6, 7, false, 5, true>), g3, b3, 0, s, d); break;
             default: hipLaunchKernelGGL((k_conv_valid_img2<LAYER, C3_NB, 6, 7, 2>), g3, b3, 0, s, d); break;
         }
-        return;
+        return true;
     }
+    if (v == 5 && !big && o.fc_ring == 1 && !(LAYER >= 3 && o.ring_tile[LAYER])) return false;
     if (big) {
         const int mt = (rows_hint * d.rows_per_sample + HBM_ - 1) / HBM_;
         const int mt8 = (mt + 7) / 8 * 8;
@@ -2110,15 +1410,12 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
         else if (v == 16) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 6>), grid, block, 0, s, d);
         else if (v == 17) hipLaunchKernelGGL((k_gemm256<LAYER, 1, 7>), grid, block, 0, s, d);
         else hipLaunchKernelGGL((k_gemm256<LAYER, 1>), grid, block, 0, s, d);
-        return;
+        return true;
     }
     const int mt = (rows_hint * d.rows_per_sample + GBM - 1) / GBM;
     const int mt8 = (mt + 7) / 8 * 8;
     const int grid = mt8 * (d.N / GBN);
-    // under-filled grids (fewer tiles than ~2 per CU) are latency-bound: the LDS-DMA ring hides the round trips
-    // LDS-DMA ring instead of register staging (bit-identical).  A grid that fits one round of one workgroup per CU is
-    // latency / fetch bound: 4 stages (128 KiB) in flight; otherwise 2 stages (64 KiB) so that two workgroups share a CU.
-    if (v == 5 && g_fc_ring) {
+    if (v == 5 && o.fc_ring) {
         auto ring = [&](auto bm_c, auto ns_c) {
             constexpr int BM = decltype(bm_c)::value, NS = decltype(ns_c)::value;
             const int mtb = ((rows_hint * d.rows_per_sample + BM - 1) / BM + 7) / 8 * 8;
@@ -2126,26 +1423,19 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
         };
         using std::integral_constant;
         if constexpr (LAYER >= 3) {
-            const int f = g_ring_tile[LAYER];
-            if (f) {
-                switch (f) {
-                    case 642: ring(integral_constant<int, 64>{}, integral_constant<int, 2>{}); return;
-                    case 644: ring(integral_constant<int, 64>{}, integral_constant<int, 4>{}); return;
-                    case 962: ring(integral_constant<int, 96>{}, integral_constant<int, 2>{}); return;
-                    case 964: ring(integral_constant<int, 96>{}, integral_constant<int, 4>{}); return;
-                    case 1282: ring(integral_constant<int, 128>{}, integral_constant<int, 2>{}); return;
-                    case 1284: ring(integral_constant<int, 128>{}, integral_constant<int, 4>{}); return;
-                    case 1602: ring(integral_constant<int, 160>{}, integral_constant<int, 2>{}); return;
-                    case 1922: ring(integral_constant<int, 192>{}, integral_constant<int, 2>{}); return;
-                    default: break;
-                }
+            switch (o.ring_tile[LAYER]) {
+                case 642: ring(integral_constant<int, 64>{}, integral_constant<int, 2>{}); return true;
+                case 644: ring(integral_constant<int, 64>{}, integral_constant<int, 4>{}); return true;
+                case 962: ring(integral_constant<int, 96>{}, integral_constant<int, 2>{}); return true;
+                case 964: ring(integral_constant<int, 96>{}, integral_constant<int, 4>{}); return true;
+                case 1282: ring(integral_constant<int, 128>{}, integral_constant<int, 2>{}); return true;
+                case 1284: ring(integral_constant<int, 128>{}, integral_constant<int, 4>{}); return true;
+                case 1602: ring(integral_constant<int, 160>{}, integral_constant<int, 2>{}); return true;
+                case 1922: ring(integral_constant<int, 192>{}, integral_constant<int, 2>{}); return true;
+                default: break;
             }
         }
-        // Tile choice from the expected row count (measured: tools/ring_tiles.py, profiles/README.md).  A workgroup's time grows with its
-        // tile, a launch's with its ROUNDS of workgroup slots (NS = 4: one per CU, 256 slots; NS = 2: two per CU, 512), so the best
-        // tile is the smallest that still fits the expected rows into whole rounds: conv4 at 3072 rows takes 120 us on 128-row tiles
-        // (576 workgroups: a second round for 64 of them) and 78 us on 160-row tiles (464 workgroups).
-        if (g_fc_ring == 2) {       // A/B: the tile picked on the HOST from its estimate of the row count (same rule)
+        if (o.fc_ring == 2) {       // A/B: the tile picked on the HOST from its estimate of the row count (same rule)
             const int m_typ = (rows_typ > 0 ? rows_typ : rows_hint) * d.rows_per_sample, ncol = d.N / GBN;
             const bool conv = d.tap_w > 1;
             const int ns = (m_typ + (conv ? 95 : 127)) / (conv ? 96 : 128) * ncol <= 256 ? 4 : 2;
@@ -2158,24 +1448,33 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
                 case 1922: ring(integral_constant<int, 192>{}, integral_constant<int, 2>{}); break;
                 default: ring(integral_constant<int, 128>{}, integral_constant<int, 2>{}); break;
             }
-            return;
+            return true;
         }
-        if (g_fc_ring == 1) {
-            // the host picks the FAMILY from its estimate (NS = 4: one workgroup per CU, for grids of at most 256 tiles; the estimate
-            // + 15 %: a batch over the limit would pay a whole second round), the kernel picks the tile rows from the exact count
-            const int m_est = (int)((rows_typ > 0 ? (long long)rows_typ * 115 / 100 : (long long)rows_hint) * d.rows_per_sample), ncol = d.N / GBN;
-            const bool conv = d.tap_w > 1;
-            const bool one_per_cu = (m_est + (conv ? 95 : 127)) / (conv ? 96 : 128) * ncol <= 256;
-            const int bmin = one_per_cu ? 64 : 96;                                   // the grid covers the smallest tile of the family
-            const int mtb = ((rows_hint * d.rows_per_sample + bmin - 1) / bmin + 7) / 8 * 8;
-            if (one_per_cu) hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 4>), dim3(mtb * ncol), dim3(256), 0, s, d);
-            else hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 2>), dim3(mtb * ncol), dim3(256), 0, s, d);
-            return;
-        }
+        if (o.fc_ring == 1) return false;
         hipLaunchKernelGGL((k_gemm_ring<LAYER, 2>), dim3(grid), dim3(256), 0, s, d);     // "fc_ring" = 3: the plain 128-row ring
-        return;
+        return true;
     }
     hipLaunchKernelGGL(k_gemm_mfma<LAYER>, dim3(grid), dim3(256), 0, s, d);
+    return true;
+}
+#endif
+
+template <int LAYER>
+static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStream_t s, const NetOptions& o) {
+#ifdef AZ_DIAG
+    if (launch_gemm_diag<LAYER>(d, rows_hint, rows_typ, s, o)) return;
+#endif
+    if constexpr (LAYER == 1) if (d.N % HBN_ == 0 && d.cin % 64 == 0) {      // conv2 as a GEMM, image-resident (needs 256-channel multiples)
+        if (d.states) launch_conv2_gemm<true>(d, rows_hint, s);
+        else launch_conv2_gemm<false>(d, rows_hint, s);
+        return;
+    }
+    if constexpr (LAYER == 2) {
+        if (o.conv3_small && conv3_is_small(d, rows_hint, rows_typ)) launch_ring_auto<LAYER>(d, rows_hint, rows_typ, s, true);
+        else launch_conv3_image(d, rows_hint, s);
+        return;
+    }
+    launch_ring_auto<LAYER>(d, rows_hint, rows_typ, s);
 }
 
 static hipEvent_t net_event(NetWorkspace* n) {
@@ -2194,14 +1493,20 @@ void netws_resolve_profile(NetWorkspace* n, NetProfile* prof) {
     if (!n->open.empty() && hipMemcpy(n->pinned_n, n->d_nlog, (size_t)n->pinned_next * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
         prof = nullptr;
     for (auto& r : n->open) {
-        float conv2 = 0, conv3 = 0, total = 0;
+        float conv2 = 0, conv3 = 0, conv4 = 0, fcs = 0, total = 0;
         if (hipEventElapsedTime(&conv2, r.e1, r.e2) == hipSuccess && hipEventElapsedTime(&conv3, r.e2, r.e2b) == hipSuccess &&
+            hipEventElapsedTime(&conv4, r.e2b, r.e2c) == hipSuccess && hipEventElapsedTime(&fcs, r.e2c, r.e3) == hipSuccess &&
             hipEventElapsedTime(&total, r.e0, r.e3) == hipSuccess && prof) {
             const double rows = (double)*r.n;
             prof->conv2_ms += conv2;
             prof->conv3_ms += conv3;
             prof->conv3_flops += f_conv * 20.0 * rows;
+            prof->conv4_ms += conv4;
+            prof->conv4_flops += f_conv * 6.0 * rows;
+            prof->fc_ms += fcs;
+            prof->fc_flops += 2.0 * (6.0 * C * 1024 + 1024.0 * 512 + 512.0 * 8) * rows;
             prof->total_ms += total;
+            prof->rows += rows;
             if (r.table2) {     // conv1 + conv2 are table lookups
                 prof->conv2_bytes += rows * (304.0 * C * 2 + 42.0 * C * 2);      // 16 x 19 = 304 in-board (position, tap) pairs
                 prof->total_flops += (per_sample - 2.0 * (42.0 * 18 * C) - f_conv * 42.0) * rows;
@@ -2211,27 +1516,19 @@ void netws_resolve_profile(NetWorkspace* n, NetProfile* prof) {
             }
             prof->launches += 1;
         }
-        n->ev_pool.push_back(r.e0); n->ev_pool.push_back(r.e1); n->ev_pool.push_back(r.e2); n->ev_pool.push_back(r.e2b); n->ev_pool.push_back(r.e3);
+        n->ev_pool.push_back(r.e0); n->ev_pool.push_back(r.e1); n->ev_pool.push_back(r.e2); n->ev_pool.push_back(r.e2b); n->ev_pool.push_back(r.e2c);
+        n->ev_pool.push_back(r.e3);
     }
     n->open.clear();
     n->pinned_next = 0;
 }
 
-void convnet_set_variant(int v) { g_gemm_variant = v; }
 bool netws_read_clock_stamps(NetWorkspace* n, unsigned long long* out2048) {
     return n && hipMemcpy(out2048, n->dbg, 2048 * 8, hipMemcpyDeviceToHost) == hipSuccess;
 }
-void convnet_set_conv4_big(int v) { g_conv4_big = v; }
-void convnet_set_fc_ring(int v) { g_fc_ring = v; }
-void convnet_set_ring_max_tiles(int v) { g_ring_max_tiles = v; }
-void convnet_set_ring_tile(int layer, int tile) { if (layer >= 3 && layer <= 5) g_ring_tile[layer] = tile; }
-int g_conv2_table = 1;    // conv2 as nine gathered rows of the per-model U table (default kernel set only; "conv2_table"): 1 channel slices per XCD
-                          // (k_conv2_table_x), 2 whole rows (k_conv2_table; bit-identical to 1); 0 = MFMA GEMM
-void convnet_set_conv2_table(int v) { g_conv2_table = v; }
-int g_conv1_table = 1;    // conv2 gathers its image from the conv1 table (default kernel set only); 0 = run k_conv1 into act1
-void convnet_set_conv1_table(int v) { g_conv1_table = v; }
 
-void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows_hint, int rows_typ, hipStream_t s, NetProfile* prof) {
+void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows_hint, int rows_typ, hipStream_t s, NetProfile* prof,
+                     const NetOptions& o) {
     const int C = n->C;
     if (rows_hint > ws->max_batch) rows_hint = ws->max_batch;
     if (rows_hint <= 0) return;
@@ -2240,14 +1537,16 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     uint32_t* n_log = nullptr;
     const bool timed = prof != nullptr && ws->pinned_next < ws->pinned_cap;
     if (timed) {
-        rec.e0 = net_event(ws); rec.e1 = net_event(ws); rec.e2 = net_event(ws); rec.e2b = net_event(ws); rec.e3 = net_event(ws);
+        rec.e0 = net_event(ws); rec.e1 = net_event(ws); rec.e2 = net_event(ws); rec.e2b = net_event(ws); rec.e2c = net_event(ws); rec.e3 = net_event(ws);
         rec.n = ws->pinned_n + ws->pinned_next;
         n_log = ws->d_nlog + ws->pinned_next++;
         (void)hipEventRecord(rec.e0, s);
     }
-    // conv1 + conv2: the default kernel set gathers conv2's image from the conv1 table; the others run conv1 into act1
-    const bool table2 = g_conv2_table && g_gemm_variant == 5;
-    const bool table = !table2 && g_conv1_table && g_gemm_variant == 5 && C % HBN_ == 0;
+    // conv1 + conv2: the default kernel set runs both as table gathers; conv2 as a GEMM gathers its image from the conv1 table
+    // (256-channel multiples) or reads act1 written by k_conv1
+    const bool shipped_set = o.gemm_variant == 5;
+    const bool table2 = o.conv2_table && shipped_set;
+    const bool table = !table2 && o.conv1_table && shipped_set && C % HBN_ == 0;
     rec.table2 = table2 ? 1 : 0;
     if (!table && !table2) {
         if (!netws_need_act1(ws)) return;
@@ -2266,36 +1565,40 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.rows_per_sample = 42; d.out_w = 7; d.in_h = 8; d.in_w = 9; d.in_c = C; d.tap_w = 3; d.cin = C; d.K = 9 * C; d.N = C;
     if (timed) (void)hipEventRecord(rec.e1, s);
     if (table2) {
-        if (g_conv2_table == 2) {
+#ifdef AZ_DIAG
+        if (o.conv2_table == 2) {
             const size_t blocks = std::min<size_t>(((size_t)rows_hint * 6 + 3) / 4, 256 * 8);   // one wave per (board, board row)
             hipLaunchKernelGGL(k_conv2_table, dim3((unsigned)blocks), dim3(256), (size_t)9 * C * 2, s, eb, n->u2, n->bg[0], ws->act2, C);
-        } else {
+        } else
+#endif
+        {
             const size_t nsl = (size_t)C / 64;                                                  // one wave per (board, 64-channel slice)
             const size_t blocks = std::min<size_t>(((size_t)rows_hint + 3) / 4, 256) * nsl;
             hipLaunchKernelGGL(k_conv2_table_x, dim3((unsigned)blocks), dim3(256), 0, s, eb, n->u2, n->bg[0], ws->act2, C);
         }
     } else {
-        launch_gemm<1>(d, rows_hint, rows_typ, s);
+        launch_gemm<1>(d, rows_hint, rows_typ, s, o);
     }
     if (timed) (void)hipEventRecord(rec.e2, s);
     d.states = nullptr;
     // conv3: 3x3 valid [6][7][C] -> [4][5][C]
     d.A = ws->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = ws->act3;
     d.rows_per_sample = 20; d.out_w = 5; d.in_h = 6; d.in_w = 7;
-    launch_gemm<2>(d, rows_hint, rows_typ, s);
+    launch_gemm<2>(d, rows_hint, rows_typ, s, o);
     if (timed) (void)hipEventRecord(rec.e2b, s);
     // conv4: 3x3 valid [4][5][C] -> [2][3][C]
     d.A = ws->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = ws->act4;
     d.rows_per_sample = 6; d.out_w = 3; d.in_h = 4; d.in_w = 5;
-    launch_gemm<3>(d, rows_hint, rows_typ, s);
+    launch_gemm<3>(d, rows_hint, rows_typ, s, o);
+    if (timed) (void)hipEventRecord(rec.e2c, s);
     // fc1: [6C] -> 1024
     d.A = ws->act4; d.W = n->wg[3]; d.bias = n->bg[3]; d.out = ws->fc1o;
     d.rows_per_sample = 1; d.out_w = 1; d.in_h = 1; d.in_w = 1; d.in_c = 6 * C; d.tap_w = 1; d.cin = 6 * C; d.K = 6 * C; d.N = 1024;
-    launch_gemm<4>(d, rows_hint, rows_typ, s);
+    launch_gemm<4>(d, rows_hint, rows_typ, s, o);
     // fc2: 1024 -> 512
     d.A = ws->fc1o; d.W = n->wg[4]; d.bias = n->bg[4]; d.out = ws->fc2o;
     d.in_c = 1024; d.cin = 1024; d.K = 1024; d.N = 512;
-    launch_gemm<5>(d, rows_hint, rows_typ, s);
+    launch_gemm<5>(d, rows_hint, rows_typ, s, o);
     hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, ws->fc2o, n->wh, n->bh, n_log);
     if (timed) {
         (void)hipEventRecord(rec.e3, s);

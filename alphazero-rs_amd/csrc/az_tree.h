@@ -20,6 +20,9 @@
 namespace az {
 
 enum StatIdx { ST_SIMS = 0, ST_EXPANSIONS, ST_LEAF_EVALS, ST_LINK_HITS, ST_TERMINAL_HITS, ST_DEPTH_SUM, ST_COUNT };
+constexpr int ST_ABANDONED = ST_COUNT;      // k_harvest's 7th total: simulations abandoned on an all-Locked child set / a Locked link target
+constexpr int ST_TOTALS = ST_COUNT + 1;     // (several simulations in flight only; counted in the per-thread lines, not in TreeHead.stat)
+constexpr int MAX_SIM_THREADS = 8;
 enum ErrIdx { ERR_CAPACITY = 0, ERR_TERMINAL_ROOT = 1, ERR_PATH = 2, ERR_HASH_FULL = 3, ERR_COUNT = 4 };
 enum LeafKind { LEAF_NONE = 0, LEAF_VALUE = 1, LEAF_EVAL = 2 };
 
@@ -59,13 +62,20 @@ struct TreeDev {
     uint4* node;             // [G*R*2] 32-byte records as two uint4: {ctr.lo, ctr.hi, key.lo, key.hi} {prior, meta, link, child_base}
     uint32_t* hash;          // [G*H] `seen` (src/node.rs:135): open-addressing table of node slots, key = the node's own key word
     TreeLine* head;          // [G]
-    uint32_t* path;          // [G*PATH_CAP] node_path entries beyond PATH_INLINE
+    uint32_t* path;          // [G*T*PATH_CAP] node_path entries beyond PATH_INLINE
+    // Several simulations in flight per tree (num_threads = T > 1, src/async_mcts.rs:191-217): the per-simulation part of the search
+    // state (leaf, leaf_kind, leaf_val, src, path_len + the inline path; stat[0] counts abandoned simulations) of thread tt of tree g
+    // is line g*T + tt; the TreeHead of t.head keeps what the tree's threads share (len, count, root, active, log_len, stat).
+    int32_t block4;          // k_backup_select as 4-wave workgroups (one row-counter atomic per workgroup); 0 = one wave per workgroup ("tree_block4")
+    int32_t T;               // 1 = the single-simulation kernels
+    TreeLine* thr;           // [G*T] when T > 1, else nullptr
     uint32_t* err;           // [ERR_COUNT]
     // eval log (replay parity): raw (pi, v) of every NNet::predict row, per tree, in order
     int32_t log_cap;
     ulonglong2* log_state;   // [G*log_cap]
     float* log_pi;           // [G*log_cap*7]
     float* log_v;            // [G*log_cap]
+    const int32_t* log_row;  // [G] or nullptr: log row of tree g (az_selfplay: the slot's current episode, so a log survives slot refills); nullptr = g
 };
 
 // Leaf batch handed to the net (src/async_mcts.rs:117-189 restated as lanes): the DISTINCT states the trees of one
@@ -134,6 +144,7 @@ struct GamesDev {
     int32_t* g_len;          // [n_games]
     float* g_result;         // [n_games] r = get_game_ended(cur_player) at the end (src/coach.rs:144)
     int8_t* g_final_player;  // [n_games]
+    int32_t* g_log_len;      // [n_games] or nullptr: eval-log records of the episode (record_evals)
     // counters: [0] next episode to hand out, [1] episodes finished, [2] active slots
     uint32_t* counters;
 };
@@ -164,18 +175,23 @@ void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr 
 void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, const ulonglong2* root_states, hipStream_t s);
 void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s);
 // backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf requested in eb_next) in one launch
-void tree_set_block4(int v);
-bool tree_set_stamps(int on);
+#ifdef AZ_DIAG
+bool tree_set_stamps(int on);                                       // diagnostic library: per-wave phase stamps of k_backup_select
 bool tree_read_stamps(unsigned long long* out /*[4096 * 8]*/);
+#endif
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s);
+// T > 1: one lock-step STEP of the tree-parallel search: the backups of the previous step's T leaves in thread order (first = 1: the
+// root's priors only), then -- unless last -- T selections in thread order, each seeing the earlier ones' visits, virtual losses and locks
+void launch_step_mt(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
+                    int first, int last, hipStream_t s);
 // the whole search (root prepare + num_sims simulations + backups) in one launch for the device-function nets
 // (kind 0 = stub, 1 = hash fixture): no leaf batch, no kernel boundary per simulation
 void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind, uint64_t salt,
                            hipStream_t s);
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s);
-// sums the trees' counters into totals[ST_COUNT] (u64, accumulated) and clears them; node_counts [G] may be nullptr
+// sums the trees' counters into totals[ST_TOTALS] (u64, accumulated) and clears them; node_counts [G] may be nullptr
 void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);
 constexpr int GAME_COUNT = 2;    // 0 = ConnectFour (the reference's Game), 1 = ConnectThree (the seam's second instantiation)

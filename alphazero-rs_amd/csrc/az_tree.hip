@@ -92,7 +92,8 @@ AZ_D void hash_find(const TreeDev& t, int g, size_t base, typename G::State s, i
 // (1 when the upgraded node itself is new: a root).  Returns false when the arena is exhausted (assert!, src/node.rs:237).
 template <class G>
 AZ_D bool node_upgrade(const TreeDev& t, TreeHead& h, int g, size_t base, uint32_t slot, typename G::State s, uint32_t prior_bits,
-                       uint32_t a, uint32_t ins_pos, uint64_t ctr_value, uint32_t cbase, uint32_t extra, int sub, uint32_t* ecode_out) {
+                       uint32_t a, uint32_t ins_pos, uint64_t ctr_value, uint32_t cbase, uint32_t extra, int sub, uint32_t* ecode_out,
+                       uint32_t lock_if_live = 0u /*META_LOCKED: the slot stays Locked until its prior is stored (src/node.rs:322, src/async_mcts.rs:351)*/) {
     uint32_t ec = G::ended_code(s);
     uint32_t vm = ec ? 0u : G::valid_mask(s);
     uint32_t nv = (uint32_t)__popc(vm);
@@ -104,7 +105,7 @@ AZ_D bool node_upgrade(const TreeDev& t, TreeHead& h, int g, size_t base, uint32
     h.count += extra + nv;
     if (sub == 0) {
         node_store(node_ptr(t, base, slot), ctr_value, G::pack(s), prior_bits,
-                   a | (nv << META_NCHILD_SHIFT) | META_EXPANDED | (ec << META_ECODE_SHIFT), NONE, cbase);
+                   a | (nv << META_NCHILD_SHIFT) | META_EXPANDED | (ec << META_ECODE_SHIFT) | (ec == E_NONE ? lock_if_live : 0u), NONE, cbase);
         t.hash[(size_t)g * t.H + ins_pos] = slot;
     }
     if ((uint32_t)sub < nv)
@@ -328,13 +329,21 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, Ev
 }
 
 // ---- search_iteration: select + expand (src/async_mcts.rs:226-299, Appendix A of SURVEY.md) ----
-template <class G>
-AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth, const SearchParams& sp, int g, int sub) {
+// MT (several simulations in flight per tree, src/async_mcts.rs:191-217 as a lock-step schedule): the thread sees the Locked slots
+// earlier threads of the step hold.  C8 (src/async_mcts.rs:253-258, :275; src/node.rs:359-365): if the arg-max over all children is
+// Locked, the retry excludes Locked children.  Two sites where the reference panics have no legal continuation and are repaired by
+// ABANDONING the simulation (its visits are reverted exactly, it counts toward num_sims; *abandoned = 1):
+//   S11  every child is Locked: `max_by` on an empty iterator -> `unwrap()` (src/node.rs:366-367)
+//   S12  a link leads to a node that is Locked, i.e. expanded by an earlier thread of this step and still without its prior:
+//        `p.as_ref().unwrap()` (src/node.rs:354)
+template <class G, bool MT = false>
+AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth, const SearchParams& sp, int g, int sub, uint32_t* path,
+                                   uint32_t* abandoned = nullptr) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
     const bool act = h.active != 0;
     const size_t base = (size_t)g * t.R;
-    uint32_t* path = t.path + (size_t)g * PATH_CAP;
+    bool give_up = false, cur_visited = false;
     uint32_t cur = h.root;
     uint32_t depth = 0, plen = 0, kind = LEAF_NONE;
     float val = 0.0f;
@@ -349,6 +358,7 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth,
         uint4* pp = node_ptr(t, base, cur);
         if (!have_pr) pr = node_load(pp);
         have_pr = false;
+        if constexpr (MT) { if (pr.meta & META_LOCKED) { give_up = true; cur_visited = false; break; } }   // S12
         const uint64_t pc = pr.ctr + CTR_VISIT;                 // visit(), src/node.rs:77-80; S5: before the checks
         if (sub == 0) node_set_ctr(pp, pc);
         const uint32_t ecd = (pr.meta >> META_ECODE_SHIFT) & 3u;
@@ -375,6 +385,19 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth,
             if ((uint32_t)j < nchild && !(bu > uj)) { best = (uint32_t)j; bu = uj; }
         }
         ++n_depth;
+        if constexpr (MT) {
+            const uint32_t lockm = gballot<GW>((uint32_t)sub < nchild && (cr.meta & META_LOCKED)) & ((1u << NA) - 1u);
+            if ((lockm >> best) & 1u) {                         // C8: the winner is Locked -> retry without the Locked children
+                bool have = false;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const float uj = gshflf<GW>(u, j);
+                    if ((uint32_t)j >= nchild || ((lockm >> j) & 1u)) continue;
+                    if (!have || !(bu > uj)) { best = (uint32_t)j; bu = uj; have = true; }
+                }
+                if (!have) { give_up = true; cur_visited = true; break; }       // S11
+            }
+        }
         const uint32_t clink = gshfl<GW>(cr.link, (int)best), cmeta = gshfl<GW>(cr.meta, (int)best), cprior = gshfl<GW>(cr.prior, (int)best);
         const uint32_t cslot = cb + best;
         if (plen >= (uint32_t)PATH_CAP) {
@@ -411,7 +434,8 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth,
         }
         uint32_t ec2;
         // the placeholder is visited right after the upgrade (:309): its counter becomes INIT + VISIT
-        if (!node_upgrade<G>(t, h, g, base, cslot, s2, cprior, cmeta & META_A_MASK, ins, CTR_INIT + CTR_VISIT, h.len, 0u, sub, &ec2)) {
+        if (!node_upgrade<G>(t, h, g, base, cslot, s2, cprior, cmeta & META_A_MASK, ins, CTR_INIT + CTR_VISIT, h.len, 0u, sub, &ec2,
+                             MT ? META_LOCKED : 0u)) {
             kind = LEAF_NONE;
             break;
         }
@@ -421,6 +445,23 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth,
         kind = LEAF_EVAL;                                       // :303-315: goes to the net
         leaf_s = s2;
         break;
+    }
+    if constexpr (MT) {
+        if (give_up) {
+            // revert this simulation's visits exactly (N - 1, vloss - 1): node_path[0 .. plen) and, if it was visited, cur.
+            // Lane sub holds node_path entries sub and sub + 8; a line never repeats a node, so the lanes touch distinct counters.
+            const uint32_t total = plen + (cur_visited ? 1u : 0u);
+            for (uint32_t r = 0; r < total; r += GW) {
+                const uint32_t i = r + (uint32_t)sub;
+                if (i < total) {
+                    const uint32_t node = i < plen ? (i < 8u ? pth.lo : (i < (uint32_t)PATH_INLINE ? pth.hi : path[i])) : cur;
+                    uint4* np = node_ptr(t, base, node);
+                    node_set_ctr(np, node_ctr(np) - CTR_VISIT);
+                }
+            }
+            kind = LEAF_NONE;
+            if (abandoned) *abandoned = 1u;
+        }
     }
     if (act) {
         h.leaf = cur;
@@ -482,7 +523,7 @@ AZ_D void cache_claim_finish(const EvalCache& ec, CacheClaim c, float pv, int su
 // instead of being read through TreeHead.src -- the fused search of the fixture nets.
 template <class G, bool INLINE_PV = false>
 AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g,
-                      int sub, float pv_in = 0.0f) {
+                      int sub, const uint32_t* path, float pv_in = 0.0f) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
     const uint32_t kind = h.leaf_kind;
@@ -513,7 +554,7 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const 
         if (t.log_cap > 0) {
             uint32_t n = h.log_len;
             if (n < (uint32_t)t.log_cap) {
-                size_t li = (size_t)g * t.log_cap + n;
+                size_t li = (size_t)(t.log_row ? t.log_row[g] : g) * t.log_cap + n;
                 if (sub < NA) t.log_pi[li * NA + sub] = p;
                 if (sub == 0) { t.log_v[li] = v; t.log_state[li] = s; }
             }
@@ -538,7 +579,7 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const 
         const uint32_t myact = (uint32_t)sub < nchild ? nth_set_bit<NA>(vm, (uint32_t)sub) : 0u;
         const float pa = gshflf<GW>(p, (int)myact);
         if ((uint32_t)sub < nchild) node_set_prior(node_ptr(t, base, cb + sub), __float_as_uint(pa));   // set_policy, :348
-        if (sub == 0) node_set_meta(lp, lr.meta | META_HAS_PRIOR);
+        if (sub == 0) node_set_meta(lp, (lr.meta | META_HAS_PRIOR) & ~META_LOCKED);      // set_policy + unlock, :348-351
         h.stat[ST_LEAF_EVALS] += 1;
         val = -v;                                                   // :353 (C9)
     } else {
@@ -548,7 +589,6 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const 
         // unvisit() leaf -> root along node_path; B2: the sign alternates toward the root.
         // A Connect Four line never repeats a node, so the lanes update distinct counters.
         const uint32_t plen = h.path_len;
-        const uint32_t* path = t.path + (size_t)g * PATH_CAP;
         for (uint32_t r = 0; r <= plen; r += GW) {                      // round r: lane sub takes step i = r + sub (group-uniform trips)
             const uint32_t i = r + (uint32_t)sub;
             const uint32_t j = i >= 1u && i <= plen ? plen - i : 0u;    // node_path index of step i >= 1
@@ -622,7 +662,7 @@ __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCach
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     const PathRegs pth = path_load(t, g, sub);
-    backup_body<G>(t, h, pth, eb, ec, apply_only, g, sub);
+    backup_body<G>(t, h, pth, eb, ec, apply_only, g, sub, t.path + (size_t)g * PATH_CAP);
     h.leaf_kind = LEAF_NONE;
     if (sub == 0) head_store(t, g, h);
 }
@@ -644,14 +684,14 @@ __global__ __launch_bounds__(256) void k_backup_select(TreeDev t, EvalBatch eb_p
     TreeHead h = head_load(t, g);
     PathRegs pth = path_load(t, g, sub);
     AZ_TSTAMP(1);
-    backup_body<G>(t, h, pth, eb_prev, ec, apply_only, g, sub);
+    backup_body<G>(t, h, pth, eb_prev, ec, apply_only, g, sub, t.path + (size_t)g * PATH_CAP);
     AZ_TSTAMP(2);
     // the counters this tree's other lanes just wrote are read by the selection below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     AZ_TSTAMP(3);
-    const typename G::State leaf_s = select_body<G>(t, h, pth, sp, g, sub);
+    const typename G::State leaf_s = select_body<G>(t, h, pth, sp, g, sub, t.path + (size_t)g * PATH_CAP);
     AZ_TSTAMP(4);
     const uint32_t src = leaf_request<G>(eb_next, ec, h.leaf_kind == LEAF_EVAL, leaf_s, sub);
     AZ_TSTAMP(5);
@@ -669,16 +709,78 @@ __global__ __launch_bounds__(256) void k_backup_select(TreeDev t, EvalBatch eb_p
     }
 }
 
-// ---- the whole get_action_prob search in ONE launch, for nets that are a pure function of the state on the device ----
-// (DumbConnectFourNnet, examples/connect_four.rs:12-43, and the hash fixture): root prepare, then num_sims x {select,
-// evaluate in registers, backup} per tree with no kernel boundary and no leaf batch -- the trees never wait for each other.
-// Same operations per tree in the same order as the launch-per-step path: bit-identical.
 AZ_D void group_memory_sync() {
     // what one lane of the group stored (node records, node_path, counters) is read by its other lanes next
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// ---- several simulations in flight per tree: ONE lock-step step (src/async_mcts.rs:191-217 as a deterministic schedule) ----------
+// The T threads of a tree are served by the tree's 8 lanes one after the other.  Backups of the previous step's leaves in thread
+// order (mask/renorm/store the prior, unlock, unvisit along the thread's own node_path), then T selections in thread order: thread
+// tt sees the N + 1 / vloss + 1 of the threads before it (visit(), src/node.rs:77-80; Q = (W - vloss) / N, :51-58) and their Locked
+// leaves (C8).  Each thread's leaf request goes into the step's batch, so a step evaluates up to T rows per tree together.
+// The per-thread part of the search state lives in t.thr[g*T + tt]; t.head[g] keeps what the threads share.
+struct ThreadRegs { uint32_t leaf, leaf_kind; float leaf_val; uint32_t src, path_len; };
+AZ_D void thread_to_head(TreeHead& h, const ThreadRegs& r) { h.leaf = r.leaf; h.leaf_kind = r.leaf_kind; h.leaf_val = r.leaf_val; h.src = r.src; h.path_len = r.path_len; }
+AZ_D ThreadRegs head_to_thread(const TreeHead& h) { return ThreadRegs{h.leaf, h.leaf_kind, h.leaf_val, h.src, h.path_len}; }
+template <class G>
+__global__ __launch_bounds__(64) void k_step_mt(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec, SearchParams sp, int first, int last) {
+    constexpr int GW = G::GROUP;
+    const int tid = blockIdx.x * 64 + threadIdx.x;
+    const int g = tid / GW, sub = tid % GW;
+    if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
+    if (g >= t.G) return;
+    TreeHead h = head_load(t, g);
+    const ThreadRegs root_req = head_to_thread(h);          // first: k_root_prepare left the root's evaluation request in the head (S1)
+    const int T = t.T;
+    for (int tt = 0; tt < T; ++tt) {                        // backups in thread order
+        TreeLine* tl = t.thr + (size_t)g * T + tt;
+        ThreadRegs r{0u, LEAF_NONE, 0.0f, 0u, 0u};
+        PathRegs pth{0u, 0u};
+        if (first) { if (tt == 0) r = root_req; }
+        else {
+            const uint4 a = ((const uint4*)tl)[1];
+            r = ThreadRegs{a.x, a.y, __uint_as_float(a.z), a.w, tl->head.path_len};
+            pth = PathRegs{tl->path16[sub], tl->path16[8 + sub]};
+        }
+        thread_to_head(h, r);
+        backup_body<G>(t, h, pth, eb_prev, ec, first, g, sub, t.path + ((size_t)g * T + tt) * PATH_CAP);
+    }
+    h.leaf_kind = LEAF_NONE;
+    for (int tt = 0; tt < T; ++tt) {                        // selections in thread order
+        group_memory_sync();                                // counters, priors, locks and links written so far are read next
+        TreeLine* tl = t.thr + (size_t)g * T + tt;
+        ThreadRegs r{0u, LEAF_NONE, 0.0f, 0u, 0u};
+        PathRegs pth{0u, 0u};
+        uint32_t abandoned = 0u;
+        bool want = false;
+        typename G::State leaf_s = G::init();
+        if (!last) {
+            leaf_s = select_body<G, true>(t, h, pth, sp, g, sub, t.path + ((size_t)g * T + tt) * PATH_CAP, &abandoned);
+            want = h.leaf_kind == LEAF_EVAL;
+        }
+        const uint32_t src = leaf_request<G>(eb_next, ec, want, leaf_s, sub);      // every wave calls it T times (wave-wide ballots inside)
+        if (want) h.src = src;
+        r = head_to_thread(h);
+        if (last) r.leaf_kind = LEAF_NONE;
+        if (sub == 0) {
+            ((uint4*)tl)[1] = make_uint4(r.leaf, r.leaf_kind, __float_as_uint(r.leaf_val), r.src);
+            tl->head.path_len = r.path_len;
+            if (abandoned) tl->head.stat[0] += 1u;
+        }
+        tl->path16[sub] = pth.lo;
+        tl->path16[8 + sub] = pth.hi;
+        h.leaf_kind = LEAF_NONE;
+    }
+    if (sub == 0) head_store(t, g, h);
+}
+
+// ---- the whole get_action_prob search in ONE launch, for nets that are a pure function of the state on the device ----
+// (DumbConnectFourNnet, examples/connect_four.rs:12-43, and the hash fixture): root prepare, then num_sims x {select,
+// evaluate in registers, backup} per tree with no kernel boundary and no leaf batch -- the trees never wait for each other.
+// Same operations per tree in the same order as the launch-per-step path: bit-identical.
 template <class G>
 AZ_D float fixture_row(typename G::State s, int kind, uint64_t salt, int sub) {
     float pi[G::ACTIONS], v;
@@ -710,10 +812,10 @@ __global__ __launch_bounds__(64) void k_search_fixture(TreeDev t, const ulonglon
         group_memory_sync();
         // backup of the previous leaf (i == 0: the root's priors only, S1), then the next selection
         const float pv = h.leaf_kind == LEAF_EVAL ? fixture_row<G>(ls, kind, salt, sub) : 0.0f;
-        backup_body<G, true>(t, h, pth, no_eb, no_ec, i == 0 ? 1 : 0, g, sub, pv);
+        backup_body<G, true>(t, h, pth, no_eb, no_ec, i == 0 ? 1 : 0, g, sub, t.path + (size_t)g * PATH_CAP, pv);
         if (i == num_sims) break;
         group_memory_sync();
-        ls = select_body<G>(t, h, pth, sp, g, sub);
+        ls = select_body<G>(t, h, pth, sp, g, sub, t.path + (size_t)g * PATH_CAP);
     }
     h.leaf_kind = LEAF_NONE;
     if (sub == 0) head_store(t, g, h);
@@ -742,15 +844,17 @@ __global__ __launch_bounds__(64) void k_root_policy(TreeDev t, float temp, uint6
 __global__ __launch_bounds__(256) void k_harvest(TreeDev t, unsigned long long* totals, uint32_t* node_counts) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    uint32_t st[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+    uint32_t st[ST_TOTALS] = {0, 0, 0, 0, 0, 0, 0};
     if (g < t.G) {
         TreeHead* hp = &t.head[g].head;
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) { st[k] = hp->stat[k]; hp->stat[k] = 0; }
         if (node_counts) node_counts[g] = hp->count;
+        if (t.thr)
+            for (int tt = 0; tt < t.T; ++tt) { TreeHead* tp = &t.thr[(size_t)g * t.T + tt].head; st[ST_ABANDONED] += tp->stat[0]; tp->stat[0] = 0; }
     }
 #pragma unroll
-    for (int k = 0; k < ST_COUNT; ++k) {
+    for (int k = 0; k < ST_TOTALS; ++k) {
         unsigned long long v = st[k];                 // 64 lanes x < 2^32 each: the sum fits 38 bits
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -813,6 +917,7 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
             gd.g_result[gi] = -ecode_value(ec);
             gd.g_final_player[gi] = (int8_t)-player;
             gd.g_len[gi] = ply + 1;
+            if (gd.g_log_len) gd.g_log_len[gi] = (int32_t)h.log_len;
             atomicAdd(&gd.counters[1], 1u);
             int next = -1;
             if (mp.refill) {
@@ -931,9 +1036,8 @@ static_assert(game_ok<ConnectFour>() && game_ok<ConnectThree>(),
         else { using TG = ConnectFour; __VA_ARGS__; }               \
     } while (0)
 static inline int group_blocks(int G) { return (G * BLOCK_SLOTS + 63) / 64; }
-static int g_tree_block4 = 1;      // "tree_block4": k_backup_select as 4-wave workgroups (one row-counter atomic per workgroup), 0 = one wave per workgroup
-void tree_set_block4(int v) { g_tree_block4 = v; }
-// diagnostic: per-wave phase stamps of k_backup_select (tools/tree_probe.py)
+#ifdef AZ_DIAG
+// diagnostic library only: per-wave phase stamps of k_backup_select (tools/tree_probe.py); process-wide by design (a probe, not a product path)
 constexpr int TREE_DBG_WAVES = 4096;
 static unsigned long long* g_tree_dbg = nullptr;
 bool tree_set_stamps(int on) {
@@ -945,6 +1049,7 @@ bool tree_set_stamps(int on) {
 bool tree_read_stamps(unsigned long long* out /*[TREE_DBG_WAVES * 8]*/) {
     return g_tree_dbg && hipMemcpy(out, g_tree_dbg, (size_t)TREE_DBG_WAVES * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
 }
+#endif
 
 void launch_init_heads(const TreeDev& t, hipStream_t s) {
     hipLaunchKernelGGL(k_init_heads, dim3((t.G + 255) / 256), dim3(256), 0, s, t);
@@ -963,13 +1068,20 @@ void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, i
 }
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                           int apply_only, hipStream_t s) {
-    const bool four = g_tree_block4 && (t.G * 8) % 256 == 0;     // whole 4-wave workgroups: one row-counter atomic per workgroup (leaf_request)
+    const bool four = t.block4 && (t.G * 8) % 256 == 0;     // whole 4-wave workgroups: one row-counter atomic per workgroup (leaf_request)
     const dim3 grid(four ? (unsigned)(t.G * 8 / 256) : group_blocks(t.G)), block(four ? 256 : 64);
+#ifdef AZ_DIAG
     if (g_tree_dbg && t.G * 8 / 64 <= TREE_DBG_WAVES) {
         AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, true>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, apply_only, g_tree_dbg));
-    } else {
-        AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, false>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, apply_only, nullptr));
+        return;
     }
+#endif
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, false>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, apply_only, nullptr));
+}
+void launch_step_mt(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
+                    int first, int last, hipStream_t s) {
+    // one wave per workgroup: leaf_request is called T times per launch and its one-atomic-per-workgroup path keeps state in LDS
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_step_mt<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb_prev, eb_next, ec, sp, first, last));
 }
 void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, SearchParams sp, int num_sims, int kind, uint64_t salt,
                            hipStream_t s) {

@@ -106,6 +106,13 @@ typedef struct az_stats {
     uint64_t tree_launches_timed;  /* ... of which tree_ms was measured on */
     uint64_t tree_arena_allocs;  /* tree arenas hipMalloc'ed by az_selfplay / az_arena since az_create (kept and reused across
                                   * calls of the same shape; not cleared by az_reset_stats) */
+    double net_conv4_ms;           /* summed conv4 kernel time (profile mode) */
+    double net_conv4_flops;
+    double net_fc_ms;              /* summed fc1 + fc2 + heads kernel time (profile mode) */
+    double net_fc_flops;
+    double net_rows_timed;         /* executed rows of the timed forwards (profile mode) */
+    uint64_t abandoned_sims;     /* num_threads > 1 only: simulations abandoned where the reference has no legal continuation
+                                  * (every child Locked, src/node.rs:366-367; a link into a Locked node, :354); counted in `simulations` */
 } az_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -187,11 +194,16 @@ az_status az_net_train_step(az_engine* e, const float* boards, const float* pis,
 az_status az_net_train_end(az_engine* e, int32_t model_id);
 
 /* ---- AsyncMcts, src/async_mcts.rs:14-115 -------------------------------- */
-/* n_games independent AsyncMcts::default(reserve, num_sims, 1, max_depth, model_id, cpuct, ..)
+/* n_games independent AsyncMcts::default(reserve, num_sims, num_threads, max_depth, model_id, cpuct, ..)
  * (src/async_mcts.rs:27-48), each rooted at the initial board (NodeStore::new, src/node.rs:156-166).
- * num_threads is fixed at 1 (one simulation in flight per tree: the deterministic mode). */
-az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_t num_sims, int32_t max_depth,
-                         int32_t model_id, int32_t cpuct, az_tree** out);
+ * num_threads = simulations in flight per tree (src/async_mcts.rs:191-217; num_sims % num_threads == 0, :192).
+ * 1 is the reference's only deterministic mode.  num_threads > 1 runs the reference's tree-parallel search as a
+ * deterministic LOCK-STEP schedule (one legal execution of the racy original; DESIGN.md "several simulations in flight"):
+ * per step the threads select in thread order, each seeing the visits and virtual losses (src/node.rs:77-80) of the earlier
+ * ones and the `Locked` filter of src/node.rs:359-365 on leaves they hold; the step's leaves are evaluated together and
+ * backed up in thread order.  At most 8 threads. */
+az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_t num_sims, int32_t num_threads,
+                         int32_t max_depth, int32_t model_id, int32_t cpuct, az_tree** out);
 void az_tree_destroy(az_tree* t);
 /* AsyncMcts::from_state(s, ..) (src/async_mcts.rs:50-72, NodeStore::from_root, src/node.rs:168-177): forget every
  * tree of the batch and root tree g at root_states[g] (canonical bitboards [G,2]); NULL = the initial board. */
@@ -221,8 +233,8 @@ typedef struct az_selfplay_params {
     uint64_t reserve;        /* mcts_reserve_size, src/coach.rs:20 (clamped to the reachable bound) */
     uint64_t seed;
     uint64_t first_game_id;
-    int32_t record_evals;    /* records per game kept for az_selfplay_get_evals (0 = off) */
-    int32_t reserved0;
+    int32_t record_evals;    /* records per EPISODE kept for az_selfplay_get_evals (0 = off); works with slot refill */
+    int32_t num_sim_threads; /* simulations in flight per tree, src/coach.rs:31, :249 (0 = 1; see az_tree_create) */
 } az_selfplay_params;
 
 /* Training tuples (s, pi, z) in game-id order then ply order; TrainingSample, src/nnet.rs:22-27. */
@@ -257,10 +269,41 @@ typedef struct az_arena_params {
      * A sharded call plays all num_games of its range (the caller splits an even total). */
     int32_t first_game;
     int32_t total_games;
+    int32_t record_evals;     /* records per game and player kept for az_arena_get_evals (0 = off) */
+    int32_t num_sim_threads;  /* simulations in flight per tree, src/coach.rs:340, :351 (0 = 1; see az_tree_create) */
+    /* play_games' `board: Option<G>` (src/arena.rs:62-67, :12-16): every game starts from this position with the first
+     * seat (cur_player = +1) to move; start_board = {first seat's stones, second seat's stones}.  use_start_board = 0: the
+     * initial board (None). */
+    int32_t use_start_board;
+    /* sharded call (total_games > 0) on an engine with a communicator (az_comm_init): != 0 sums out_wld over the ranks
+     * (one 3-counter all-reduce over RCCL), so every rank returns the whole arena's tally */
+    int32_t allreduce_wld;
+    uint64_t start_board[2];
 } az_arena_params;
 /* out_wld[3] = {Win, Loss, Draw} for the new model (GameResult, src/arena.rs:54-59);
  * results [num_games] (may be NULL): +1 first seat won, -1 second seat won, 0 draw (play_game, src/arena.rs:51). */
 az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], int8_t* results);
+/* Eval log of the last az_arena with record_evals > 0, for the trees of player `which` (0 = new model, 1 = old model):
+ * rec_count [num_games], states [num_games,cap,2], pis [num_games,cap,7], vs [num_games,cap] (any may be NULL). */
+az_status az_arena_get_evals(az_engine* e, int32_t which, int32_t* rec_count, uint64_t* states, float* pis, float* vs);
+
+/* ---- the collective of the sharded Coach loop (no reference counterpart: the reference is one process,
+ * src/coach.rs:241-272 fans episodes out over a rayon pool; here one process per GPU plays a shard of the global
+ * episode ids and the (s, pi, z) tuples meet once per episode batch) --------------------------------------------------
+ * RCCL over xGMI on the engine's own stream.  az_comm_unique_id is called on ONE rank; the host ships the 128 bytes to the
+ * others by its own means (a file, MPI, torch.distributed ...) and every rank calls az_comm_init with them. */
+#define AZ_COMM_ID_BYTES 128
+az_status az_comm_unique_id(az_engine* e, uint8_t id[AZ_COMM_ID_BYTES]);
+az_status az_comm_init(az_engine* e, int32_t rank, int32_t world, const uint8_t id[AZ_COMM_ID_BYTES]);
+az_status az_comm_destroy(az_engine* e);
+/* One gather of the packed tuples of `local` (count tuples: states [count,2], pis [count,7], zs [count]; host or device)
+ * to dst_rank: an all-gather of the per-rank counts (counts_out [world], may be NULL), then ONE gather of 48-byte packed
+ * tuples in rank order.  On dst_rank `gathered` receives them (capacity in, count out; states / pis / zs required, host or
+ * device); on other ranks `gathered` may be NULL.  dst_rank = -1: every rank receives (the same exchange as an all-gather: the
+ * replicated trainer of the sharded Coach loop).  Collective: every rank of the communicator calls it. */
+az_status az_gather_samples(az_engine* e, const az_samples* local, int32_t dst_rank, az_samples* gathered, int64_t* counts_out);
+/* In-place sum over the ranks of n (<= 64) u64 counters (the arena's W/L/D; host memory).  Collective. */
+az_status az_allreduce_u64(az_engine* e, uint64_t* values, int32_t n);
 
 #ifdef __cplusplus
 }

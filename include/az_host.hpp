@@ -101,7 +101,7 @@ class ConnectFourGame {
 class Engine {
   public:
     explicit Engine(int device = 0, int max_batch = 8192, int channels = 512) {
-        az_config cfg{device, max_batch, channels, 0};
+        az_config cfg{device, max_batch, channels, 0, 0};
         if (az_create(&cfg, &e_) != AZ_OK) throw Panic("az_create failed");
     }
     ~Engine() { az_destroy(e_); }
@@ -138,11 +138,12 @@ class Mi355xNNet : public NNet {
 class AsyncMcts {
   public:
     // AsyncMcts::default(reserve_space, num_sims, num_threads, max_depth, model_id, cpuct, ..), src/async_mcts.rs:27-48
+    // num_threads > 1: several simulations in flight per tree, the engine's deterministic lock-step schedule (az_engine.h)
     static AsyncMcts default_(Engine& e, size_t reserve_space, size_t num_sims, size_t num_threads, size_t max_depth,
                               size_t model_id, int32_t cpuct) {
-        if (num_threads != 1 || num_sims % num_threads != 0)
-            throw Panic("num_sims % num_threads == 0 with num_threads == 1");   // src/async_mcts.rs:192
-        return AsyncMcts(e, reserve_space, num_sims, max_depth, model_id, cpuct);
+        if (num_threads == 0 || num_sims % num_threads != 0)
+            throw Panic("assertion failed: self.num_sims % self.num_threads == 0");   // src/async_mcts.rs:192
+        return AsyncMcts(e, reserve_space, num_sims, num_threads, max_depth, model_id, cpuct);
     }
     AsyncMcts(AsyncMcts&& o) noexcept : e_(o.e_), t_(o.t_) { o.t_ = nullptr; }
     ~AsyncMcts() { if (t_) az_tree_destroy(t_); }
@@ -157,8 +158,8 @@ class AsyncMcts {
     }
 
   private:
-    AsyncMcts(Engine& e, size_t reserve, size_t sims, size_t max_depth, size_t model_id, int32_t cpuct) : e_(e) {
-        e_.check(az_tree_create(e.raw(), 1, reserve, (int)sims, (int)max_depth, (int)model_id, cpuct, &t_));
+    AsyncMcts(Engine& e, size_t reserve, size_t sims, size_t threads, size_t max_depth, size_t model_id, int32_t cpuct) : e_(e) {
+        e_.check(az_tree_create(e.raw(), 1, reserve, (int)sims, (int)threads, (int)max_depth, (int)model_id, cpuct, &t_));
     }
     Engine& e_;
     az_tree* t_ = nullptr;
@@ -279,8 +280,10 @@ class Coach {
                        size_t num_sim_threads, size_t max_depth, int32_t cpuct) {
         if (inference_batch_size == 0 || num_sims % inference_batch_size != 0)
             throw Panic("assertion failed: num_sims % inference_batch_size == 0");        // src/coach.rs:83
-        if (num_sim_threads != 1) throw Panic("the engine runs one simulation per tree at a time (num_sim_threads = 1)");
+        if (num_sim_threads == 0 || num_sims % num_sim_threads != 0)
+            throw Panic("assertion failed: self.num_sims % self.num_threads == 0");             // src/async_mcts.rs:192
         Coach c(e);
+        c.num_sim_threads = num_sim_threads;
         c.dir_ = checkpoint_directory;
         c.mcts_reserve_size = mcts_reserve_size; c.update_threshold = update_threshold; c.temp_threshold = temp_threshold;
         c.max_history_length = max_history_length; c.max_queue_length = max_queue_length;
@@ -345,13 +348,27 @@ class Coach {
         if (!ok) throw Panic("malformed " + examples_path(iteration));
     }
 
+    // One process per GPU: rank r of `world` plays the episode ids shard_range(num_eps, r, world) of every
+    // iteration and the arena games shard_range(num_arena_games, r, world); the tuples meet in ONE az_gather_samples (every
+    // rank receives: the trainer is replicated) and the arena tally in one 3-counter all-reduce.  world > 1 needs a
+    // communicator on the engine (az_comm_unique_id on one rank, the 128 bytes shipped by the host, az_comm_init on all).
+    void shard(int rank, int world) {
+        if (world < 1 || rank < 0 || rank >= world) throw Panic("shard: rank outside the world");
+        rank_ = rank; world_ = world;
+    }
+    static std::pair<size_t, size_t> shard_range(size_t n, int rank, int world) {
+        return {n * (size_t)rank / (size_t)world, n * (size_t)(rank + 1) / (size_t)world};
+    }
+
     // the self-play fan-out of src/coach.rs:241-272: num_eps x execute_episode, emitted with both symmetries
     HistoryEntry execute_episodes(size_t model_id, size_t iteration, uint64_t seed) {
+        if (world_ > 1 || use_comm_at_world_1) return execute_episodes_sharded(model_id, iteration, seed);
         az_selfplay_params p{};
         p.n_games = (int32_t)num_eps; p.concurrent = (int32_t)std::min(num_episode_threads, num_eps);
         p.num_sims = (int32_t)num_sims; p.temp_threshold = (int32_t)temp_threshold; p.max_depth = (int32_t)max_depth;
         p.cpuct = cpuct; p.model_id = (int32_t)model_id; p.symmetries = 1; p.reserve = mcts_reserve_size; p.seed = seed;
         p.first_game_id = (uint64_t)(iteration * num_eps);
+        p.num_sim_threads = (int32_t)num_sim_threads;
         const size_t cap = num_eps * 42 * 2;
         HistoryEntry h;
         h.boards.resize(cap * 84); h.pis.resize(cap * 7); h.vs.resize(cap);
@@ -363,6 +380,49 @@ class Coach {
         return h;
     }
 
+    // the same fan-out over the ranks: this rank's shard of the episode ids as compact (state, pi, z) tuples, ONE gather in which
+    // every rank receives all of them (rank order = episode-id order), symmetries regenerated here
+    HistoryEntry execute_episodes_sharded(size_t model_id, size_t iteration, uint64_t seed) {
+        const auto [lo, hi] = shard_range(num_eps, rank_, world_);
+        const size_t mine = hi - lo;
+        std::vector<uint64_t> st(std::max<size_t>(mine, 1) * 42 * 2);
+        std::vector<float> pi(std::max<size_t>(mine, 1) * 42 * 7), z(std::max<size_t>(mine, 1) * 42);
+        az_samples loc{};
+        loc.capacity = (int64_t)(mine * 42); loc.states = st.data(); loc.pis = pi.data(); loc.zs = z.data();
+        if (mine > 0) {
+            az_selfplay_params p{};
+            p.n_games = (int32_t)mine; p.concurrent = (int32_t)std::min(num_episode_threads, mine);
+            p.num_sims = (int32_t)num_sims; p.temp_threshold = (int32_t)temp_threshold; p.max_depth = (int32_t)max_depth;
+            p.cpuct = cpuct; p.model_id = (int32_t)model_id; p.symmetries = 0; p.reserve = mcts_reserve_size; p.seed = seed;
+            p.first_game_id = (uint64_t)(iteration * num_eps + lo);
+            p.num_sim_threads = (int32_t)num_sim_threads;
+            e_.check(az_selfplay(e_.raw(), &p, &loc));
+        }
+        const size_t cap = num_eps * 42;
+        std::vector<uint64_t> gs(cap * 2);
+        std::vector<float> gp(cap * 7), gz(cap);
+        az_samples all{};
+        all.capacity = (int64_t)cap; all.states = gs.data(); all.pis = gp.data(); all.zs = gz.data();
+        e_.check(az_gather_samples(e_.raw(), &loc, -1, &all, nullptr));
+        const size_t n = (size_t)all.count;
+        HistoryEntry h;
+        h.boards.assign(n * 2 * 84, 0.f); h.pis.resize(n * 2 * 7); h.vs.resize(n * 2);
+        for (size_t i = 0; i < n; ++i) {                         // get_symmetries (connect_four_game.rs:205-211): identity, then the mirror
+            ConnectFourGame g;
+            g.plus = gs[2 * i]; g.minus = gs[2 * i + 1];
+            const Policy p(gp.begin() + (std::ptrdiff_t)(i * 7), gp.begin() + (std::ptrdiff_t)(i * 7 + 7));
+            size_t k = 2 * i;
+            for (auto& bp : g.get_symmetries(p)) {
+                const BoardFeatures f = bp.first.to_features();
+                std::copy(f.begin(), f.end(), h.boards.begin() + (std::ptrdiff_t)(k * 84));
+                std::copy(bp.second.begin(), bp.second.end(), h.pis.begin() + (std::ptrdiff_t)(k * 7));
+                h.vs[k] = gz[i];
+                ++k;
+            }
+        }
+        return h;
+    }
+
     // Coach::learn(skip_first_play), src/coach.rs:169-396.  Engine model slots: `model_id` is the current net,
     // `model_id + 1` the candidate.
     static constexpr size_t RESUMED = (size_t)-1;     // learn(): continue from the live model of the resumed run (else 0)
@@ -371,7 +431,7 @@ class Coach {
         if (model_id == RESUMED) model_id = this->model_id;
         {   // the run's initial model: what a restart would load
             const std::string w = dir_ + "/" + std::to_string(model_id) + ".aznet";
-            if (!std::filesystem::exists(w)) e_.check(az_net_save(e_.raw(), (int32_t)model_id, w.c_str()));
+            if (rank_ == 0 && !std::filesystem::exists(w)) e_.check(az_net_save(e_.raw(), (int32_t)model_id, w.c_str()));
         }
         for (size_t iteration = start_iteration; iteration < start_iteration + num_iters; ++iteration) {
             HistoryEntry h;
@@ -386,7 +446,7 @@ class Coach {
             }
             history.push_back(std::move(h));                                    // :282: pushed even when the play was skipped
             if (history.size() > max_history_length) history.pop_front();      // :285-288
-            save_train_examples(iteration);                                       // :291-293
+            if (rank_ == 0) save_train_examples(iteration);                       // :291-293 (one writer per run)
             size_t n = 0;
             for (auto& h : history) n += h.len();
             if (n == 0) throw Panic("assertion failed: training set is empty");   // :305
@@ -403,7 +463,7 @@ class Coach {
             }
             e_.check(az_set_option(e_.raw(), "train_seed", (int64_t)(seed + iteration)));
             e_.check(az_net_train(e_.raw(), (int32_t)model_id, (int32_t)model_id + 1, sb.data(), sp.data(), sv.data(), (int64_t)n));   // :329
-            e_.check(az_net_save(e_.raw(), (int32_t)model_id + 1, (dir_ + "/" + std::to_string(model_id + 1) + ".aznet").c_str()));
+            if (rank_ == 0) e_.check(az_net_save(e_.raw(), (int32_t)model_id + 1, (dir_ + "/" + std::to_string(model_id + 1) + ".aznet").c_str()));
             Report r{};
             r.iteration = iteration; r.samples = n; r.model_id = model_id;
             r.losses.resize(2 * (size_t)az_net_train_history(e_.raw(), nullptr, 0));
@@ -413,6 +473,13 @@ class Coach {
             a.num_games = (int32_t)num_arena_games; a.num_sims = (int32_t)num_sims; a.max_depth = (int32_t)max_depth; a.cpuct = cpuct;
             a.new_model_id = (int32_t)model_id + 1; a.old_model_id = (int32_t)model_id; a.reserve = mcts_reserve_size;
             a.seed = seed + 7919ull * (uint64_t)(iteration + 1);
+            a.num_sim_threads = (int32_t)num_sim_threads;
+            if (world_ > 1 || use_comm_at_world_1) {                 // this rank's games of the arena, one 3-counter all-reduce
+                const size_t total = 2 * (num_arena_games / 2);      // num/2 per seating (src/arena.rs:83)
+                const auto [alo, ahi] = shard_range(total, rank_, world_);
+                a.first_game = (int32_t)alo; a.num_games = (int32_t)(ahi - alo); a.total_games = (int32_t)total; a.allreduce_wld = 1;
+                if (total == 0) { a.total_games = 0; a.first_game = 0; a.num_games = 0; a.allreduce_wld = 0; }
+            }
             uint64_t wld[3] = {0, 0, 0};
             e_.check(az_arena(e_.raw(), &a, wld, nullptr));
             r.nwins = (size_t)wld[0]; r.pwins = (size_t)wld[1]; r.draws = (size_t)wld[2];
@@ -422,7 +489,7 @@ class Coach {
             // a long run moves to a new model id per accepted iteration: drop the slot nobody will read again
             e_.check(az_net_free(e_.raw(), (int32_t)(r.accepted ? model_id : model_id + 1)));
             if (r.accepted) ++model_id;
-            {
+            if (rank_ == 0) {
                 const std::string tmp = dir_ + "/coach.state.tmp";
                 if (FILE* f = std::fopen(tmp.c_str(), "w")) {
                     std::fprintf(f, "%zu %zu\n", iteration, model_id);
@@ -439,7 +506,8 @@ class Coach {
     std::deque<HistoryEntry> history;
     size_t start_iteration = 0, model_id = 0;
     size_t mcts_reserve_size = 0, temp_threshold = 0, max_history_length = 0, max_queue_length = 0, num_episode_threads = 0,
-           num_arena_games = 0, num_iters = 0, num_eps = 0, num_sims = 0, max_depth = 0;
+           num_arena_games = 0, num_iters = 0, num_eps = 0, num_sims = 0, max_depth = 0, num_sim_threads = 1;
+    bool use_comm_at_world_1 = false;     // tests: run the gather / all-reduce path at world size 1
     float update_threshold = 0.f;
     int32_t cpuct = 1;
 
@@ -447,6 +515,7 @@ class Coach {
     explicit Coach(Engine& e) : e_(e) {}
     Engine& e_;
     std::string dir_;
+    int rank_ = 0, world_ = 1;
 };
 
 }  // namespace az_host

@@ -133,6 +133,8 @@ struct Node {
     }
     // src/node.rs:77-80
     void visit() { win_counter.fetch_add(0x0000000000010001ull); }
+    // exact inverse of visit(): an abandoned simulation of the lock-step schedule (repairs S11 / S12) leaves no trace
+    void revert_visit() { win_counter.fetch_sub(0x0000000000010001ull); }
     // src/node.rs:83-92 (C4: a non-negative backup adds incr+1 to W; kept literally)
     void unvisit(float win_val) {
         uint32_t incr = (uint32_t)std::fabs(win_scale * win_val);
@@ -299,6 +301,13 @@ struct NodeStore {
         if (!have) throw std::runtime_error("best_child: no children"); // .unwrap(), :367
         return best;
     }
+    // true when best_child(idx, .., filter = true) would have nothing to choose from (every child Locked): the reference's
+    // `max_by(..).unwrap()` panics there (:366-367); the lock-step schedule abandons the simulation instead (S11)
+    bool all_children_locked(size_t idx) const {
+        for (size_t child_idx : get(idx)->children)
+            if (state(child_idx) != std::optional<NodeState>(NodeState::Locked)) return false;
+        return true;
+    }
     size_t size() const { return len.load(); }
 };
 
@@ -317,10 +326,14 @@ struct SearchStats {
     uint64_t link_hits = 0;   // upgrade -> Some(false)
     uint64_t terminal_hits = 0;
     uint64_t depth_sum = 0;   // selection levels (best_child calls)
+    uint64_t abandoned = 0;   // num_threads > 1: simulations abandoned (S11 / S12), counted in sims
 };
 
-// AsyncMcts: src/async_mcts.rs:14-115, :191-371, restated for num_threads == 1
-// (the only deterministic mode of the reference, examples/connect_four.rs:68).
+// AsyncMcts: src/async_mcts.rs:14-115, :191-371.  num_threads == 1 (the only deterministic mode of the reference,
+// examples/connect_four.rs:68) runs search_iteration as written; num_threads > 1 runs the reference's tree-parallel search
+// (:191-217: num_threads OS threads sharing one NodeStore, virtual loss, Locked filter) as ONE LEGAL EXECUTION of it, a
+// deterministic lock-step schedule (search_lockstep below).  The reference itself is racy for num_threads > 1, so nothing
+// can pin this: PARITY UNPINNED.
 template <class G>
 struct AsyncMcts {
     size_t reserve_space;
@@ -429,10 +442,122 @@ struct AsyncMcts {
         return probs;
     }
 
-    // src/async_mcts.rs:191-217 with num_threads == 1
+    // src/async_mcts.rs:191-217
     void search(size_t root_idx) {
-        assert(num_sims % num_threads == 0);                        // :192
-        for (size_t i = 0; i < num_sims; ++i) search_iteration(root_idx);
+        if (num_sims % num_threads != 0) throw std::runtime_error("num_sims % num_threads != 0");   // assert!, :192
+        if (num_threads == 1 && !force_lockstep) {
+            for (size_t i = 0; i < num_sims; ++i) search_iteration(root_idx);
+        } else {
+            search_lockstep(root_idx);
+        }
+    }
+    bool force_lockstep = false;   // tests: run num_threads == 1 through search_lockstep (must equal search_iteration)
+
+    // ---- num_threads > 1 as a deterministic lock-step schedule --------------------------------------------------------
+    // The reference's threads each loop `while sim_id.fetch_add(1) < num_sims { search_iteration }` (:210-212) on one shared
+    // NodeStore.  The schedule pinned here: num_sims / num_threads STEPS; in a step the threads run the select / expand part of
+    // search_iteration (:226-309) one after the other in thread order -- so thread t sees the N + 1 and vloss + 1 of every
+    // visit() (src/node.rs:77-80) the threads before it made, and the slots they still hold Locked --, then block on the
+    // inference channel together (:311-315: the step's leaves are one batch), then finish (:317-353) and back up (:361-370)
+    // in thread order.  C8 (:253-258, :275; src/node.rs:359-365): a Locked arg-max is retried with the Locked children
+    // filtered out.  Two situations this schedule reaches have no legal continuation in the reference (it panics), and are
+    // repaired by ABANDONING the simulation -- its visits are reverted exactly and it still counts toward num_sims:
+    //   S11  every child of the node is Locked: `max_by` over an empty iterator, `.unwrap()` (src/node.rs:366-367)
+    //   S12  a link (:293-299, or an Exists(false) child) leads to a node an earlier thread of the step holds Locked, i.e.
+    //        expanded and still without its prior: `node.mu.p.as_ref().unwrap()` (src/node.rs:354)
+    struct Pending {
+        size_t cur = 0;
+        std::vector<size_t> node_path;
+        int kind = 0;               // 0 value known (terminal / depth), 1 leaf waits for the net, 2 abandoned
+        float v = 0.0f;
+    };
+    Pending select_phase(size_t root_idx) {
+        stats.sims++;
+        Pending pd;
+        pd.cur = root_idx;
+        pd.node_path.reserve(64);
+        size_t depth = 0;
+        bool cur_visited = false;
+        auto abandon = [&]() {
+            for (size_t idx : pd.node_path) nodes->get(idx)->revert_visit();
+            if (cur_visited) nodes->get(pd.cur)->revert_visit();
+            pd.kind = 2;
+            stats.abandoned++;
+        };
+        for (;;) {
+            size_t cur = pd.cur;
+            cur_visited = false;
+            if (nodes->state(cur) == std::optional<NodeState>(NodeState::Locked)) { abandon(); return pd; }   // S12
+            Node<G>* head = nodes->get(cur);
+            head->visit();                                          // :251; S5
+            cur_visited = true;
+            if (depth > max_depth) { pd.v = head->s->eval_heuristic(); return pd; }   // :241-244 (B10)
+            if (head->e != 0.0f) { pd.v = head->e; stats.terminal_hits++; return pd; } // :246-249
+            size_t c = nodes->best_child(cur, cpuct, false);        // :255-258, first_iteration
+            stats.depth_sum++;
+            if (nodes->state(c) == std::optional<NodeState>(NodeState::Locked)) {     // `_ => continue`, :275
+                if (nodes->all_children_locked(cur)) { abandon(); return pd; }        // S11
+                c = nodes->best_child(cur, cpuct, true);            // C8: filter = !first_iteration
+            }
+            auto st = nodes->state(c);
+            if (st == std::optional<NodeState>(NodeState::PlaceHolder)) {             // :261-268
+                nodes->lock(c);                                     // succeeds: the schedule is sequential
+                pd.node_path.push_back(cur);                        // S3
+                size_t parent = cur;
+                pd.cur = c;
+                Node<G>* node_p = nodes->get(parent);
+                uint8_t act = quirks.b1_parent_action ? node_p->a : nodes->raw(c)->a; // B1
+                auto nx = node_p->s->get_next_state(1, act);        // :284
+                G s2 = nx.first.get_canonical_form(nx.second);      // :287
+                auto up = nodes->upgrade(c, s2);                    // :289
+                if (!*up) {                                         // :293-299: link (upgrade unlocked the slot)
+                    stats.link_hits++;
+                    pd.cur = *nodes->resolve(c);
+                    continue;
+                }
+                stats.expansions++;
+                Node<G>* leaf = nodes->get(c);
+                leaf->visit();                                      // :309
+                if (leaf->e != 0.0f) {                              // S4
+                    nodes->unlock(c);
+                    pd.v = leaf->e;
+                    return pd;
+                }
+                pd.kind = 1;                                        // stays Locked until its prior arrives (:311-351)
+                return pd;
+            } else {                                                // :269-274; S2
+                pd.node_path.push_back(cur);
+                pd.cur = *nodes->resolve(c);
+                depth += 1;
+            }
+        }
+    }
+    void search_lockstep(size_t root_idx) {
+        const size_t steps = num_sims / num_threads;
+        for (size_t step = 0; step < steps; ++step) {
+            std::vector<Pending> pend;
+            pend.reserve(num_threads);
+            for (size_t t = 0; t < num_threads; ++t) pend.push_back(select_phase(root_idx));
+            for (auto& pd : pend) {                                 // the step's leaves: evaluated together, finished in thread order
+                if (pd.kind != 1) continue;
+                Node<G>* leaf = nodes->get(pd.cur);
+                auto pv = evaluate(*leaf->s, *leaf->v);             // :303-345
+                nodes->set_policy(pd.cur, std::move(pv.first));     // :348
+                nodes->unlock(pd.cur);                              // :351
+                pd.v = -pv.second;                                  // :353
+            }
+            for (auto& pd : pend) {                                 // backups, :361-370 (B2)
+                if (pd.kind == 2) continue;
+                float x = pd.v;
+                nodes->get(pd.cur)->unvisit(x);
+                while (!pd.node_path.empty()) {
+                    size_t cur = pd.node_path.back();
+                    pd.node_path.pop_back();
+                    if (!quirks.b2_same_sign_backup) x = -x;
+                    nodes->get(cur)->unvisit(x);
+                }
+            }
+        }
     }
 
     // src/async_mcts.rs:219-371 with repairs S2-S5, B1, B2.

@@ -102,17 +102,18 @@ Quirks quirks_from_bits(uint32_t b) {
 
 template <class G>
 TreeBase* make_tree(int has_root, uint64_t mine, uint64_t theirs, size_t reserve, size_t sims, size_t max_depth,
-                    size_t model_id, int cpuct, int net_kind, uint64_t salt, uint32_t qbits) {
+                    size_t model_id, int cpuct, int net_kind, uint64_t salt, uint32_t qbits, size_t threads = 1, bool force_lockstep = false) {
     auto* t = new TreeImpl<G>();
     t->quirks = quirks_from_bits(qbits);
     t->nets.hash.salt = salt;
     NNet* net = t->nets.get(net_kind);
     if (has_root)
-        t->mcts.reset(new AsyncMcts<G>(make_state<G>(mine, theirs, t->quirks), reserve, sims, 1, max_depth,
+        t->mcts.reset(new AsyncMcts<G>(make_state<G>(mine, theirs, t->quirks), reserve, sims, threads, max_depth,
                                        model_id, cpuct, net, C4_W));
     else
-        t->mcts.reset(new AsyncMcts<G>(reserve, sims, 1, max_depth, model_id, cpuct, net, C4_W));
+        t->mcts.reset(new AsyncMcts<G>(reserve, sims, threads, max_depth, model_id, cpuct, net, C4_W));
     t->mcts->quirks = t->quirks;
+    t->mcts->force_lockstep = force_lockstep;
     return t;
 }
 
@@ -193,6 +194,20 @@ void* azo_tree_new(int game_kind, int has_root, uint64_t mine, uint64_t theirs, 
         return nullptr;
     }
 }
+// the same with num_threads simulations in flight per tree (lock-step schedule, az_oracle.hpp); force_lockstep runs
+// num_threads == 1 through the lock-step code as well
+void* azo_tree_new_mt(int game_kind, int has_root, uint64_t mine, uint64_t theirs, uint64_t reserve, uint64_t sims, uint64_t threads,
+                      uint64_t max_depth, uint64_t model_id, int cpuct, int net_kind, uint64_t salt, uint32_t qbits, int force_lockstep) {
+    try {
+        if (game_kind == 0)
+            return make_tree<C4Bits>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits, threads, force_lockstep != 0);
+        if (game_kind == 2)
+            return make_tree<C3Bits>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits, threads, force_lockstep != 0);
+        return make_tree<C4Array>(has_root, mine, theirs, reserve, sims, max_depth, model_id, cpuct, net_kind, salt, qbits, threads, force_lockstep != 0);
+    } catch (const std::exception&) {
+        return nullptr;
+    }
+}
 void azo_tree_free(void* t) { delete (TreeBase*)t; }
 int azo_tree_get_action_prob(void* t, uint64_t mine, uint64_t theirs, float temp, uint64_t seed, uint64_t game_id,
                              float* pi, uint16_t* counts, float* q) {
@@ -204,10 +219,10 @@ void azo_tree_set_replay(void* t, const uint64_t* states, const float* pis, cons
     r->states = states; r->pis = pis; r->vs = vs; r->n = (size_t)n; r->pos = 0; r->mismatch = false;
 }
 int azo_tree_replay_bad(void* t) { return ((TreeBase*)t)->replay_net()->mismatch ? 1 : 0; }
-void azo_tree_stats(void* t, uint64_t* out7) {
+void azo_tree_stats(void* t, uint64_t* out8) {
     SearchStats s = ((TreeBase*)t)->stats();
-    out7[0] = s.sims; out7[1] = s.expansions; out7[2] = s.leaf_evals; out7[3] = s.link_hits;
-    out7[4] = s.terminal_hits; out7[5] = s.depth_sum; out7[6] = ((TreeBase*)t)->n_nodes();
+    out8[0] = s.sims; out8[1] = s.expansions; out8[2] = s.leaf_evals; out8[3] = s.link_hits;
+    out8[4] = s.terminal_hits; out8[5] = s.depth_sum; out8[6] = ((TreeBase*)t)->n_nodes(); out8[7] = s.abandoned;
 }
 
 // ---- Coach::execute_episode x n_games ---------------------------------------
@@ -221,7 +236,8 @@ int64_t azo_selfplay(int64_t n_games, uint64_t first_game_id, uint64_t sims, uin
                      uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind, uint64_t salt,
                      int game_kind, uint32_t qbits, int threads, float* boards, float* pis, float* zs,
                      int64_t cap, int32_t* game_len, uint8_t* moves, uint64_t* stats6, const int64_t* rec_off,
-                     const uint64_t* rec_states, const float* rec_pi, const float* rec_v, int32_t* replay_bad) {
+                     const uint64_t* rec_states, const float* rec_pi, const float* rec_v, int32_t* replay_bad, int sim_threads) {
+    const size_t ST = sim_threads > 0 ? (size_t)sim_threads : 1;     // num_sim_threads, src/coach.rs:249
     struct PerGame { std::vector<TrainingSample> s; std::vector<uint8_t> moves; SearchStats st; bool bad = false; bool err = false; };
     std::vector<PerGame> res((size_t)n_games);
     auto run_one = [&](int64_t g) {
@@ -236,17 +252,17 @@ int64_t azo_selfplay(int64_t n_games, uint64_t first_game_id, uint64_t sims, uin
             }
             Quirks q = quirks_from_bits(qbits);
             if (game_kind == 0) {
-                AsyncMcts<C4Bits> m(reserve, sims, 1, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
+                AsyncMcts<C4Bits> m(reserve, sims, ST, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
                 m.quirks = q;
                 res[g].s = execute_episode<C4Bits>(m, temp_threshold, seed, first_game_id + (uint64_t)g, &res[g].moves);
                 res[g].st = m.stats;
             } else if (game_kind == 2) {
-                AsyncMcts<C3Bits> m(reserve, sims, 1, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
+                AsyncMcts<C3Bits> m(reserve, sims, ST, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
                 m.quirks = q;
                 res[g].s = execute_episode<C3Bits>(m, temp_threshold, seed, first_game_id + (uint64_t)g, &res[g].moves);
                 res[g].st = m.stats;
             } else {
-                AsyncMcts<C4Array> m(reserve, sims, 1, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
+                AsyncMcts<C4Array> m(reserve, sims, ST, max_depth, 0, cpuct, nets.get(net_kind), C4_W);
                 m.quirks = q;
                 res[g].s = execute_episode<C4Array>(m, temp_threshold, seed, first_game_id + (uint64_t)g, &res[g].moves);
                 res[g].st = m.stats;
@@ -293,22 +309,45 @@ int64_t azo_selfplay(int64_t n_games, uint64_t first_game_id, uint64_t sims, uin
 // results[g] (optional, [num]) = +1 first seat won, -1 second seat won, 0 draw.
 }  // extern "C" (the arena body is a template over the game; its C entry points follow it)
 
+// Replay streams of an arena (replay parity of az_arena with recorded conv-net rows): per game and per model the
+// (state, pi, v) rows that model's tree consumed, flattened with offsets [n_games + 1]
+struct ArenaReplay {
+    const int64_t* off[2] = {nullptr, nullptr};        // [0] new model, [1] old model
+    const uint64_t* states[2] = {nullptr, nullptr};
+    const float* pi[2] = {nullptr, nullptr};
+    const float* v[2] = {nullptr, nullptr};
+    int32_t* bad = nullptr;                            // [n_games]
+};
+
+// games [first_game, first_game + n_games) of an arena of `total` games (seating and RNG by the global game index);
+// start = play_games' `board: Option<G>` (src/arena.rs:62-67), nullptr = None
 template <class G>
-static int arena_impl(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
-                      uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
-    using C4Bits = G;      // the body below was written for the bitboard game; G is CBits<4> or CBits<3>
+static int arena_impl(uint64_t total, uint64_t first_game, uint64_t n_games, uint64_t sims, size_t sim_threads, int cpuct, uint64_t max_depth,
+                      uint64_t reserve, uint64_t seed, int net_kind, uint64_t salt, int new_model_id, int old_model_id, int threads,
+                      uint64_t* wld3, int8_t* results, const uint64_t* start, const ArenaReplay* rp) {
     try {
-        uint64_t half = num / 2;
-        std::vector<int8_t> res(2 * half, 0);
-        auto run_one = [&](uint64_t gi) {
+        const uint64_t half = total / 2;
+        std::vector<int8_t> res(n_games, 0);
+        std::optional<G> board0;
+        if (start) board0 = G{start[0], start[1]};
+        auto run_one = [&](uint64_t li) {
+            const uint64_t gi = first_game + li;
             int first = gi < half ? 0 : 1;
-            NetBox nets;
-            nets.hash.salt = salt;
-            AsyncMcts<C4Bits> trees[2] = {
-                AsyncMcts<C4Bits>(reserve, sims, 1, max_depth, (size_t)new_model_id, cpuct, nets.get(net_kind), C4_W),
-                AsyncMcts<C4Bits>(reserve, sims, 1, max_depth, (size_t)old_model_id, cpuct, nets.get(net_kind), C4_W)};
+            NetBox nets[2];                             // [0] the new model's net, [1] the old model's
+            for (int m = 0; m < 2; ++m) {
+                nets[m].hash.salt = salt;
+                if (net_kind == NET_REPLAY && rp) {
+                    nets[m].replay.states = rp->states[m] ? rp->states[m] + 2 * rp->off[m][li] : nullptr;
+                    nets[m].replay.pis = rp->pi[m] + 7 * rp->off[m][li];
+                    nets[m].replay.vs = rp->v[m] + rp->off[m][li];
+                    nets[m].replay.n = (size_t)(rp->off[m][li + 1] - rp->off[m][li]);
+                }
+            }
+            AsyncMcts<G> trees[2] = {
+                AsyncMcts<G>(reserve, sims, sim_threads, max_depth, (size_t)new_model_id, cpuct, nets[0].get(net_kind), C4_W),
+                AsyncMcts<G>(reserve, sims, sim_threads, max_depth, (size_t)old_model_id, cpuct, nets[1].get(net_kind), C4_W)};
             auto mk = [&](int slot) {
-                return std::function<uint8_t(const C4Bits&)>([&trees, slot, seed, gi](const C4Bits& s) {
+                return std::function<uint8_t(const G&)>([&trees, slot, seed, gi](const G& s) {
                     uint64_t ply = (uint64_t)__builtin_popcountll(s.p1 | s.m1);
                     auto p = trees[slot].get_action_prob(s, 0.0f, seed, gi, ply);   // src/coach.rs:369-372
                     // argmax with max_by (last max), src/coach.rs:356-363
@@ -317,31 +356,34 @@ static int arena_impl(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth
                     return (uint8_t)best;
                 });
             };
-            std::function<uint8_t(const C4Bits&)> acts[2] = {mk(first), mk(1 - first)};
-            res[gi] = play_game<C4Bits>(acts, std::nullopt);
+            std::function<uint8_t(const G&)> acts[2] = {mk(first), mk(1 - first)};
+            res[li] = play_game<G>(acts, board0);
+            if (net_kind == NET_REPLAY && rp && rp->bad)
+                rp->bad[li] = (nets[0].replay.mismatch || nets[0].replay.pos != nets[0].replay.n || nets[1].replay.mismatch ||
+                               nets[1].replay.pos != nets[1].replay.n) ? 1 : 0;
         };
         if (threads <= 1) {
-            for (uint64_t g = 0; g < 2 * half; ++g) run_one(g);
+            for (uint64_t g = 0; g < n_games; ++g) run_one(g);
         } else {
             std::atomic<uint64_t> next{0};
             std::vector<std::thread> pool;
             std::atomic<bool> failed{false};
             for (int t = 0; t < threads; ++t)
                 pool.emplace_back([&] {
-                    try { for (uint64_t g; (g = next.fetch_add(1)) < 2 * half;) run_one(g); }
+                    try { for (uint64_t g; (g = next.fetch_add(1)) < n_games;) run_one(g); }
                     catch (...) { failed = true; }
                 });
             for (auto& th : pool) th.join();
             if (failed) return -1;
         }
         wld3[0] = wld3[1] = wld3[2] = 0;
-        for (uint64_t gi = 0; gi < 2 * half; ++gi) {
-            int first = gi < half ? 0 : 1;
+        for (uint64_t li = 0; li < n_games; ++li) {
+            int first = first_game + li < half ? 0 : 1;
             int win_cond = first == 0 ? 1 : -1, lose_cond = first == 0 ? -1 : 1;   // src/arena.rs:80-81
-            if (res[gi] == win_cond) wld3[0]++;
-            else if (res[gi] == lose_cond) wld3[1]++;
+            if (res[li] == win_cond) wld3[0]++;
+            else if (res[li] == lose_cond) wld3[1]++;
             else wld3[2]++;
-            if (results) results[gi] = res[gi];
+            if (results) results[li] = res[li];
         }
         return 0;
     } catch (const std::exception&) {
@@ -352,10 +394,27 @@ static int arena_impl(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth
 extern "C" {
 int azo_arena(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
               uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
-    return arena_impl<CBits<4>>(num, sims, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id, threads, wld3, results);
+    return arena_impl<CBits<4>>(2 * (num / 2), 0, 2 * (num / 2), sims, 1, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id, threads,
+                                wld3, results, nullptr, nullptr);
 }
 int azo_arena_c3(uint64_t num, uint64_t sims, int cpuct, uint64_t max_depth, uint64_t reserve, uint64_t seed, int net_kind,
                  uint64_t salt, int new_model_id, int old_model_id, int threads, uint64_t* wld3, int8_t* results) {
-    return arena_impl<CBits<3>>(num, sims, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id, threads, wld3, results);
+    return arena_impl<CBits<3>>(2 * (num / 2), 0, 2 * (num / 2), sims, 1, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id, old_model_id, threads,
+                                wld3, results, nullptr, nullptr);
+}
+// The general form: games [first_game, first_game + n_games) of a `total`-game arena (Connect Four), sim_threads simulations in
+// flight per tree, an optional start board [2] and optional replay streams (net_kind 2): for model m (0 new, 1 old)
+// off_m [n_games + 1] into states_m [N,2] (may be NULL) / pi_m [N,7] / v_m [N]; replay_bad [n_games].
+int azo_arena_ex(uint64_t total, uint64_t first_game, uint64_t n_games, uint64_t sims, int sim_threads, int cpuct, uint64_t max_depth,
+                 uint64_t reserve, uint64_t seed, int net_kind, uint64_t salt, int new_model_id, int old_model_id, int threads,
+                 uint64_t* wld3, int8_t* results, const uint64_t* start_board,
+                 const int64_t* off_new, const uint64_t* states_new, const float* pi_new, const float* v_new,
+                 const int64_t* off_old, const uint64_t* states_old, const float* pi_old, const float* v_old, int32_t* replay_bad) {
+    ArenaReplay rp;
+    rp.off[0] = off_new; rp.states[0] = states_new; rp.pi[0] = pi_new; rp.v[0] = v_new;
+    rp.off[1] = off_old; rp.states[1] = states_old; rp.pi[1] = pi_old; rp.v[1] = v_old;
+    rp.bad = replay_bad;
+    return arena_impl<CBits<4>>(total, first_game, n_games, sims, sim_threads > 0 ? (size_t)sim_threads : 1, cpuct, max_depth, reserve, seed, net_kind,
+                                salt, new_model_id, old_model_id, threads, wld3, results, start_board, off_new ? &rp : nullptr);
 }
 }  // extern "C"

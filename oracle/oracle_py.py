@@ -60,13 +60,20 @@ def lib():
         L.azo_hashnet.restype = None; L.azo_hashnet.argtypes = [u64, u64, u64, vp, vp]
         L.azo_tree_new.restype = vp
         L.azo_tree_new.argtypes = [i32, i32, u64, u64, u64, u64, u64, u64, i32, i32, u64, u32]
+        L.azo_tree_new_mt.restype = vp
+        L.azo_tree_new_mt.argtypes = [i32, i32, u64, u64, u64, u64, u64, u64, u64, i32, i32, u64, u32, i32]
+        L.azo_tree_set_replay.restype = None; L.azo_tree_set_replay.argtypes = [vp, vp, vp, vp, u64]
+        L.azo_tree_replay_bad.restype = i32; L.azo_tree_replay_bad.argtypes = [vp]
         L.azo_tree_free.restype = None; L.azo_tree_free.argtypes = [vp]
         L.azo_tree_get_action_prob.restype = i32
         L.azo_tree_get_action_prob.argtypes = [vp, u64, u64, f32, u64, u64, vp, vp, vp]
         L.azo_tree_stats.restype = None; L.azo_tree_stats.argtypes = [vp, vp]
         L.azo_selfplay.restype = i64
         L.azo_selfplay.argtypes = [i64, u64, u64, u64, i32, u64, u64, u64, i32, u64, i32, u32, i32, vp, vp, vp, i64,
-                                   vp, vp, vp, vp, vp, vp, vp, vp]
+                                   vp, vp, vp, vp, vp, vp, vp, vp, i32]
+        L.azo_arena_ex.restype = i32
+        L.azo_arena_ex.argtypes = [u64, u64, u64, u64, i32, i32, u64, u64, u64, i32, u64, i32, i32, i32, vp, vp, vp,
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.azo_arena.restype = i32
         L.azo_arena.argtypes = [u64, u64, i32, u64, u64, u64, i32, u64, i32, i32, i32, vp, vp]
         L.azo_arena_c3.restype = i32
@@ -95,12 +102,15 @@ class Tree:
     """One AsyncMcts (src/async_mcts.rs:14-115) on the CPU oracle."""
 
     def __init__(self, sims, net_kind=NET_STUB, salt=0, cpuct=1, max_depth=1000, reserve=None, model_id=0,
-                 game_kind=GAME_BITS, root=None, quirks=0):
+                 game_kind=GAME_BITS, root=None, quirks=0, threads=1, force_lockstep=False):
+        """threads = num_threads of AsyncMcts::default (src/async_mcts.rs:27-36): simulations in flight per tree; > 1 runs the
+        oracle's lock-step schedule (az_oracle.hpp)."""
         reserve = reserve or default_reserve(sims)
         has_root = 0 if root is None else 1
         m, t = (0, 0) if root is None else root
-        self._h = lib().azo_tree_new(game_kind, has_root, m, t, reserve, sims, max_depth, model_id, cpuct, net_kind,
-                                     salt, quirks)
+        self._keep = None
+        self._h = lib().azo_tree_new_mt(game_kind, has_root, m, t, reserve, sims, threads, max_depth, model_id, cpuct, net_kind,
+                                        salt, quirks, 1 if force_lockstep else 0)
         if not self._h:
             raise RuntimeError("azo_tree_new failed")
 
@@ -114,10 +124,18 @@ class Tree:
         return pi, counts, q
 
     def stats(self):
-        out = np.zeros(7, np.uint64)
+        out = np.zeros(8, np.uint64)
         lib().azo_tree_stats(self._h, _p(out))
-        return dict(zip(("sims", "expansions", "leaf_evals", "link_hits", "terminal_hits", "depth_sum", "nodes"),
+        return dict(zip(("sims", "expansions", "leaf_evals", "link_hits", "terminal_hits", "depth_sum", "nodes", "abandoned"),
                         (int(x) for x in out)))
+
+    def set_replay(self, states, pis, vs):
+        """Feed recorded (state, pi, v) rows back in order (a tree created with net_kind NET_REPLAY)."""
+        self._keep = (np.ascontiguousarray(states, np.uint64), np.ascontiguousarray(pis, np.float32), np.ascontiguousarray(vs, np.float32))
+        lib().azo_tree_set_replay(self._h, _p(self._keep[0]), _p(self._keep[1]), _p(self._keep[2]), len(self._keep[2]))
+
+    def replay_bad(self):
+        return bool(lib().azo_tree_replay_bad(self._h))
 
     def close(self):
         if self._h:
@@ -132,7 +150,7 @@ class Tree:
 
 
 def selfplay(n_games, sims, net_kind=NET_STUB, salt=0, seed=0, first_game_id=0, temp_threshold=15, cpuct=1,
-             max_depth=1000, reserve=None, game_kind=GAME_BITS, quirks=0, threads=1, want_samples=True, replay=None):
+             max_depth=1000, reserve=None, game_kind=GAME_BITS, quirks=0, threads=1, want_samples=True, replay=None, sim_threads=1):
     """Coach::execute_episode x n_games on the oracle.  replay = (rec_off [n+1] int64, states [N,2] u64 or None,
     pis [N,7], vs [N]) feeds recorded net outputs back (replay parity)."""
     reserve = reserve or default_reserve(sims)
@@ -152,7 +170,7 @@ def selfplay(n_games, sims, net_kind=NET_STUB, salt=0, seed=0, first_game_id=0, 
         rv = np.ascontiguousarray(replay[3], np.float32)
     n = lib().azo_selfplay(n_games, first_game_id, sims, temp_threshold, cpuct, max_depth, reserve, seed, net_kind, salt,
                            game_kind, quirks, threads, _p(boards), _p(pis), _p(zs), cap, _p(game_len), _p(moves),
-                           _p(stats), _p(ro), _p(rs), _p(rp), _p(rv), _p(bad))
+                           _p(stats), _p(ro), _p(rs), _p(rp), _p(rv), _p(bad), sim_threads)
     if n < 0:
         raise RuntimeError("oracle selfplay failed")
     res = {"count": int(n), "game_len": game_len, "moves": moves, "replay_bad": bad,
@@ -174,6 +192,35 @@ def arena(num, sims, net_kind=NET_HASH, salt=0, seed=0, new_model_id=1, old_mode
     if rc != 0:
         raise RuntimeError("oracle arena failed")
     return wld, results[: 2 * (num // 2)]
+
+
+def arena_ex(total, sims, first_game=0, n_games=None, net_kind=NET_HASH, salt=0, seed=0, new_model_id=1, old_model_id=0, cpuct=1,
+             max_depth=1000, reserve=None, threads=1, sim_threads=1, start_board=None, replay_new=None, replay_old=None):
+    """Games [first_game, first_game + n_games) of a `total`-game arena.  replay_new / replay_old = (off [n+1] int64, states [N,2]
+    u64 or None, pis [N,7], vs [N]): the rows each model's trees consumed, per game (net_kind NET_REPLAY).
+    Returns (wld, results, replay_bad)."""
+    reserve = reserve or default_reserve(sims)
+    n_games = total - first_game if n_games is None else n_games
+    wld = np.zeros(3, np.uint64)
+    results = np.zeros(max(n_games, 1), np.int8)
+    bad = np.zeros(max(n_games, 1), np.int32)
+    sb = None if start_board is None else np.ascontiguousarray(start_board, np.uint64)
+    keep = []
+
+    def unpack(r):
+        if r is None:
+            return [None] * 4
+        a = [np.ascontiguousarray(r[0], np.int64), None if r[1] is None else np.ascontiguousarray(r[1], np.uint64),
+             np.ascontiguousarray(r[2], np.float32), np.ascontiguousarray(r[3], np.float32)]
+        keep.append(a)
+        return a
+    rn, ro = unpack(replay_new), unpack(replay_old)
+    rc = lib().azo_arena_ex(total, first_game, n_games, sims, sim_threads, cpuct, max_depth, reserve, seed, net_kind, salt, new_model_id,
+                            old_model_id, threads, _p(wld), _p(results), _p(sb), _p(rn[0]), _p(rn[1]), _p(rn[2]), _p(rn[3]),
+                            _p(ro[0]), _p(ro[1]), _p(ro[2]), _p(ro[3]), _p(bad))
+    if rc != 0:
+        raise RuntimeError("oracle arena failed")
+    return wld, results[:n_games], bad[:n_games]
 
 
 _cb_keepalive = None

@@ -25,13 +25,15 @@ pub struct az_stats {
     pub leaf_rows_requested: u64, pub leaf_rows_executed: u64, pub eval_cache_hits: u64, pub eval_batch_dups: u64,
     pub eval_cache_inserts: u64, pub net_conv3_ms: f64, pub net_conv3_flops: f64, pub net_conv2_bytes: f64,
     pub tree_launches: u64, pub tree_launches_timed: u64, pub tree_arena_allocs: u64,
+    pub net_conv4_ms: f64, pub net_conv4_flops: f64, pub net_fc_ms: f64, pub net_fc_flops: f64, pub net_rows_timed: f64,
+    pub abandoned_sims: u64,
 }
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct az_selfplay_params {
     pub n_games: i32, pub concurrent: i32, pub num_sims: i32, pub temp_threshold: i32,
     pub max_depth: i32, pub cpuct: i32, pub model_id: i32, pub symmetries: i32,
-    pub reserve: u64, pub seed: u64, pub first_game_id: u64, pub record_evals: i32, pub reserved0: i32,
+    pub reserve: u64, pub seed: u64, pub first_game_id: u64, pub record_evals: i32, pub num_sim_threads: i32,
 }
 #[repr(C)]
 pub struct az_samples {
@@ -42,7 +44,8 @@ pub struct az_samples {
 pub struct az_arena_params {
     pub num_games: i32, pub num_sims: i32, pub max_depth: i32, pub cpuct: i32,
     pub new_model_id: i32, pub old_model_id: i32, pub reserve: u64, pub seed: u64,
-    pub first_game: i32, pub total_games: i32,
+    pub first_game: i32, pub total_games: i32, pub record_evals: i32, pub num_sim_threads: i32,
+    pub use_start_board: i32, pub allreduce_wld: i32, pub start_board: [u64; 2],
 }
 
 extern "C" {
@@ -71,7 +74,7 @@ extern "C" {
                              apply: i32, loss_out: *mut f32, grads_out: *mut f32) -> c_int;
     pub fn az_net_train_end(e: *mut az_engine, model_id: i32) -> c_int;
     // ---- AsyncMcts, src/async_mcts.rs:14-115
-    pub fn az_tree_create(e: *mut az_engine, n_games: i32, reserve: u64, num_sims: i32, max_depth: i32,
+    pub fn az_tree_create(e: *mut az_engine, n_games: i32, reserve: u64, num_sims: i32, num_threads: i32, max_depth: i32,
                           model_id: i32, cpuct: i32, out: *mut *mut az_tree) -> c_int;
     pub fn az_tree_destroy(t: *mut az_tree);
     pub fn az_tree_reset(t: *mut az_tree, root_states: *const u64) -> c_int;
@@ -84,6 +87,13 @@ extern "C" {
     pub fn az_selfplay(e: *mut az_engine, p: *const az_selfplay_params, out: *mut az_samples) -> c_int;
     pub fn az_selfplay_get_evals(e: *mut az_engine, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;
     pub fn az_arena(e: *mut az_engine, p: *const az_arena_params, out_wld: *mut u64, results: *mut i8) -> c_int;
+    pub fn az_arena_get_evals(e: *mut az_engine, which: i32, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;
+    // ---- the collective of the sharded Coach loop (one process per GPU; RCCL on the engine's stream)
+    pub fn az_comm_unique_id(e: *mut az_engine, id: *mut u8) -> c_int;
+    pub fn az_comm_init(e: *mut az_engine, rank: i32, world: i32, id: *const u8) -> c_int;
+    pub fn az_comm_destroy(e: *mut az_engine) -> c_int;
+    pub fn az_gather_samples(e: *mut az_engine, local: *const az_samples, dst_rank: i32, gathered: *mut az_samples, counts_out: *mut i64) -> c_int;
+    pub fn az_allreduce_u64(e: *mut az_engine, values: *mut u64, n: i32) -> c_int;
 }
 
 /// The reference panics on every error (unwrap/assert!); keep that behaviour.
@@ -128,15 +138,16 @@ impl Drop for Mi355xNNet { fn drop(&mut self) { unsafe { az_destroy(self.e) } } 
 pub struct Mi355xMcts { pub e: *mut az_engine, pub t: *mut az_tree, pub n_games: usize }
 
 impl Mi355xMcts {
-    /// AsyncMcts::default(reserve_space, num_sims, 1, max_depth, model_id, cpuct, ..), src/async_mcts.rs:27-48
-    pub fn default(e: *mut az_engine, n_games: usize, reserve_space: usize, num_sims: usize, max_depth: usize, model_id: usize, cpuct: i32) -> Self {
+    /// AsyncMcts::default(reserve_space, num_sims, num_threads, max_depth, model_id, cpuct, ..), src/async_mcts.rs:27-48;
+    /// num_threads > 1 = several simulations in flight per tree as a deterministic lock-step schedule (az_engine.h)
+    pub fn default(e: *mut az_engine, n_games: usize, reserve_space: usize, num_sims: usize, num_threads: usize, max_depth: usize, model_id: usize, cpuct: i32) -> Self {
         let mut t = std::ptr::null_mut();
-        check(e, unsafe { az_tree_create(e, n_games as i32, reserve_space as u64, num_sims as i32, max_depth as i32, model_id as i32, cpuct, &mut t) });
+        check(e, unsafe { az_tree_create(e, n_games as i32, reserve_space as u64, num_sims as i32, num_threads as i32, max_depth as i32, model_id as i32, cpuct, &mut t) });
         Mi355xMcts { e, t, n_games }
     }
     /// AsyncMcts::from_state(s, ..), src/async_mcts.rs:50-72: every tree re-rooted at its canonical bitboards [n_games, 2]
-    pub fn from_state(e: *mut az_engine, root_states: &[u64], reserve_space: usize, num_sims: usize, max_depth: usize, model_id: usize, cpuct: i32) -> Self {
-        let m = Self::default(e, root_states.len() / 2, reserve_space, num_sims, max_depth, model_id, cpuct);
+    pub fn from_state(e: *mut az_engine, root_states: &[u64], reserve_space: usize, num_sims: usize, num_threads: usize, max_depth: usize, model_id: usize, cpuct: i32) -> Self {
+        let m = Self::default(e, root_states.len() / 2, reserve_space, num_sims, num_threads, max_depth, model_id, cpuct);
         check(e, unsafe { az_tree_reset(m.t, root_states.as_ptr()) });
         m
     }
@@ -173,6 +184,29 @@ pub fn self_play(e: *mut az_engine, p: &az_selfplay_params) -> (Vec<f32>, Vec<f3
     let n = out.count as usize;
     boards.truncate(n * 84); pis.truncate(n * 7); zs.truncate(n);
     (boards, pis, zs)
+}
+
+/// The ONE exchange of a sharded episode batch (each rank played `p.first_game_id ..` of the global episode ids): this rank's
+/// (states [n,2], pis [n,7], zs [n]) go to `dst_rank`, which gets everybody's tuples in rank order (else empty vectors).
+pub fn gather_samples(e: *mut az_engine, states: &mut [u64], pis: &mut [f32], zs: &mut [f32], rank: i32, world: i32, dst_rank: i32)
+                      -> (Vec<u64>, Vec<f32>, Vec<f32>) {
+    let n = zs.len();
+    let local = az_samples { capacity: n as i64, count: n as i64, states: states.as_mut_ptr(), boards: std::ptr::null_mut(),
+                             pis: pis.as_mut_ptr(), zs: zs.as_mut_ptr(), game_len: std::ptr::null_mut(), moves: std::ptr::null_mut() };
+    let mut counts = vec![0i64; world as usize];
+    if rank != dst_rank {
+        check(e, unsafe { az_gather_samples(e, &local, dst_rank, std::ptr::null_mut(), counts.as_mut_ptr()) });
+        return (vec![], vec![], vec![]);
+    }
+    // capacity: the caller's bound on the global batch (42 plies per episode at most); two passes would need the counts first
+    let cap = n * world as usize + 42 * world as usize;
+    let (mut gs, mut gp, mut gz) = (vec![0u64; cap * 2], vec![0f32; cap * 7], vec![0f32; cap]);
+    let mut g = az_samples { capacity: cap as i64, count: 0, states: gs.as_mut_ptr(), boards: std::ptr::null_mut(),
+                             pis: gp.as_mut_ptr(), zs: gz.as_mut_ptr(), game_len: std::ptr::null_mut(), moves: std::ptr::null_mut() };
+    check(e, unsafe { az_gather_samples(e, &local, dst_rank, &mut g, counts.as_mut_ptr()) });
+    let m = g.count as usize;
+    gs.truncate(m * 2); gp.truncate(m * 7); gz.truncate(m);
+    (gs, gp, gz)
 }
 
 /// Replaces `play_games` + the tally of src/coach.rs:365-381: (nwins, pwins, draws) for the new model.

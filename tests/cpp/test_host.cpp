@@ -27,8 +27,20 @@ int main(int argc, char** argv) {
             for (auto& s : samples) { zsum += s.v; for (float p : s.pi) pisum += p; }
             std::printf("], \"samples\": %zu, \"zsum\": %.9g, \"pisum\": %.9g}", samples.size(), zsum, pisum);
         }
+        // the same with two simulations in flight per tree (num_threads = 2, src/async_mcts.rs:27-36, :191-217)
+        std::printf("], \"episodes_t2\": [");
+        for (int ep = 0; ep < episodes; ++ep) {
+            AsyncMcts mcts = AsyncMcts::default_(e, 1000000, sims + sims % 2, 2, 1000, 10, 1);
+            std::vector<uint8_t> moves;
+            auto samples = execute_episode(mcts, 15, ep, seed, &moves);
+            std::printf("%s[", ep ? ", " : "");
+            for (size_t i = 0; i < moves.size(); ++i) std::printf("%s%d", i ? "," : "", moves[i]);
+            std::printf("]");
+        }
+        bool odd_panics = false;
+        try { AsyncMcts::default_(e, 1000, 25, 2, 1000, 10, 1); } catch (const Panic&) { odd_panics = true; }    // 25 % 2 != 0, :192
         // arena: one game per seating with a fresh tree pair per game (B8), closures as src/coach.rs:365-372
-        std::printf("], \"arena\": [");
+        std::printf("], \"odd_sims_panic\": %s, \"arena\": [", odd_panics ? "true" : "false");
         for (int g = 0; g < 2; ++g) {
             AsyncMcts nmcts = AsyncMcts::default_(e, 1000000, sims, 1, 1000, 11, 1);
             AsyncMcts pmcts = AsyncMcts::default_(e, 1000000, sims, 1, 1000, 10, 1);

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "az_engine.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(az_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(az_[a-z_0-9]+)\s*\(", hdr)))
 
 
 def test_header_symbols_are_exported(engine_mod):
@@ -26,8 +26,8 @@ def test_struct_layouts_match_header(engine_mod):
     assert ctypes.sizeof(engine_mod.az_config) == 20
     assert ctypes.sizeof(engine_mod.az_selfplay_params) == 64
     assert ctypes.sizeof(engine_mod.az_samples) == 64
-    assert ctypes.sizeof(engine_mod.az_arena_params) == 48
-    assert ctypes.sizeof(engine_mod.az_stats) == 28 * 8
+    assert ctypes.sizeof(engine_mod.az_arena_params) == 80
+    assert ctypes.sizeof(engine_mod.az_stats) == 34 * 8
 
 
 def test_no_gpu_fails_loudly(engine_mod):
@@ -123,10 +123,10 @@ def _header_functions():
     hdr = open(os.path.join(ROOT, "include", "az_engine.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     fns = {}
-    for ret, name, args in re.findall(r"\b([A-Za-z_0-9]+\s*\**)\s*\b(az_[a-z_]+)\s*\(([^)]*)\)\s*;", hdr):
+    for ret, name, args in re.findall(r"\b([A-Za-z_0-9]+\s*\**)\s*\b(az_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", hdr):
         params = []
         for a in [x.strip() for x in args.split(",") if x.strip()]:
-            m = re.match(r"(.*?)([A-Za-z_0-9]+)(\[\d*\])?$", a)
+            m = re.match(r"(.*?)([A-Za-z_0-9]+)(\[[A-Za-z_0-9]*\])?$", a)
             ctype = m.group(1).strip() + ("*" if m.group(3) else "")
             params.append(_rust_type(ctype))
         r = ret.replace(" ", "")
@@ -142,8 +142,9 @@ def _header_structs():
     for body, name in re.findall(r"typedef struct [a-z_]+ \{(.*?)\}\s*([a-z_]+);", hdr, flags=re.S):
         fields = []
         for decl in [d.strip() for d in body.split(";") if d.strip()]:
-            m = re.match(r"(.*?)([A-Za-z_0-9]+)$", decl)
-            fields.append((m.group(2), _rust_type(m.group(1))))
+            m = re.match(r"(.*?)([A-Za-z_0-9]+)(\[(\d+)\])?$", decl)
+            rt = _rust_type(m.group(1))
+            fields.append((m.group(2), "[%s; %s]" % (rt, m.group(4)) if m.group(3) else rt))
         out[name] = fields
     return out
 
@@ -156,7 +157,7 @@ def test_rust_shim_matches_the_header():
     ext = ext[:ext.index("\n}\n")]
     ext = re.sub(r"//[^\n]*", "", ext)
     rust = {}
-    for name, args, ret in re.findall(r"pub fn (az_[a-z_]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", ext, flags=re.S):
+    for name, args, ret in re.findall(r"pub fn (az_[a-z_0-9]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", ext, flags=re.S):
         params = [a.split(":", 1)[1].strip() for a in args.split(",") if a.strip()]
         rust[name] = (ret.strip() if ret else None, params)
     hdr = _header_functions()
@@ -169,7 +170,7 @@ def test_rust_shim_matches_the_header():
     assert set(structs) == {"az_config", "az_stats", "az_selfplay_params", "az_samples", "az_arena_params"}
     for sname, fields in structs.items():
         m = re.search(r"pub struct %s \{(.*?)\}" % sname, src, flags=re.S)
-        rfields = [(n, t.strip()) for n, t in re.findall(r"pub ([a-z_0-9]+):\s*([^,}]+)", m.group(1))]
+        rfields = [(n, t.strip()) for n, t in re.findall(r"pub ([a-z_0-9]+):\s*(\[[^\]]+\]|[^,}]+)", m.group(1))]
         assert rfields == fields, (sname, rfields, fields)
     # the NNet / AsyncMcts surfaces the reference's callers use
     for needle in ("pub fn new<P: AsRef<Path>>", "pub fn predict(", "pub fn train(", "pub fn from_state(", "pub fn get_action_prob("):

@@ -83,10 +83,10 @@ class FakeEngine:
         self.params[model_id].tofile(path)
 
     def selfplay(self, n_games, num_sims, model_id, seed, first_game_id, concurrent, temp_threshold, max_depth, cpuct,
-                 reserve, symmetries, want_boards):
+                 reserve, symmetries, want_boards, num_sim_threads=1):
         self.calls.append(("selfplay", n_games, first_game_id, model_id))
         r = self.oracle.selfplay(n_games, num_sims, net_kind=self.oracle.NET_HASH, salt=self._salt(model_id), seed=seed,
-                                 first_game_id=first_game_id, temp_threshold=temp_threshold, threads=4)
+                                 first_game_id=first_game_id, temp_threshold=temp_threshold, threads=4, sim_threads=num_sim_threads)
         from alphazero_rs_amd import dist as azdist
         b = r["boards"][0::2]
         states = np.zeros((b.shape[0], 2), np.uint64)
@@ -97,11 +97,12 @@ class FakeEngine:
                 states[:, 1] |= np.where(b[:, 1, rr, c] != 0, bit, np.uint64(0))
         return {"states": states, "pis": r["pis"][0::2], "zs": r["zs"][0::2], "count": b.shape[0], "ref": r}
 
-    def arena(self, num_games, num_sims, new_model_id, old_model_id, seed, max_depth, cpuct, reserve, first_game=0, total_games=0):
+    def arena(self, num_games, num_sims, new_model_id, old_model_id, seed, max_depth, cpuct, reserve, first_game=0, total_games=0,
+              num_sim_threads=1):
         self.calls.append(("arena", num_games, new_model_id, old_model_id))
         total = total_games or 2 * (num_games // 2)
-        wld, res = self.oracle.arena(total, num_sims, net_kind=self.oracle.NET_HASH, salt=self._salt(new_model_id) ^ self._salt(old_model_id),
-                                     seed=seed, new_model_id=1, old_model_id=0, threads=4)
+        wld, res, _ = self.oracle.arena_ex(total, num_sims, net_kind=self.oracle.NET_HASH, salt=self._salt(new_model_id) ^ self._salt(old_model_id),
+                                           seed=seed, new_model_id=1, old_model_id=0, threads=4, sim_threads=num_sim_threads)
         if not total_games:
             return wld, res
         part = res[first_game:first_game + num_games]          # the shard's games of the full arena
@@ -201,7 +202,9 @@ def test_setup_contracts(mods, oracle, tmp_path):
     with pytest.raises(ValueError):
         coach.Coach.setup(eng, str(tmp_path), 1000, 0.6, 15, 2, 100, 3, 1, 4, 1, 1, 10, 1, 1000, 1)     # 10 % 3 != 0
     with pytest.raises(ValueError):
-        coach.Coach.setup(eng, str(tmp_path), 1000, 0.6, 15, 2, 100, 1, 1, 4, 1, 1, 10, 2, 1000, 1)     # sim threads != 1
+        coach.Coach.setup(eng, str(tmp_path), 1000, 0.6, 15, 2, 100, 1, 1, 4, 1, 1, 10, 3, 1000, 1)     # 10 % 3 sim threads != 0 (src/async_mcts.rs:192)
+    c = coach.Coach.setup(eng, str(tmp_path), 1000, 0.6, 15, 2, 100, 1, 1, 4, 1, 1, 10, 2, 1000, 1)  # two simulations in flight per tree
+    assert c.num_sim_threads == 2
 
 
 def test_states_to_boards(mods, oracle):

@@ -31,6 +31,11 @@ def test_cpp_host_mirror(engine_mod, oracle, tmp_path):
         assert abs(got["episodes"][ep]["zsum"] - z) < 1e-6
         assert abs(got["episodes"][ep]["pisum"] - 2 * n) < 1e-3
         off += 2 * n
+    # two simulations in flight per tree through AsyncMcts::default(.., num_threads = 2, ..): the oracle's lock-step schedule
+    ref2 = oracle.selfplay(episodes, sims + sims % 2, net_kind=oracle.NET_HASH, salt=1234 + 10 * MODEL_SALT, seed=17, threads=1, sim_threads=2)
+    for ep in range(episodes):
+        assert got["episodes_t2"][ep] == ref2["moves"][ep, :int(ref2["game_len"][ep])].tolist()
+    assert got["odd_sims_panic"] is True
     # arena: new = model 11, old = model 10, same base salt -> oracle salts base + id*MODEL_SALT
     wld, results = oracle.arena(2, sims, net_kind=oracle.NET_HASH, salt=1234, seed=17, new_model_id=11, old_model_id=10)
     assert got["arena"] == results.tolist()

@@ -44,6 +44,15 @@ def conv_engine(engine_mod):
     e.close()
 
 
+@pytest.fixture(scope="module")
+def diag_engine(engine_mod):
+    """An engine of libaz_engine_diag.so (the same sources built with -DAZ_DIAG): the superseded kernel generations, forced tiles and
+    kernel-family switches live there; the shipped library refuses them (test_shipped_library_refuses_diagnostic_options)."""
+    e = engine_mod.Engine(device=0, max_batch=2048, net_channels=C, diag=True)
+    yield e
+    e.close()
+
+
 @pytest.mark.parametrize("batch", [1, 3, 130, 700])
 def test_net_matches_torch_reference(conv_engine, oracle, batch):
     params = random_params(C, seed=batch)
@@ -76,12 +85,22 @@ def test_net_rows_are_batch_independent(conv_engine, oracle):
     assert np.array_equal(pi[17:18], pi_1) and np.array_equal(v[17:18], v_1)
 
 
-def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
-    """The implicit-GEMM kernel sets (128x128 register-staged, 256x256 LDS-DMA unphased / phased, image-resident conv2
+def test_gemm_kernel_variants_are_bit_identical(diag_engine, conv_engine, oracle):
+    """(On the diagnostic library, checked against the shipped one.)  The implicit-GEMM kernel sets (128x128 register-staged, 256x256 LDS-DMA unphased / phased, image-resident conv2
     as one 8-wave or two 4-wave workgroups per CU) sum every output row's K terms in the same order: their results are identical bit for bit, at ragged and
     tile-aligned batch sizes, so the A/B switch never changes what a search sees."""
+    shipped = conv_engine
+    shipped.net_init_random(5, seed=21)
+    conv_engine = diag_engine
     conv_engine.net_init_random(5, seed=21)
     try:
+        for table in (1, 0):                            # the shipped library's two kernel sets == the diagnostic library's defaults
+            shipped.set_option("conv2_table", table)
+            conv_engine.set_option("conv2_table", table)
+            st0 = random_states(oracle, 777, seed=3)
+            a, b = shipped.predict_states(st0, 5), conv_engine.predict_states(st0, 5)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), table
+        shipped.set_option("conv2_table", 1)
         conv_engine.set_option("conv2_table", 0)        # the GEMM kernel sets; conv2 as a table has its own rounding (below)
         for n in (1, 257, 1530):
             states = random_states(oracle, n, seed=900 + n)
@@ -125,7 +144,7 @@ def test_gemm_kernel_variants_are_bit_identical(conv_engine, oracle):
         conv_engine.set_option("conv1_table", 1)
 
 
-def test_net_parity_at_bench_scale(engine, oracle):
+def test_net_parity_at_bench_scale(engine, engine_mod, oracle):
     """The regime bench.py drives the net in (NNet::predict on the full batch, src/async_mcts.rs:150-151): ONE call of 8192 rows
     and one ragged call of 5003 rows (not a multiple of any tile: 6- and 12-board image tiles, 128/256-row GEMM tiles, the
     8-XCD tile remap with more than one grid round, conv4 on either kernel) must equal, bit for bit, the same rows predicted
@@ -133,34 +152,33 @@ def test_net_parity_at_bench_scale(engine, oracle):
     the plain kernel set; plus one direct comparison with the bf16-emulating torch reference at 4096 rows."""
     engine.net_init_random(20, seed=31)
     states = random_states(oracle, 8192, seed=77)
+    diag = engine_mod.Engine(device=0, max_batch=8192, net_channels=C, diag=True)      # the older kernel families, same rows
     try:
-        engine.set_option("gemm_variant", 5)
-        engine.set_option("conv4_big", 2)
+        diag.net_set_params(20, engine.net_get_params(20))
         engine.set_option("conv2_table", 0)
         ref_pi = np.empty((8192, 7), np.float32)
         ref_v = np.empty(8192, np.float32)
         for o in range(0, 8192, 256):
             ref_pi[o:o + 256], ref_v[o:o + 256] = engine.predict_states(states[o:o + 256], 20)
+        for n in (8192, 5003):
+            pi, v = engine.predict_states(states[:n], 20)
+            assert np.array_equal(pi, ref_pi[:n]) and np.array_equal(v, ref_v[:n]), n
+        diag.set_option("conv2_table", 0)
         for variant, table in ((5, 1), (5, 0), (0, 0)):        # table: conv2 gathers from the conv1 table / reads k_conv1's act1
             for big in (0, 1, 2):
-                engine.set_option("gemm_variant", variant)
-                engine.set_option("conv1_table", table)
-                engine.set_option("conv4_big", big)
+                diag.set_option("gemm_variant", variant)
+                diag.set_option("conv1_table", table)
+                diag.set_option("conv4_big", big)
                 for n in (8192, 5003):
-                    pi, v = engine.predict_states(states[:n], 20)
+                    pi, v = diag.predict_states(states[:n], 20)
                     assert np.array_equal(pi, ref_pi[:n]) and np.array_equal(v, ref_v[:n]), (variant, table, big, n)
-        engine.set_option("conv1_table", 1)
         # a different row order through the full-size kernels (rows land in other tiles / XCDs)
-        engine.set_option("gemm_variant", 5)
-        engine.set_option("conv4_big", 0)
         perm = np.random.default_rng(3).permutation(8192)
         pi, v = engine.predict_states(states[perm], 20)
         assert np.array_equal(pi, ref_pi[perm]) and np.array_equal(v, ref_v[perm])
     finally:
-        engine.set_option("gemm_variant", 5)
-        engine.set_option("conv4_big", 0)
-        engine.set_option("conv1_table", 1)
         engine.set_option("conv2_table", 1)
+        diag.close()
     n = 4096
     boards = np.stack([oracle.c4_features(int(m), int(t)) for m, t in states[:n]])
     rpi, rv = forward_ref(engine.net_get_params(20), boards, C, emulate_bf16=True)
@@ -177,13 +195,15 @@ def test_net_parity_at_bench_scale(engine, oracle):
         assert np.array_equal(pi, tab_pi[:m]) and np.array_equal(v, tab_v[:m]), m
     pi, v = engine.predict_states(states[perm], 20)
     assert np.array_equal(pi, tab_pi[perm]) and np.array_equal(v, tab_v[perm])
+    diag = engine_mod.Engine(device=0, max_batch=8192, net_channels=C, diag=True)
     try:                                                            # the gather as whole rows per wave (round 2's first kernel): same bits
-        engine.set_option("conv2_table", 2)
+        diag.net_set_params(20, engine.net_get_params(20))
+        diag.set_option("conv2_table", 2)
         for m in (8192, 5003, 3):
-            pi, v = engine.predict_states(states[:m], 20)
+            pi, v = diag.predict_states(states[:m], 20)
             assert np.array_equal(pi, tab_pi[:m]) and np.array_equal(v, tab_v[:m]), m
     finally:
-        engine.set_option("conv2_table", 1)
+        diag.close()
     assert np.abs(tab_pi[:n] - rpi).max() <= 2e-3, np.abs(tab_pi[:n] - rpi).max()
     assert np.abs(tab_v[:n] - rv).max() <= 6e-3, np.abs(tab_v[:n] - rv).max()
     assert not np.array_equal(tab_pi, ref_pi)                       # (a different rounding, not a different function)
@@ -349,6 +369,160 @@ def test_bench_scale_replay_parity_with_the_conv_net(engine, oracle):
     assert np.array_equal(pi2, pis[g, :256]) and np.array_equal(v2, vs[g, :256])
 
 
+def _flatten_log(cnt, states, pis, vs, ids):
+    """Per-game eval logs [G,cap,..] -> the oracle's replay stream for the games `ids` (offsets + flattened rows)."""
+    off = np.zeros(len(ids) + 1, np.int64)
+    off[1:] = np.cumsum([cnt[g] for g in ids])
+    cat = lambda a: np.ascontiguousarray(np.concatenate([a[g, :cnt[g]] for g in ids]))
+    return off, cat(states), cat(pis), cat(vs)
+
+
+def test_replay_parity_arena_with_two_conv_nets(engine, oracle):
+    """BASELINE config 3 AS BENCHMARKED -- az_arena with two bf16 conv nets, the old model's searches on a second stream, the
+    model-tagged evaluation cache shared by both, the small-batch conv3 path and the per-ply batch feedback -- held to the
+    oracle by replay parity: az_arena records every NNet::predict row each tree consumed (per game, per player); the oracle
+    re-plays the games feeding those rows back.  Same states requested in the same order, same results, same W/L/D.
+    First a 64-game, 100-sim arena in full, then 16 game ids picked at random out of the 4096-game, 400-sim arena itself."""
+    engine.net_init_random(22, seed=5)
+    engine.net_init_random(23, seed=6)
+    for num, sims, picks in ((64, 100, None), (4096, 400, 16)):
+        cap = 22 * (sims + 1) + 8                                    # a player moves at most 21 times
+        engine.reset_stats()
+        wld, res = engine.arena(num, sims, new_model_id=23, old_model_id=22, seed=9, record_evals=cap)
+        st = engine.stats()
+        assert int(wld.sum()) == num and st["leaf_rows_executed"] < st["leaf_rows_requested"]
+        logs = [engine.arena_get_evals(w, num, cap) for w in (0, 1)]
+        assert max(int(l[0].max()) for l in logs) <= cap
+        if picks is None:
+            groups = [list(range(num))]                              # the whole small arena in one oracle call
+        else:
+            groups = [[int(g)] for g in sorted(np.random.default_rng(2).choice(num, size=picks, replace=False))]
+        for sel in groups:
+            rn, ro = (_flatten_log(*logs[w], sel) for w in (0, 1))
+            owld, ores, bad = oracle.arena_ex(num, sims, first_game=sel[0], n_games=len(sel), net_kind=oracle.NET_REPLAY, seed=9,
+                                              threads=8, replay_new=rn, replay_old=ro)
+            assert not bad.any(), (num, sel[0])
+            assert np.array_equal(ores, res[sel[0]:sel[0] + len(sel)]), (num, sel[0])
+            if picks is None:
+                assert owld.tolist() == wld.tolist()
+        ids = [g for sel in groups for g in sel]
+        # the recorded rows are what NNet::predict returns for those states, under the right model
+        for w, mid in ((0, 23), (1, 22)):
+            cnt, states, pis, vs = logs[w]
+            k = int(min(cnt[ids[0]], 128))
+            pi2, v2 = engine.predict_states(states[ids[0], :k], mid)
+            assert np.array_equal(pi2, pis[ids[0], :k]) and np.array_equal(v2, vs[ids[0], :k])
+
+
+def test_replay_parity_selfplay_with_refill_and_the_conv_net(engine, oracle):
+    """The bench's shape: more episodes than slots -- 16,384 episodes on 8,192 slots, C = 512, tables + de-duplication + the
+    evaluation cache on, the drain of the last 8,192 on shrinking batches (ring / image-resident kernel switching) -- with
+    per-EPISODE eval logs that survive the slot refills.  24 episode ids, half of them from the last 8,192 (which drain),
+    replayed on the oracle from their own recorded rows: moves, pi and z bit for bit."""
+    engine.net_init_random(24, seed=8)
+    n, conc, sims, seed = 16384, 8192, 100, 44
+    cap = 42 * (sims + 1) + 8
+    engine.reset_stats()
+    got = engine.selfplay(n_games=n, concurrent=conc, num_sims=sims, model_id=24, seed=seed, want_boards=False, record_evals=cap)
+    st = engine.stats()
+    assert st["games"] == n and st["leaf_rows_executed"] < 0.8 * st["leaf_rows_requested"]
+    cnt, states, pis, vs = engine.selfplay_get_evals(n, cap)
+    assert cnt.max() <= cap and cnt.min() > 0
+    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
+    rng = np.random.default_rng(4)
+    ids = np.concatenate([rng.choice(conc, size=12, replace=False), conc + rng.choice(n - conc, size=12, replace=False)])
+    for g in ids:
+        c = int(cnt[g])
+        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_REPLAY, seed=seed, first_game_id=int(g),
+                              replay=(np.array([0, c], np.int64), np.ascontiguousarray(states[g, :c]), np.ascontiguousarray(pis[g, :c]),
+                                      np.ascontiguousarray(vs[g, :c])))
+        assert not ref["replay_bad"].any(), g
+        L = int(ref["game_len"][0])
+        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
+        lo, hi = offs[g], offs[g + 1]
+        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+
+
+def test_set_option_is_per_engine(engine_mod, oracle):
+    """az_set_option changes the handle it is given and nothing else: two engines in one process, one with conv2 as the MFMA
+    GEMM ("conv2_table" = 0: a different rounding of the same function) and the older kernel families, interleaved
+    predict_states calls -- each engine's rows equal its own single-engine result bit for bit."""
+    a = engine_mod.Engine(device=0, max_batch=512, net_channels=128)
+    b = engine_mod.Engine(device=0, max_batch=512, net_channels=128)
+    try:
+        st = random_states(oracle, 300, seed=9)
+        for e in (a, b):
+            e.net_init_random(0, seed=5)
+        ref_a = a.predict_states(st, 0)
+        b.set_option("conv2_table", 0)
+        ref_b = b.predict_states(st, 0)
+        assert not np.array_equal(ref_a[0], ref_b[0])               # the two kernel sets round differently
+        for k in range(3):
+            ga, gb = a.predict_states(st, 0), b.predict_states(st, 0)
+            assert np.array_equal(ga[0], ref_a[0]) and np.array_equal(ga[1], ref_a[1]), k
+            assert np.array_equal(gb[0], ref_b[0]) and np.array_equal(gb[1], ref_b[1]), k
+            b.set_option("conv3_small", k % 2)                      # a bit-identical family switch: b keeps its own results, a never notices
+        # the tree options too
+        a.net_set_kind(1, engine_mod.NET_HASH, 3)
+        b.net_set_kind(1, engine_mod.NET_HASH, 3)
+        b.set_option("fused_search", 0)
+        b.set_option("tree_block4", 0)
+        ra = a.selfplay(n_games=32, num_sims=25, model_id=1, seed=2)
+        rb = b.selfplay(n_games=32, num_sims=25, model_id=1, seed=2)
+        assert np.array_equal(ra["moves"], rb["moves"]) and np.array_equal(ra["pis"], rb["pis"])
+        # the diagnostic library keeps its switches per engine too (one of them on a superseded kernel family)
+        c = engine_mod.Engine(device=0, max_batch=512, net_channels=128, diag=True)
+        d = engine_mod.Engine(device=0, max_batch=512, net_channels=128, diag=True)
+        try:
+            for e in (c, d):
+                e.net_init_random(0, seed=5)
+            d.set_option("conv2_table", 0)
+            d.set_option("gemm_variant", 0)
+            for k in range(2):
+                gc, gd = c.predict_states(st, 0), d.predict_states(st, 0)
+                assert np.array_equal(gc[0], ref_a[0]) and np.array_equal(gd[0], ref_b[0]) and np.array_equal(gd[1], ref_b[1]), k
+        finally:
+            c.close()
+            d.close()
+    finally:
+        a.close()
+        b.close()
+
+
+def test_shipped_library_refuses_diagnostic_options(engine_mod):
+    """The timing ablations that compute WRONG results and the clock-stamp builds live in libaz_engine_diag.so (tools/ only):
+    the shipped library does not contain them and refuses their option values."""
+    e = engine_mod.Engine(device=0, max_batch=64, net_channels=128)
+    try:
+        for key, val in (("gemm_variant", 12), ("gemm_variant", 17), ("conv3_pipe", 11), ("conv3_pipe", 15), ("conv3_pipe", 3),
+                         ("tree_stamps", 1), ("print_seg_stamps", 0)):
+            with pytest.raises(engine_mod.AzError) as ei:
+                e.set_option(key, val)
+            assert ei.value.status == 1, (key, val)
+    finally:
+        e.close()
+
+
+def test_evaluation_cache_is_sized_from_the_call(engine_mod):
+    """A 1-tree, 25-sim call must not allocate the bench's 5.4 GB evaluation cache or clear a gigabyte per call: the cache
+    is sized from what the call can insert (trees x (sims + 1) x calls, x 4 for the load factor) up to "eval_cache_log2"."""
+    import torch
+    e = engine_mod.Engine(device=0, max_batch=64, net_channels=128)
+    try:
+        e.net_init_random(0, seed=1)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        tb = e.tree_create(1, reserve=10000, num_sims=25, max_depth=1000, model_id=0, cpuct=1)
+        tb.get_action_prob(np.zeros((1, 2), np.uint64), 1.0)
+        r = e.selfplay(n_games=4, num_sims=25, model_id=0, seed=1)
+        torch.cuda.synchronize()
+        used = free0 - torch.cuda.mem_get_info(0)[0]
+        assert used < 512 << 20, used                              # trees + workspace + a small cache, not 5.4 GB
+        assert r["count"] > 0
+    finally:
+        e.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels", [256, 384])
 def test_other_channel_widths(oracle, channels):
@@ -356,10 +530,21 @@ def test_other_channel_widths(oracle, channels):
     the same rows in chunks, the table gather's two kernels agree bit for bit, the GEMM set stays within the table set's distance, and
     the older kernels reproduce the GEMM set bit for bit."""
     from alphazero_rs_amd import engine as azeng
-    e = azeng.Engine(device=0, max_batch=2048, net_channels=channels)
+    e = azeng.Engine(device=0, max_batch=2048, net_channels=channels, diag=True)
+    shipped = azeng.Engine(device=0, max_batch=2048, net_channels=channels)
     try:
         e.net_init_random(0, seed=3)
+        shipped.net_init_random(0, seed=3)
         st = random_states(oracle, 1201, seed=5)
+        sp = shipped.predict_states(st, 0)                          # the shipped library at this width == the diagnostic one's default
+        dp = e.predict_states(st, 0)
+        assert np.array_equal(sp[0], dp[0]) and np.array_equal(sp[1], dp[1])
+        shipped.set_option("conv2_table", 0)
+        e.set_option("conv2_table", 0)
+        sp, dp = shipped.predict_states(st, 0), e.predict_states(st, 0)
+        assert np.array_equal(sp[0], dp[0]) and np.array_equal(sp[1], dp[1])
+        e.set_option("conv2_table", 1)
+        shipped.close()
         ref = e.predict_states(st, 0)
         parts = [e.predict_states(st[o:o + 250], 0) for o in range(0, 1201, 250)]
         assert np.array_equal(np.concatenate([p[0] for p in parts]), ref[0]) and np.array_equal(np.concatenate([p[1] for p in parts]), ref[1])

@@ -67,6 +67,7 @@ def replay_trace(oracle, entry, game_kind):
         assert pi.view(np.uint32).tolist() == mv["pi"] and q.view(np.uint32).tolist() == mv["q"]
         assert int(counts.sum()) >= entry["sims"] - 1
     st = t.stats()
+    assert st.pop("abandoned") == 0          # only a several-simulations-in-flight search can abandon one
     assert st == entry["trace"]["stats"]
 
 

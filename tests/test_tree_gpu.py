@@ -289,7 +289,7 @@ def test_arena_odd_and_empty(engine, engine_mod):
     assert int(wld.sum()) == 4 and len(results) == 4
 
 
-def test_arena_full_size_properties(engine, engine_mod):
+def test_arena_full_size_properties(engine, engine_mod, oracle):
     """BASELINE config 3 (4096 paired games, 400 sims/move) with the hash nets: size-independent properties --
     every game ends, W + L + D = 4096, the tally follows the per-game results under the seat swap, and swapping
     which model is listed first mirrors wins and losses (play_games is symmetric in its two players)."""
@@ -303,10 +303,108 @@ def test_arena_full_size_properties(engine, engine_mod):
     assert [wins, losses, 4096 - wins - losses] == wld.tolist()
     st = engine.stats()
     assert st["games"] == 4096 and st["simulations"] % 400 == 0
-    wld2, res2 = engine.arena(4096, 400, new_model_id=40, old_model_id=41, seed=5)
-    # same games with the seats' owners renamed: game g of the swapped call is game (g + 2048) % 4096 of the first
-    # only if the RNG stream were keyed on seats; it is keyed on the game index, so compare tallies statistically:
-    assert int(wld2.sum()) == 4096
+    # the multi-GPU partitioning at full size: three ragged shards by GLOBAL game index (seating and RNG follow the global
+    # index) reproduce the unsharded arena game for game, and their W/L/D counters add up to its tally
+    tot, parts = np.zeros(3, np.uint64), []
+    for lo, hi in ((0, 1365), (1365, 2731), (2731, 4096)):
+        w, r = engine.arena(hi - lo, 400, new_model_id=41, old_model_id=40, seed=5, first_game=lo, total_games=4096)
+        tot += w
+        parts.append(r)
+    assert np.array_equal(np.concatenate(parts), res) and tot.tolist() == wld.tolist()
+    # 16 games picked at random replayed one by one on the oracle (game g depends on (seed, g) and its seating only)
+    for g in np.random.default_rng(3).choice(4096, size=16, replace=False):
+        _, ores, _ = oracle.arena_ex(4096, 400, first_game=int(g), n_games=1, net_kind=oracle.NET_HASH, salt=9001, seed=5,
+                                     new_model_id=41, old_model_id=40)
+        assert int(ores[0]) == int(res[g]), g
+
+
+def test_arena_start_board(engine, oracle, engine_mod):
+    """play_games' `board: Option<G>` (src/arena.rs:62-67, :12-16): every game starts from the given position with the first
+    seat to move; both trees are rooted at the initial board (AsyncMcts::default, src/coach.rs:333-354) and meet the position
+    through S10.  A finished start board never enters the loop (src/arena.rs:18): result = round(ended(+1))."""
+    engine.net_set_kind(61, engine_mod.NET_HASH, 777 - 61 * MODEL_SALT)
+    engine.net_set_kind(60, engine_mod.NET_HASH, 777 + MODEL_SALT - 60 * MODEL_SALT)
+    s = (0, 0)
+    for a in (3, 3, 2, 4, 4, 2):                      # six plies: the first seat (+1) is to move again, canonical = absolute
+        s = oracle.c4_play(s[0], s[1], a)
+    wld, res = engine.arena(12, 50, new_model_id=61, old_model_id=60, seed=4, start_board=s)
+    owld, ores, _ = oracle.arena_ex(12, 50, net_kind=oracle.NET_HASH, salt=777, seed=4, new_model_id=0, old_model_id=1, threads=4,
+                                    start_board=s)
+    assert np.array_equal(res, ores) and wld.tolist() == owld.tolist()
+    wld0, res0 = engine.arena(12, 50, new_model_id=61, old_model_id=60, seed=4)
+    assert not np.array_equal(res0, res) or wld0.tolist() != wld.tolist() or True      # (a different opening; may coincide)
+    # a start board on which the SECOND seat has already won: every game is over before its first move
+    w = (0, 0)
+    for a in (0, 1, 0, 1, 0, 1, 6, 1):                # the second mover completes column 1
+        w = oracle.c4_play(w[0], w[1], a)
+    assert oracle.c4_ended(*w) == -1.0
+    wld, res = engine.arena(6, 50, new_model_id=61, old_model_id=60, seed=4, start_board=w)
+    owld, ores, _ = oracle.arena_ex(6, 50, net_kind=oracle.NET_HASH, salt=777, seed=4, new_model_id=0, old_model_id=1, start_board=w)
+    assert res.tolist() == ores.tolist() == [-1] * 6 and wld.tolist() == owld.tolist() == [3, 3, 0]
+    with pytest.raises(engine_mod.AzError):
+        engine.arena(4, 10, new_model_id=61, old_model_id=60, start_board=(3, 1))       # overlapping stones
+
+
+# ---- several simulations in flight per tree (num_threads > 1, src/async_mcts.rs:191-217) ---------------------------------
+@pytest.mark.parametrize("threads,sims,okind", [(2, 100, "hash"), (4, 100, "hash"), (5, 25, "stub"), (8, 96, "hash")])
+def test_several_simulations_in_flight(engine, oracle, threads, sims, okind):
+    """The reference's tree-parallel search as the deterministic lock-step schedule (oracle/az_oracle.hpp search_lockstep):
+    per step T selections in thread order with visit()'s virtual loss (src/node.rs:77-80, :51-58) and the Locked filter
+    (C8, src/node.rs:359-365) visible to the later threads, the step's leaves evaluated together, backups in thread order;
+    S11 / S12 abandon where the reference panics.  Whole games, every move: counts / pi / Q bit-exact, node counts, every
+    counter incl. the abandoned simulations.  PARITY UNPINNED by the reference (it is racy for T > 1): this pins one legal
+    execution, the same one on both sides."""
+    model, kind, salt = (10, oracle.NET_HASH, oracle_salt(10)) if okind == "hash" else (0, oracle.NET_STUB, 0)
+    G = 6
+    engine.reset_stats()
+    tb = engine.tree_create(G, reserve=oracle.default_reserve(sims), num_sims=sims, max_depth=1000, model_id=model, cpuct=1,
+                            num_threads=threads)
+    trees = [oracle.Tree(sims, net_kind=kind, salt=salt, threads=threads) for _ in range(G)]
+    states = [(0, 0)] * G
+    alive = [True] * G
+    rng = np.random.default_rng(threads)
+    for move in range(42):
+        if not any(alive):
+            break
+        temp = 1.0 if move < 10 else 0.0
+        pi, counts, q = tb.get_action_prob(np.array(states, dtype=np.uint64), temp, seed=7, first_game_id=50)
+        for g in range(G):
+            opi, ocnt, oq = trees[g].get_action_prob(states[g][0], states[g][1], temp, seed=7, game_id=50 + g)
+            assert np.array_equal(counts[g], ocnt), (move, g, counts[g], ocnt)
+            assert np.array_equal(pi[g], opi) and np.array_equal(q[g], oq), (move, g)
+            if alive[g]:
+                nxt = oracle.c4_play(states[g][0], states[g][1], int(rng.choice([a for a in range(7) if opi[a] > 0])))
+                if oracle.c4_ended(*nxt) != 0.0:
+                    alive[g] = False
+                else:
+                    states[g] = nxt
+    ost = [t.stats() for t in trees]
+    assert [int(x) for x in tb.node_counts()] == [s["nodes"] for s in ost]
+    st = engine.stats()
+    for mine, theirs in (("simulations", "sims"), ("expansions", "expansions"), ("leaf_evals", "leaf_evals"), ("link_hits", "link_hits"),
+                         ("terminal_hits", "terminal_hits"), ("depth_sum", "depth_sum"), ("abandoned_sims", "abandoned")):
+        assert st[mine] == sum(s[theirs] for s in ost), (mine, st[mine], sum(s[theirs] for s in ost))
+
+
+def test_several_simulations_in_flight_selfplay_and_arena(engine, oracle, engine_mod):
+    """num_sim_threads through az_selfplay (with slot refill) and az_arena (src/coach.rs:246-255, :333-354), and the contracts:
+    num_sims % num_threads == 0 (src/async_mcts.rs:192), at most 8 threads."""
+    n, sims, T = 72, 48, 4
+    ref = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=12, threads=8, sim_threads=T)
+    ref1 = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=12, threads=8)
+    assert not np.array_equal(ref["moves"], ref1["moves"])                       # a different search than one simulation at a time
+    assert ref["stats"]["sims"] == ref1["stats"]["sims"] * 0 + sims * int(ref["game_len"].sum())
+    for concurrent in (n, 20):
+        _compare_selfplay(engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=12, concurrent=concurrent, num_sim_threads=T), ref)
+    engine.net_set_kind(71, engine_mod.NET_HASH, 888 - 71 * MODEL_SALT)
+    engine.net_set_kind(70, engine_mod.NET_HASH, 888 + MODEL_SALT - 70 * MODEL_SALT)
+    wld, res = engine.arena(20, 60, new_model_id=71, old_model_id=70, seed=2, num_sim_threads=3)
+    owld, ores, _ = oracle.arena_ex(20, 60, net_kind=oracle.NET_HASH, salt=888, seed=2, new_model_id=0, old_model_id=1, threads=8, sim_threads=3)
+    assert np.array_equal(res, ores) and wld.tolist() == owld.tolist()
+    for bad in (dict(num_sims=50, num_sim_threads=4), dict(num_sims=90, num_sim_threads=9)):
+        with pytest.raises(engine_mod.AzError) as ei:
+            engine.selfplay(n_games=2, model_id=10, **bad)
+        assert ei.value.status == 1
 
 
 def test_from_state_reset(engine, oracle):

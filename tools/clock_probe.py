@@ -4,7 +4,7 @@ import sys, os, time, numpy as np, ctypes
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tools'))
 from alphazero_rs_amd import engine as azeng
 from _states import random_states
-e = azeng.Engine(device=0, max_batch=8192, profile=True)
+e = azeng.Engine(device=0, max_batch=8192, profile=True, diag=True)
 e.net_init_random(0, 1)
 uniq = random_states(512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, 8192)]

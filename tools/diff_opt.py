@@ -5,7 +5,7 @@ from alphazero_rs_amd import engine as azeng
 from _states import random_states
 key, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 3000
-e = azeng.Engine(device=0, max_batch=8192)
+e = azeng.Engine(device=0, max_batch=8192, diag=True)
 e.net_init_random(0, 1)
 st = random_states(n, 3)
 e.set_option(key, a); pa, va = e.predict_states(st, 0)

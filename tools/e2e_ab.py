@@ -12,7 +12,7 @@ if "--" in argv:
     argv = argv[:i]
 key, vals = argv[0], [int(x) for x in argv[1:]]
 G, E = 8192, int(os.environ.get("E", 16384))
-e = azeng.Engine(device=0, max_batch=G)
+e = azeng.Engine(device=0, max_batch=G, diag=True)
 for k, v in fixed:
     e.set_option(k, int(v))
 if os.environ.get('NET', 'conv') == 'stub':

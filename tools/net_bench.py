@@ -6,7 +6,7 @@ from alphazero_rs_amd import engine as azeng
 from _states import random_states
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-e = azeng.Engine(device=0, max_batch=B, profile=True)
+e = azeng.Engine(device=0, max_batch=B, profile=True, diag=True)
 e.net_init_random(0, 1)
 uniq = random_states(512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, B)]

@@ -5,7 +5,7 @@ from alphazero_rs_amd import engine as azeng
 from _states import random_states
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-e = azeng.Engine(device=0, max_batch=B)
+e = azeng.Engine(device=0, max_batch=B, diag=True)
 e.net_init_random(0, 1)
 if len(sys.argv) > 3:
     e.set_option("gemm_variant", int(sys.argv[3]))

@@ -5,7 +5,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 from alphazero_rs_amd import engine as azeng
 from _states import random_states
 key, vals = sys.argv[1], [int(x) for x in sys.argv[2:]]
-e = azeng.Engine(device=0, max_batch=8192, profile=True)
+e = azeng.Engine(device=0, max_batch=8192, profile=True, diag=True)
 e.net_init_random(0, 1)
 uniq = random_states(int(os.environ.get("UNIQ", 8192)), 3)
 for L in [int(x) for x in os.environ.get("LEAVES", "1400,2048,2700,4096,5000,6700,8192").split(",")]:

@@ -8,7 +8,7 @@ TILES = [0, 642, 644, 962, 964, 1282, 1284, 1602, 1922]
 if sys.argv[1] == "run":
     from alphazero_rs_amd import engine as azeng
     from _states import random_states
-    e = azeng.Engine(device=0, max_batch=8192)
+    e = azeng.Engine(device=0, max_batch=8192, diag=True)
     e.net_init_random(0, 1)
     uniq = random_states(8192, 3)
     for L in ROWS:

@@ -5,7 +5,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 from alphazero_rs_amd import engine as azeng
 from _states import random_states
 lo, hi, step = (int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (256, 8192, 256)))
-e = azeng.Engine(device=0, max_batch=8192, profile=True)
+e = azeng.Engine(device=0, max_batch=8192, profile=True, diag=True)
 e.net_init_random(0, 1)
 for kv in filter(None, os.environ.get("OPT", "").split(",")):
     k, v = kv.split("=")

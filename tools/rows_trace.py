@@ -10,7 +10,7 @@ if mode == "run":
     from alphazero_rs_amd import engine as azeng
     from _states import random_states
     lo, hi, step = (int(x) for x in sys.argv[2:5])
-    e = azeng.Engine(device=0, max_batch=8192)
+    e = azeng.Engine(device=0, max_batch=8192, diag=True)
     e.net_init_random(0, 1)
     for kv in filter(None, os.environ.get("OPT", "").split(",")):
         k, v = kv.split("=")

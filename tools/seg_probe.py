@@ -4,7 +4,7 @@ import sys, os, time, numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tools'))
 from alphazero_rs_amd import engine as azeng
 from _states import random_states
-e = azeng.Engine(device=0, max_batch=8192, profile=True)
+e = azeng.Engine(device=0, max_batch=8192, profile=True, diag=True)
 e.net_init_random(0, 1)
 uniq = random_states(8192, 3)
 names = ["reads+MMA1", "wait+bar1", "dmaW", "rd+MMA2", "rd+MMA3", "wait+bar2", "imgswitch", "rd+MMA4", "total", "ticks100MHz"]

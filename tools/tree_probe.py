@@ -4,7 +4,7 @@ launch of a short self-play run.  python tools/tree_probe.py"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 from alphazero_rs_amd import engine as azeng
-e = azeng.Engine(device=0, max_batch=8192)
+e = azeng.Engine(device=0, max_batch=8192, diag=True)
 e.net_init_random(0, 1)
 e.set_option("tree_stamps", 1)
 e.selfplay(n_games=8192 * 2, concurrent=8192, num_sims=100, model_id=0, seed=1, want_boards=False)
