@@ -59,7 +59,11 @@ AZ_D float puct(uint64_t child_ctr, float prior, float sqrt_parent, float cpuct_
     float denom = (float)((ctr_n(child_ctr) + 1u) & 0xFFFFu);   // u16 arithmetic
     return __fadd_rn(ctr_q(child_ctr), __fdiv_rn(__fmul_rn(__fmul_rn(cpuct_f, prior), sqrt_parent), denom));
 }
-AZ_D float puct_sqrt_parent(uint32_t parent_n) { return __fsqrt_rn(__fadd_rn((float)parent_n, 1e-6f)); }
+// f32::sqrt of the reference is IEEE (correctly rounded).  NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS the HIP headers map it
+// to __ocml_native_sqrt_f32 = a bare v_sqrt_f32 (1 ulp), which flips the arg-max between two children whose PUCT terms tie to the last
+// bit (found by replaying the 4096 x 400 arena on the oracle: round 3).  __builtin_sqrtf is lowered to v_sqrt_f32 + the correction
+// steps under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt, like the `/` behind __fdiv_rn.
+AZ_D float puct_sqrt_parent(uint32_t parent_n) { return __builtin_sqrtf(__fadd_rn((float)parent_n, 1e-6f)); }
 
 // ---- RNG of the build ------------------------------------------
 AZ_HD uint64_t mix64(uint64_t x) {

@@ -1635,4 +1635,39 @@ az_status az_gather_samples(az_engine* e, const az_samples* local, int32_t dst_r
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
 
+#ifdef AZ_DIAG
+// Diagnostic library only (not part of the ABI): the children of the node reached from tree g's current root by following `path`
+// (child indices, not actions).  out rows of 8 u64: slot, a, ctr (resolved through a link), prior bits, link, meta, own ctr, key.
+// Returns the number of children, or -1.
+int az_diag_tree_children(az_tree* t, int g, const int* path, int depth, unsigned long long* out) {
+    if (!t || g < 0 || g >= t->th.d.G) return -1;
+    TreeDev& d = t->th.d;
+    std::vector<TreeLine> heads(d.G);
+    if (hipMemcpy(heads.data(), d.head, heads.size() * sizeof(TreeLine), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    struct Rec { unsigned long long ctr, key; uint32_t prior, meta, link, child_base; };
+    auto load = [&](uint32_t slot, Rec* r) { return hipMemcpy(r, d.node + ((size_t)g * d.R + slot) * 2, 32, hipMemcpyDeviceToHost) == hipSuccess; };
+    uint32_t cur = heads[g].head.root;
+    Rec pr;
+    if (!load(cur, &pr)) return -1;
+    for (int i = 0; i < depth; ++i) {
+        Rec c;
+        if (!load(pr.child_base + (uint32_t)path[i], &c)) return -1;
+        cur = c.link != NONE ? c.link : pr.child_base + (uint32_t)path[i];
+        if (!load(cur, &pr)) return -1;
+    }
+    const int n = (int)((pr.meta >> META_NCHILD_SHIFT) & 7u);
+    for (int j = 0; j < n; ++j) {
+        Rec c, r;
+        if (!load(pr.child_base + (uint32_t)j, &c)) return -1;
+        r = c;
+        if (c.link != NONE && !load(c.link, &r)) return -1;
+        unsigned long long* o = out + 8 * j;
+        o[0] = pr.child_base + (uint32_t)j; o[1] = c.meta & META_A_MASK; o[2] = r.ctr; o[3] = c.prior; o[4] = c.link; o[5] = r.meta; o[6] = c.ctr; o[7] = r.key;
+    }
+    out[8 * 7] = pr.ctr; out[8 * 7 + 1] = pr.key; out[8 * 7 + 2] = cur;
+    return n;
+}
+void az_diag_tree_set_sims(az_tree* t, int num_sims) { if (t) t->num_sims = num_sims; }
+#endif
+
 }  // extern "C"

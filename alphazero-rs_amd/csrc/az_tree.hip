@@ -1037,6 +1037,25 @@ static_assert(game_ok<ConnectFour>() && game_ok<ConnectThree>(),
     } while (0)
 static inline int group_blocks(int G) { return (G * BLOCK_SLOTS + 63) / 64; }
 #ifdef AZ_DIAG
+// diagnostic library only: the PUCT term of best_child (src/node.rs:352-356) for n (child counter, prior bits, parent N) triples, as the
+// selection kernels compute it -- lets a test hold every operation of it to the oracle's IEEE arithmetic, bit for bit
+__global__ void k_diag_puct(const unsigned long long* ctr, const uint32_t* prior, const uint32_t* parent_n, float cpuct, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = puct(ctr[i], __uint_as_float(prior[i]), puct_sqrt_parent(parent_n[i]), cpuct);
+}
+extern "C" int az_diag_puct(const unsigned long long* ctr, const uint32_t* prior, const uint32_t* parent_n, int cpuct, float* out, int n) {
+    unsigned long long* d_c = nullptr; uint32_t *d_p = nullptr, *d_n = nullptr; float* d_o = nullptr;
+    bool ok = hipMalloc((void**)&d_c, (size_t)n * 8) == hipSuccess && hipMalloc((void**)&d_p, (size_t)n * 4) == hipSuccess &&
+              hipMalloc((void**)&d_n, (size_t)n * 4) == hipSuccess && hipMalloc((void**)&d_o, (size_t)n * 4) == hipSuccess;
+    ok = ok && hipMemcpy(d_c, ctr, (size_t)n * 8, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_p, prior, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_n, parent_n, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_diag_puct, dim3((n + 255) / 256), dim3(256), 0, nullptr, d_c, d_p, d_n, (float)cpuct, d_o, n);
+        ok = hipMemcpy(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d_c); (void)hipFree(d_p); (void)hipFree(d_n); (void)hipFree(d_o);
+    return ok ? 0 : -1;
+}
 // diagnostic library only: per-wave phase stamps of k_backup_select (tools/tree_probe.py); process-wide by design (a probe, not a product path)
 constexpr int TREE_DBG_WAVES = 4096;
 static unsigned long long* g_tree_dbg = nullptr;

@@ -25,6 +25,8 @@ struct CallbackNet : NNet {
 
 struct TreeBase {
     virtual ~TreeBase() = default;
+    virtual int debug_children(uint64_t mine, uint64_t theirs, const int* path, int depth, uint64_t* out) = 0;
+    virtual void set_sims(size_t n) = 0;
     virtual int get_action_prob(uint64_t mine, uint64_t theirs, float temp, uint64_t seed, uint64_t game_id,
                                 float* pi, uint16_t* counts, float* q) = 0;
     virtual SearchStats stats() = 0;
@@ -86,6 +88,30 @@ struct TreeImpl : TreeBase {
             return -1;
         }
     }
+    // diagnostics: children of the node reached from the node of state (mine, theirs) by following `path` (child indices);
+    // rows of 8 u64: slot, a, ctr (resolved), prior bits, link (or ~0), expanded, own ctr, 0; row 7: the node's own ctr
+    int debug_children(uint64_t mine, uint64_t theirs, const int* path, int depth, uint64_t* out) override {
+        auto root = mcts->nodes->lookup_state_id(make_state<G>(mine, theirs, quirks));
+        if (!root) return -1;
+        size_t cur = *root;
+        for (int i = 0; i < depth; ++i) cur = *mcts->nodes->resolve(mcts->nodes->get(cur)->children[(size_t)path[i]]);
+        Node<G>* nd = mcts->nodes->get(cur);
+        int j = 0;
+        for (size_t ci : nd->children) {
+            Node<G>* ch = mcts->nodes->get(ci);
+            uint8_t a = mcts->nodes->raw(ci)->a;
+            float p = nd->p ? (*nd->p)[a] : 0.0f;
+            uint32_t pb;
+            std::memcpy(&pb, &p, 4);
+            uint64_t* o = out + 8 * j;
+            o[0] = ci; o[1] = a; o[2] = ch->win_counter.load(); o[3] = pb;
+            o[4] = mcts->nodes->buf[ci].link ? *mcts->nodes->buf[ci].link : ~0ull; o[5] = ch->s ? 1 : 0; o[6] = mcts->nodes->raw(ci)->win_counter.load(); o[7] = 0;
+            ++j;
+        }
+        out[8 * 7] = nd->win_counter.load(); out[8 * 7 + 2] = cur;
+        return j;
+    }
+    void set_sims(size_t n) override { mcts->num_sims = n; }
     SearchStats stats() override { return mcts->stats; }
     size_t n_nodes() override { return mcts->nodes->size(); }
     ReplayNet* replay_net() override { return &nets.replay; }
@@ -208,6 +234,10 @@ void* azo_tree_new_mt(int game_kind, int has_root, uint64_t mine, uint64_t their
         return nullptr;
     }
 }
+int azo_tree_debug_children(void* t, uint64_t mine, uint64_t theirs, const int* path, int depth, uint64_t* out) {
+    return ((TreeBase*)t)->debug_children(mine, theirs, path, depth, out);
+}
+void azo_tree_set_sims(void* t, uint64_t n) { ((TreeBase*)t)->set_sims((size_t)n); }
 void azo_tree_free(void* t) { delete (TreeBase*)t; }
 int azo_tree_get_action_prob(void* t, uint64_t mine, uint64_t theirs, float temp, uint64_t seed, uint64_t game_id,
                              float* pi, uint16_t* counts, float* q) {
@@ -309,6 +339,9 @@ int64_t azo_selfplay(int64_t n_games, uint64_t first_game_id, uint64_t sims, uin
 // results[g] (optional, [num]) = +1 first seat won, -1 second seat won, 0 draw.
 }  // extern "C" (the arena body is a template over the game; its C entry points follow it)
 
+static uint64_t g_last_bad_req[2] = {0, 0};      // diagnostics: the state requested at the first bad replay record of the last arena
+extern "C" void azo_debug_last_bad_request(uint64_t* out2) { out2[0] = g_last_bad_req[0]; out2[1] = g_last_bad_req[1]; }
+
 // Replay streams of an arena (replay parity of az_arena with recorded conv-net rows): per game and per model the
 // (state, pi, v) rows that model's tree consumed, flattened with offsets [n_games + 1]
 struct ArenaReplay {
@@ -358,9 +391,16 @@ static int arena_impl(uint64_t total, uint64_t first_game, uint64_t n_games, uin
             };
             std::function<uint8_t(const G&)> acts[2] = {mk(first), mk(1 - first)};
             res[li] = play_game<G>(acts, board0);
-            if (net_kind == NET_REPLAY && rp && rp->bad)
-                rp->bad[li] = (nets[0].replay.mismatch || nets[0].replay.pos != nets[0].replay.n || nets[1].replay.mismatch ||
-                               nets[1].replay.pos != nets[1].replay.n) ? 1 : 0;
+            if (net_kind == NET_REPLAY && rp && rp->bad) {
+                // 0 = replayed cleanly; else bit 0 / 1: the new / old model's tree asked for a state its record does not hold,
+                // bit 2 / 3: ... left records unused; bits 8..: index of the first bad request of the first failing tree
+                int b = (nets[0].replay.mismatch ? 1 : 0) | (nets[1].replay.mismatch ? 2 : 0) | (nets[0].replay.pos != nets[0].replay.n ? 4 : 0) |
+                        (nets[1].replay.pos != nets[1].replay.n ? 8 : 0);
+                const long fb = nets[0].replay.first_bad >= 0 ? nets[0].replay.first_bad : nets[1].replay.first_bad;
+                if (b && fb >= 0) b |= (int)(fb << 8);
+                if (b && fb >= 0) { const ReplayNet& r = nets[0].replay.first_bad >= 0 ? nets[0].replay : nets[1].replay; g_last_bad_req[0] = r.bad_req[0]; g_last_bad_req[1] = r.bad_req[1]; }
+                rp->bad[li] = b;
+            }
         };
         if (threads <= 1) {
             for (uint64_t g = 0; g < n_games; ++g) run_one(g);

@@ -277,13 +277,15 @@ struct ReplayNet : NNet {
     const float* vs = nullptr;         // [n]
     size_t n = 0, pos = 0;
     bool mismatch = false;
+    long first_bad = -1;      // record index of the first request that did not match its record (diagnostics)
+    uint64_t bad_req[2] = {0, 0};   // ... and the state that was requested there
     void predict(const float* boards, int B, int, float* pi, float* v) override {
         for (int b = 0; b < B; ++b) {
-            if (pos >= n) { mismatch = true; for (int a = 0; a < C4_W; ++a) pi[b * 7 + a] = 1.0f / 7.0f; v[b] = 0; continue; }
+            if (pos >= n) { mismatch = true; if (first_bad < 0) first_bad = (long)pos; for (int a = 0; a < C4_W; ++a) pi[b * 7 + a] = 1.0f / 7.0f; v[b] = 0; continue; }
             if (states) {
                 uint64_t m, t;
                 features_to_bits(boards + (size_t)b * 84, &m, &t);
-                if (m != states[2 * pos] || t != states[2 * pos + 1]) mismatch = true;
+                if (m != states[2 * pos] || t != states[2 * pos + 1]) { mismatch = true; if (first_bad < 0) { first_bad = (long)pos; bad_req[0] = m; bad_req[1] = t; } }
             }
             for (int a = 0; a < C4_W; ++a) pi[b * 7 + a] = pis[pos * 7 + a];
             v[b] = vs[pos];

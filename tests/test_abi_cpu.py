@@ -177,6 +177,39 @@ def test_rust_shim_matches_the_header():
         assert needle in src, needle
 
 
+def test_integration_md_matches_the_header():
+    """INTEGRATION.md is what a maintainer copies from: every `pub fn az_*` and `pub struct az_*` in its rust blocks matches
+    include/az_engine.h (names, argument counts and types, field order), and every struct literal names exactly the struct's fields."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = "\n".join(re.findall(r"```rust\n(.*?)```", md, flags=re.S))
+    code = re.sub(r"//[^\n]*", "", blocks)
+    hdr, structs = _header_functions(), _header_structs()
+    seen_fn = 0
+    for name, args, ret in re.findall(r"pub fn (az_[a-z_0-9]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", code, flags=re.S):
+        params = [a.split(":", 1)[1].strip() for a in args.split(",") if a.strip()]
+        assert name in hdr, name
+        assert params == hdr[name][1], (name, params, hdr[name][1])
+        assert (ret.strip() if ret else None) == hdr[name][0], name
+        seen_fn += 1
+    assert seen_fn >= 15
+    seen_st = 0
+    for sname, body in re.findall(r"pub struct (az_[a-z_]+) \{\n(.*?)\n\}", code + "\n", flags=re.S) + \
+            re.findall(r"pub struct (az_[a-z_]+) \{([^\n]*?)\}", code):
+        if sname in ("az_engine", "az_tree"):
+            continue
+        rfields = [(n, t.strip()) for n, t in re.findall(r"pub ([a-z_0-9]+):\s*(\[[^\]]+\]|[^,}]+)", body)]
+        assert rfields == structs[sname], (sname, rfields, structs[sname])
+        seen_st += 1
+    assert seen_st >= 4
+    # struct literals (`az_selfplay_params { field: .., }` without `..base`): all fields, in any order
+    for sname, body in re.findall(r"= (az_[a-z_]+) \{(.*?)\};", code, flags=re.S):
+        if ".." in re.sub(r"\[[^\]]*\]", "", body).replace("...", ""):
+            continue
+        names = set(re.findall(r"(?:^|[,{\s])([a-z_0-9]+)\s*(?::|,|$)", re.sub(r"\([^()]*\)|\[[^\]]*\]", "", body)))
+        want = {n for n, _ in structs[sname]}
+        assert want <= names, (sname, sorted(want - names))
+
+
 def test_tools_and_examples_compile():
     """Every measurement helper and example parses (they only run on the GPU box, so a syntax error would otherwise surface there)."""
     import glob

@@ -95,6 +95,37 @@ def test_node_counts_and_stats_match(engine, oracle):
         assert st[mine] == sum(s[theirs] for s in ost), (mine, st[mine])
 
 
+def test_puct_term_is_ieee_bit_for_bit(engine_mod, oracle):
+    """best_child's PUCT term (src/node.rs:352-356, C6) as the selection kernels compute it (az_diag_puct of the diagnostic
+    library runs the kernels' own device functions) against the oracle's IEEE f32 arithmetic, bit for bit: EVERY parent N (the
+    square root must be correctly rounded: round 3 found __fsqrt_rn to be a bare v_sqrt_f32, 1 ulp off for some N, which flips the
+    arg-max of two children that tie to the last bit), random counters and priors, and the tie the 4096 x 400 arena ran into."""
+    import ctypes as C
+    L = engine_mod.diag_library()
+    L.az_diag_puct.restype = C.c_int
+    L.az_diag_puct.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(0)
+    n = 65536 * 4
+    parent = np.tile(np.arange(65536, dtype=np.uint32), 4)
+    wins = rng.integers(-4000, 4000, n).astype(np.int64)
+    visits = rng.integers(0, 2000, n).astype(np.uint64)
+    visits[:65536] = 6
+    ctr = (((wins + 0x7FFFFFFF).astype(np.uint64)) << np.uint64(32)) | (visits << np.uint64(16)) | rng.integers(0, 2, n).astype(np.uint64)
+    prior = rng.random(n).astype(np.float32)
+    # the arena's tie: children (W = 0.05, N = 6, p = 0x3e1373ad) and (W = 0.04, N = 6, p = 0x3e1540be) under a parent with N = 44
+    ctr[:2] = [0x8000000400060000, 0x8000000300060000]
+    prior[:2] = np.array([0x3e1373ad, 0x3e1540be], np.uint32).view(np.float32)
+    parent[:2] = 44
+    for cpuct in (1, 3):
+        out = np.zeros(n, np.float32)
+        assert L.az_diag_puct(ctr.ctypes.data, prior.view(np.uint32).ctypes.data, parent.ctypes.data, cpuct, out.ctypes.data, n) == 0
+        OL = oracle.lib()
+        ref = np.array([OL.azo_puct(int(ctr[i]), float(prior[i]), int(parent[i]), cpuct) for i in range(n)], np.float32)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), np.nonzero(out.view(np.uint32) != ref.view(np.uint32))[0][:8]
+        if cpuct == 1:
+            assert out[0] == out[1]                       # an exact tie: max_by keeps the LATER child (C7)
+
+
 def _compare_selfplay(got, ref):
     assert got["count"] == ref["count"]
     assert np.array_equal(got["game_len"], ref["game_len"])
