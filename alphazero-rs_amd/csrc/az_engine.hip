@@ -651,6 +651,9 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     // ---- options of the shipped library: every one of them lives in THIS engine ----
     if (is("conv2_table") && (value == 0 || value == 1)) { e->netopt.conv2_table = (int)value; return AZ_OK; }
     if (is("conv3_small") && (value == 0 || value == 1)) { e->netopt.conv3_small = (int)value; return AZ_OK; }
+    if (is("conv3_tail") && (value == 0 || value == 1)) { e->netopt.conv3_tail = (int)value; return AZ_OK; }
+    if (is("conv4_image") && (value == 0 || value == 1)) { e->netopt.conv4_image = (int)value; return AZ_OK; }
+    if (is("conv4_image_min_rows") && value >= 0 && value <= 1000000) { e->netopt.conv4_image_min_rows = (int)value; return AZ_OK; }
     if (is("tree_block4") && (value == 0 || value == 1)) { e->tree_block4 = (int)value; return AZ_OK; }
     if (is("dedup_stats") && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }
     if (is("profile_every") && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }

@@ -70,6 +70,9 @@ void netws_resolve_profile(NetWorkspace* ws, NetProfile* prof);
 struct NetOptions {
     int conv2_table = 1;    // 1: conv1 + conv2 as table gathers (k_conv2_table_x); 0: conv2 as the MFMA implicit GEMM (same function, other rounding)
     int conv3_small = 1;    // conv3 of a small expected batch on the 4-stage LDS-DMA ring (bit-identical)
+    int conv3_tail = 1;     // conv3: a last round of at most 256 workgroups is cut into half tiles (two per CU again); 0 = full tiles only (bit-identical)
+    int conv4_image = 1;    // conv4 image-resident (k_conv4_img) from conv4_image_min_rows expected rows; 0 = always the ring (bit-identical)
+    int conv4_image_min_rows = 600;
     // ---- diagnostic library only ----
     int gemm_variant = 5;   // 0 128x128 register-staged tiles everywhere; 1 / 2 256x256 LDS-DMA tiles; 3 conv2 image-resident, one 8-wave
                             // workgroup per CU; 5 the shipped set; 11-17 timing ablations of variant 2 (WRONG results)

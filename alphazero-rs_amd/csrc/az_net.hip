@@ -1031,6 +1031,244 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
     }
 }
 
+// ---- the image-resident 'valid' conv tile, generalised: per-wave tile = MT x NTW accumulators of 16x16 ------------------------------
+// Waves 2 x 2; a wave owns 16*MT rows x 16*NTW columns, the workgroup 32*MT rows (NB boards' outputs) x 32*NTW columns.  The pipeline
+// is k_conv_valid_pipe's (asm-issued LDS-DMA, one weight buffer, fragment reads of the next cluster between this cluster's MFMAs):
+// four clusters of (MT/2) x NTW MFMAs per K-step.  Same K order per accumulator: bit-identical to every other kernel of the layer.
+//   conv3 full tile   NB 12, 6x7, MT 8, NTW 4   240 of 256 rows x 128 channels, 63 + 16 KiB (= k_conv_valid_pipe)
+//   conv3 half tile   NB 12, 6x7, MT 8, NTW 2   the same boards x 64 channels, 63 + 8 KiB: two of them share a CU where a full tile would
+//                                               run alone (k_conv3_auto)
+//   conv4             NB 20, 4x5, MT 4, NTW 4   120 of 128 rows x 128 channels, 50 + 16 KiB
+template <int NB, int IH, int IW, int MT, int NTW>
+struct ConvTile {
+    static constexpr int OH = IH - 2, OW = IW - 2, OUT_PER = OH * OW, IN_PER = IH * IW;
+    static constexpr int OUT_ROWS = NB * OUT_PER, IMG_R = NB * IN_PER;
+    static constexpr int NCOL = 32 * NTW, WROWS = 16 * MT;
+    static constexpr int IMG_BYTES = (IMG_R * 128 + 1023) / 1024 * 1024;
+    static constexpr int LDS_BYTES = IMG_BYTES + NCOL * 128;
+    static constexpr int EP_STRIDE = NCOL * 2 + 16;
+    static_assert(OUT_ROWS <= 2 * WROWS && IMG_R % 8 == 0 && MT % 2 == 0, "tile");
+    static_assert(LDS_BYTES <= 81920, "two workgroups must fit a CU's 160 KiB");
+    static_assert(OUT_ROWS * EP_STRIDE <= LDS_BYTES, "the output tile must fit the dead buffers");
+};
+
+template <int NB, int IH, int IW, int MT, int NTW>
+__device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char* smem, const int b0 /*first board*/, const int n0 /*first column*/,
+                                                const int n_boards) {
+    using T = ConvTile<NB, IH, IW, MT, NTW>;
+    constexpr int OUT_PER = T::OUT_PER, IN_PER = T::IN_PER, OUT_ROWS = T::OUT_ROWS, IMG_R = T::IMG_R, NCOL = T::NCOL, OW = T::OW;
+    constexpr int IMG_BYTES = T::IMG_BYTES;
+    constexpr int IPIECES = (IMG_R + 31) / 32, WPIECES = NCOL / 32;       // 1 KiB DMA pieces per wave
+    constexpr int MH = MT / 2;                                           // row tiles per cluster
+    constexpr int NM = MH * NTW;                                         // MFMAs per cluster
+    const int M = n_boards * OUT_PER;
+    const int C = d.cin;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // DMA addresses: one loop-invariant 32-bit lane offset per operand; piece q adds a uniform stride to the SGPR base.  Image rows past
+    // the batch's last board are read unclamped (the workspace keeps a tile of slack; their output rows are never stored).
+    const uint32_t i_ob = (uint32_t)((b0 * IN_PER + wave * 8 + lrow) * C + chunk * 8) * 2u;
+    const uint32_t w_ob = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
+    const uint32_t lds_img = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
+    const uint32_t lds_w = (uint32_t)(uintptr_t)(lds_ptr)(smem + IMG_BYTES + wave * 1024);
+    const size_t i_stride = (size_t)64 * C, w_stride = (size_t)64 * d.K;          // 32 rows, in bytes
+#define AZ_TDMA_W(kk_)                                                                                       \
+    {                                                                                                        \
+        const char* wbase = (const char*)(d.W + (kk_));                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < WPIECES; ++q_) lds_dma16(wbase + q_ * w_stride, w_ob, lds_w + q_ * 4096); \
+    }
+#define AZ_TDMA_IMG(cb_)                                                                                     \
+    {                                                                                                        \
+        const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < IPIECES; ++q_)                                               \
+            if ((q_ * 4 + 3) * 8 + 7 < IMG_R || (q_ * 4 + wave) * 8 + 7 < IMG_R)                             \
+                lds_dma16(ibase + q_ * i_stride, i_ob, lds_img + q_ * 4096);                                 \
+    }
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    int rbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int ml = wr * T::WROWS + mt * 16 + frow;
+        ml = ml < OUT_ROWS ? ml : 0;
+        const int bl = ml / OUT_PER, p = ml - bl * OUT_PER, y = p / OW, x = p - y * OW;
+        rbase[mt] = bl * IN_PER + y * IW + x;
+    }
+    const int b_row0 = IMG_BYTES + (wc * (16 * NTW) + frow) * 128;
+    const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
+#define AZ_TLDA(dst_, mt0_, ks_, dt_)                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < MH; ++i_) {                                                      \
+        const int r_ = rbase[(mt0_) + i_] + (dt_);                                                           \
+        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
+    }
+#define AZ_TLDB(dst_, coff_)                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < NTW; ++i_)                                                       \
+        dst_[i_] = *(const bf16x8*)(smem + b_row0 + i_ * 2048 + (coff_));
+#define AZ_TMMA(mt0_, fb_, fa_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < MH; ++i_)                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < NTW; ++j_)                                                   \
+            acc[(mt0_) + i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j_], fa_[i_], acc[(mt0_) + i_][j_], 0, 0, 0);
+#define AZ_TSB __builtin_amdgcn_sched_barrier(0)
+    // the region's nr_ reads (for the NEXT cluster) go between this cluster's NM MFMAs: nr_ x { nmf MFMAs, 1 LDS read }, then the rest
+#define AZ_TMIX(nr_)                                                                                         \
+    {                                                                                                        \
+        constexpr int nmf_ = NM / (2 * (nr_)) > 1 ? NM / (2 * (nr_)) : 1;                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < (nr_); ++g_) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, nmf_, 0);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+        }                                                                                                    \
+        if (NM - nmf_ * (nr_) > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - nmf_ * (nr_), 0);        \
+    }
+    static_assert(NM >= NTW + MH, "a cluster must hold at least one MFMA per read of its region");
+    AZ_TDMA_W(0);
+    AZ_TDMA_IMG(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 fbX[NTW], fbY[NTW], faX[MH], faY[MH];
+    AZ_TLDB(fbX, coffB0);
+    AZ_TLDA(faX, 0, 0, 0);
+    const int ncb = C / 64;
+    const int nk = ncb * 9;
+    int cb = 0, tap = 0, dt = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool sw = tap == 8;
+        const int ntap = sw ? 0 : tap + 1, ncbi = sw ? cb + 1 : cb;
+        const int nky = ntap / 3, ndt = nky * IW + (ntap - nky * 3);
+        const int kk = kt + 1 < nk ? ntap * C + ncbi * 64 : 8 * C + cb * 64;      // last step: re-fetch its own tile (unused)
+        AZ_TLDB(fbY, coffB1);
+        AZ_TLDA(faY, MH, 0, dt);
+        AZ_TMMA(0, fbX, faX);
+        AZ_TMIX(NTW + MH);
+        AZ_TSB;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this step's weight fragments are in registers
+        __builtin_amdgcn_s_barrier();
+        AZ_TSB;
+        AZ_TDMA_W(kk);
+        AZ_TLDA(faX, 0, 1, dt);
+        AZ_TMMA(MH, fbX, faY);
+        AZ_TMIX(MH);
+        AZ_TSB;
+        AZ_TLDA(faY, MH, 1, dt);
+        AZ_TMMA(0, fbY, faX);
+        AZ_TMIX(MH);
+        AZ_TSB;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // my reads of the image slice are done (they are: one cluster old)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next weight tile has landed
+        __builtin_amdgcn_s_barrier();
+        AZ_TSB;
+        if (sw && ncbi < ncb) {                                  // single image buffer: the switch is covered by the CU's other workgroup
+            AZ_TDMA_IMG(ncbi);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        AZ_TSB;
+        AZ_TLDB(fbX, coffB0);                                    // next step's first fragments, under this step's last cluster
+        AZ_TLDA(faX, 0, 0, ndt);
+        AZ_TMMA(MH, fbY, faY);
+        AZ_TMIX(NTW + MH);
+        AZ_TSB;
+        tap = ntap; cb = ncbi; dt = ndt;
+    }
+#undef AZ_TDMA_W
+#undef AZ_TDMA_IMG
+#undef AZ_TLDA
+#undef AZ_TLDB
+#undef AZ_TMMA
+#undef AZ_TSB
+#undef AZ_TMIX
+    // epilogue through LDS (the image and weight buffers are dead): [OUT_ROWS][NCOL] bf16 with a padded row stride, out as whole row
+    // segments of 16 bytes per lane
+    constexpr int EP_STRIDE = T::EP_STRIDE;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                     // every wave is past its last fragment read (and the unused last DMA has landed)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int nl = wc * (16 * NTW) + nt * 16 + fq * 4;
+        const float4 bv = *(const float4*)(d.bias + n0 + nl);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ml = wr * T::WROWS + mt * 16 + frow;
+            if (ml >= OUT_ROWS) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z,
+                  r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(smem + ml * EP_STRIDE + nl * 2) = o;
+        }
+    }
+    __syncthreads();
+    constexpr int EP_CHUNKS = OUT_ROWS * (NCOL / 8);        // 16-byte chunks of the tile
+#pragma unroll
+    for (int it = 0; it < (EP_CHUNKS + 255) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int ml = idx / (NCOL / 8), c = idx - ml * (NCOL / 8);
+        const int m = b0 * OUT_PER + ml;
+        if (idx >= EP_CHUNKS || m >= M) continue;
+        *(uint4*)(d.out + (size_t)m * d.N + n0 + c * 8) = *(const uint4*)(smem + ml * EP_STRIDE + c * 16);
+    }
+}
+
+// conv3 with a HALF-TILE TAIL.  Two 4-wave workgroups per CU is what lets one workgroup's MFMA clusters run under the other's waits; a
+// launch's workgroups arrive in rounds of 512 (two per CU), and when the last round holds at most 256 of them each runs ALONE on its CU
+// (76 us for such a level of 768 rows against 56 us for a paired one: profiles/README.md).  Here the tiles of such a last round are cut
+// in two along the CHANNELS (12 boards x 64 channels, the same image, half the weights and half the MFMAs per step): twice as many
+// workgroups, two per CU again.  The role of a workgroup follows from the batch's row count, read on the device; the host launches the
+// full grid for its upper bound plus 256 extra workgroups (the second halves), which exit at once when no tile is cut.
+constexpr int C3_TAIL = 256;
+template <int LAYER>
+__global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const int full_grid) {
+    using TF = ConvTile<C3_NB, 6, 7, 8, 4>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TF::LDS_BYTES];
+    const int n_boards = (int)(*d.n_dev);
+    const int NT = d.N / 128;
+    const int tiles8 = ((n_boards + C3_NB - 1) / C3_NB + 7) / 8 * 8;
+    const int wid = tiles8 * NT;                       // workgroup ids that map to a tile of this batch (the last group of 8 row tiles may be partly empty)
+    const int full_rounds = wid / 512 * 512, rem = wid - full_rounds;
+    const bool cut = rem > 0 && rem <= C3_TAIL;        // the last round would run one workgroup per CU
+    int id = blockIdx.x, half = -1;
+    if (id >= full_grid) {                             // an extra workgroup: the second half of a cut tile
+        if (!cut || id - full_grid >= rem) return;
+        id = full_rounds + (id - full_grid);
+        half = 1;
+    } else if (cut && id >= full_rounds) {
+        half = 0;
+    }
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * C3_NB, n0 = ntile * 128;
+    if (b0 >= n_boards) return;
+    if (half < 0) conv_valid_tile<C3_NB, 6, 7, 8, 4>(d, smem, b0, n0, n_boards);
+    else conv_valid_tile<C3_NB, 6, 7, 8, 2>(d, smem, b0, n0 + half * 64, n_boards);
+}
+
+// conv4 image-resident: 20 boards (120 of 128 output rows) x 128 channels per workgroup, two workgroups per CU.  The ring kernel it
+// replaces re-fetches every input row for each of the up to 9 taps it serves (6 outputs x 9 taps over 20 inputs: 2.7x): 36 KB L2 -> LDS
+// per K-step of a 160-row tile against 50 KB once per channel block + 16 KB of weights per step here (21.6 KB per step).
+constexpr int C4_NB = 20;
+template <int LAYER>
+__global__ __launch_bounds__(256, 2) void k_conv4_img(const GemmDesc d) {
+    using TF = ConvTile<C4_NB, 4, 5, 4, 4>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TF::LDS_BYTES];
+    const int n_boards = (int)(*d.n_dev);
+    const int NT = d.N / 128;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * C4_NB, n0 = ntile * 128;
+    if (b0 >= n_boards) return;
+    conv_valid_tile<C4_NB, 4, 5, 4, 4>(d, smem, b0, n0, n_boards);
+}
+
 #ifdef AZ_DIAG
 #include "az_net_diag.inc"
 #endif
@@ -1171,7 +1409,7 @@ NetWorkspace* netws_create(int channels, int max_batch, const char** err) {
     const size_t B = (size_t)max_batch;
     bool ok = true;
     ok &= (n->act2 = n->dalloc<uint16_t>((B + 16) * 42 * C)) != nullptr;     // + 16 boards: k_conv_valid_pipe reads its last tile unclamped
-    ok &= (n->act3 = n->dalloc<uint16_t>(B * 20 * C)) != nullptr;
+    ok &= (n->act3 = n->dalloc<uint16_t>((B + 32) * 20 * C)) != nullptr;      // + 32 boards: k_conv4_img reads its last tile unclamped
     ok &= (n->act4 = n->dalloc<uint16_t>(B * 6 * C)) != nullptr;
     ok &= (n->fc1o = n->dalloc<uint16_t>(B * 1024)) != nullptr;
     ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
@@ -1333,10 +1571,17 @@ static void launch_conv2_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     const int t8 = (tiles + 7) / 8 * 8;
     hipLaunchKernelGGL((k_conv_same_pipe<1, TABLE>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
 }
-static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s) {
+static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s, bool tail) {
     const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
     const int t8 = (tiles + 7) / 8 * 8;
-    hipLaunchKernelGGL((k_conv_valid_pipe<2, C3_NB, 6, 7, false, 0, true>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
+    const int full_grid = t8 * (d.N / 128);
+    if (tail) hipLaunchKernelGGL((k_conv3_auto<2>), dim3(full_grid + C3_TAIL), dim3(256), 0, s, d, full_grid);
+    else hipLaunchKernelGGL((k_conv_valid_pipe<2, C3_NB, 6, 7, false, 0, true>), dim3(full_grid), dim3(256), 0, s, d);
+}
+static void launch_conv4_image(const GemmDesc& d, int rows_hint, hipStream_t s) {
+    const int tiles = (rows_hint + C4_NB - 1) / C4_NB;
+    const int t8 = (tiles + 7) / 8 * 8;
+    hipLaunchKernelGGL((k_conv4_img<3>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
 }
 // The LDS-DMA ring with the tile rows picked on the device.  The host picks the FAMILY from its estimate (NS = 4: one workgroup per CU,
 // for grids of at most 256 tiles; the estimate + 15 %: a batch over the limit would pay a whole second round), the kernel picks the
@@ -1471,7 +1716,12 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     }
     if constexpr (LAYER == 2) {
         if (o.conv3_small && conv3_is_small(d, rows_hint, rows_typ)) launch_ring_auto<LAYER>(d, rows_hint, rows_typ, s, true);
-        else launch_conv3_image(d, rows_hint, s);
+        else launch_conv3_image(d, rows_hint, s, o.conv3_tail != 0);
+        return;
+    }
+    if constexpr (LAYER == 3) if (o.conv4_image && d.rows_per_sample == 6 &&
+                                  (rows_typ > 0 ? (long long)rows_typ : (long long)rows_hint) >= o.conv4_image_min_rows) {
+        launch_conv4_image(d, rows_hint, s);
         return;
     }
     launch_ring_auto<LAYER>(d, rows_hint, rows_typ, s);
