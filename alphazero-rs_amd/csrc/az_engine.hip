@@ -156,7 +156,10 @@ struct TreeHost {
     TreeDev d{};
     EvalBatch eb{};         // eval batch of even simulations (and of the root evaluation)
     EvalBatch eb2{};        // eval batch of odd simulations: k_backup_select ping-pongs between the two
-    uint32_t dd_epoch = 0;  // election-table epoch of the last request launch (both batches share the counter)
+    // a run of simulation steps as ONE hipGraph launch (run_search): every launch of a search takes the same arguments, so the
+    // instantiated graph is reused as long as nothing that shapes a launch changes (graph_key: grids, kernel choices, pointers)
+    struct StepGraph { hipGraphExec_t exec = nullptr; std::vector<unsigned char> key; };
+    StepGraph step_graph;
     unsigned long long* d_totals = nullptr;   // [ST_COUNT] k_harvest's sums
     uint32_t* d_counts = nullptr;             // [G] NodeStore::len per tree (k_harvest)
     // blocks = child blocks the trees can use (each holds the <= 7 children of one expansion, or a root);
@@ -172,10 +175,13 @@ struct TreeHost {
         HIPCHK(hipMemsetAsync(d_totals, 0, ST_TOTALS * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(eb.n, 0, sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(eb2.n, 0, sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(eb.tkey, 0, ((size_t)eb.tmask + 1) * 8, s));       // a call that failed half way may have left keys behind
+        HIPCHK(hipMemsetAsync(eb2.tkey, 0, ((size_t)eb2.tmask + 1) * 8, s));
         if (d.thr) HIPCHK(hipMemsetAsync(d.thr, 0, (size_t)d.G * d.T * sizeof(TreeLine), s));
         launch_init_heads(d, s);
     }
     // T = simulations in flight per tree (1: the single-simulation kernels; > 1: per-thread lines + T rows per tree in a leaf batch)
+    ~TreeHost() { if (step_graph.exec) (void)hipGraphExecDestroy(step_graph.exec); }
     void create(int G, uint64_t blocks, uint64_t reserve_nodes, uint32_t H, int T, int game) {
         k_G = G; k_blocks = blocks; k_H = H; k_T = T;
         d.game = game;
@@ -273,7 +279,7 @@ struct az_engine {
     int profile_every = 1;          // profile mode: bracket every n-th simulation step ("profile_every")
     int dedup_stats = 1;            // "dedup_stats": the leaf-row accounting counters (requested / executed / hits / duplicates)
     uint64_t profile_tick = 0;
-    int dedup_epoch_max = 0x7FFF;   // election-table epochs before the tables are cleared (15 bits; tests lower it: "dedup_epoch_max")
+    int search_graph = 20;          // "search_graph": simulation steps per hipGraph launch (0 = every kernel launched on its own); not in profile mode
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
     int eval_cache_log2 = 27;       // entries = 2^log2 (40 B each: 5.4 GB); 0 = no cache, in-batch de-duplication only
@@ -488,16 +494,6 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
         return;
     }
     const EvalCache ec = cache_for(e, net);
-    // every launch that requests leaves gets its own election-table epoch (15 bits; stale keys could look current again
-    // after a wrap, so the tables are cleared then)
-    auto next_epoch = [&]() -> uint32_t {
-        if (++th.dd_epoch > (uint32_t)e->dedup_epoch_max) {
-            HIPCHK(hipMemsetAsync(th.eb.tkey, 0, ((size_t)th.eb.tmask + 1) * 8, s));
-            HIPCHK(hipMemsetAsync(th.eb2.tkey, 0, ((size_t)th.eb2.tmask + 1) * 8, s));
-            th.dd_epoch = 1;
-        }
-        return th.dd_epoch;
-    };
     EvalBatch B[2] = {th.eb, th.eb2};
     B[0].dedup = B[1].dedup = dedup ? 1 : 0;
     B[0].max_n = B[1].max_n = d_max_rows;
@@ -505,7 +501,6 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
     const int every = std::max(1, e->profile_every);
     // root: prepare (its leaf goes to batch 0), predict; then num_sims x {backup of the previous leaf + select of the next
     // (one launch, the new leaf goes to the other batch), predict}; a last backup closes the search.
-    B[0].epoch = next_epoch();
     launch_root_prepare(th.d, B[0], ec, d_root_states, s);
     net_forward(e, net, B[0], rows_hint, s, rows_typ, false);
     if (T > 1) {
@@ -515,7 +510,6 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
             const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
             hipEvent_t t0 = nullptr;
             if (timed) t0 = e->prof.begin(s);
-            B[(i + 1) & 1].epoch = next_epoch();
             launch_step_mt(th.d, B[i & 1], B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, 0, s);
             if (timed) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
             e->stats.tree_launches += 1;
@@ -524,17 +518,63 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
         launch_step_mt(th.d, B[steps & 1], B[(steps + 1) & 1], ec, sp, steps == 0 ? 1 : 0, 1, s);
         return;
     }
-    for (int i = 0; i < num_sims; ++i) {
+    int i = 0;
+    // A search is a chain of num_sims x ~8 dependent launches; on small batches (the arena, single trees, the drain of a self-play
+    // call) the HOST's launch calls, not the kernels, set its pace.  Every simulation step takes the same arguments (the batches
+    // ping-pong with the step's parity), so S steps (S even) are captured once into a hipGraph and replayed; the graph is kept with
+    // the tree arena and re-captured only when something that shapes a launch changes.
+    const int S = e->search_graph;
+    if (S >= 2 && !e->prof.on && num_sims >= S) {
+        // the grids' bound and the tile estimate in powers of two: the graph survives from move to move (a larger bound only adds
+        // workgroups that exit at once; the estimate only picks tile families)
+        auto pow2_up = [](int x, int cap) { int p = 1; while (p < x) p <<= 1; return p < cap ? p : cap; };
+        rows_hint = pow2_up(rows_hint, th.d.G * T);
+        if (rows_typ > 0) rows_typ = pow2_up(rows_typ, rows_hint);
+        struct Key {
+            const void *th, *conv, *ws, *stream, *root_states, *max_rows, *ec_key, *ec_stat, *log_state, *log_row;
+            unsigned long long ec_tag, salt;
+            int kind, rows_hint, rows_typ, S, dedup, block4, log_cap;
+            uint32_t ec_bmask, ec_stones, max_depth;
+            float cpuct;
+            NetOptions opt;
+        } k;
+        std::memset(&k, 0, sizeof k);
+        k.th = &th; k.conv = net.conv; k.ws = net.kind == AZ_NET_CONV ? workspace_for(e, s) : nullptr; k.stream = s; k.root_states = d_root_states;
+        k.max_rows = d_max_rows; k.ec_key = ec.key; k.ec_stat = ec.stat; k.log_state = th.d.log_state; k.log_row = th.d.log_row;
+        k.ec_tag = ec.tag; k.salt = net.salt; k.kind = net.kind; k.rows_hint = rows_hint; k.rows_typ = rows_typ; k.S = S; k.dedup = dedup ? 1 : 0;
+        k.block4 = th.d.block4; k.log_cap = th.d.log_cap; k.ec_bmask = ec.bmask; k.ec_stones = ec.max_stones; k.max_depth = sp.max_depth; k.cpuct = sp.cpuct_f;
+        k.opt = e->netopt;
+        TreeHost::StepGraph& sg = th.step_graph;
+        if (!sg.exec || sg.key.size() != sizeof k || std::memcmp(sg.key.data(), &k, sizeof k) != 0) {
+            if (sg.exec) { HIPCHK(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
+            if (net.kind == AZ_NET_CONV) convnet_prepare(workspace_for(e, s), e->netopt);      // nothing may allocate while the stream is capturing
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            for (int j = 0; j < S; ++j) {
+                launch_backup_select(th.d, B[j & 1], B[(j + 1) & 1], ec, sp, s);
+                net_forward(e, net, B[(j + 1) & 1], rows_hint, s, rows_typ, false);
+            }
+            HIPCHK(hipStreamEndCapture(s, &g));
+            const hipError_t ie = hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ie != hipSuccess) { sg.exec = nullptr; throw HipFail{ie, "hipGraphInstantiate"}; }
+            sg.key.assign((const unsigned char*)&k, (const unsigned char*)&k + sizeof k);
+        }
+        for (; i + S <= num_sims; i += S) {
+            HIPCHK(hipGraphLaunch(sg.exec, s));
+            e->stats.tree_launches += (uint64_t)S;
+        }
+    }
+    for (; i < num_sims; ++i) {
         const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
         hipEvent_t t0 = nullptr;
         if (timed) t0 = e->prof.begin(s);
-        B[(i + 1) & 1].epoch = next_epoch();
-        launch_backup_select(th.d, B[i & 1], B[(i + 1) & 1], ec, sp, i == 0 ? 1 : 0, s);   // i == 0: the root's priors only
+        launch_backup_select(th.d, B[i & 1], B[(i + 1) & 1], ec, sp, s);
         if (timed) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
         e->stats.tree_launches += 1;
         net_forward(e, net, B[(i + 1) & 1], rows_hint, s, rows_typ, timed);
     }
-    launch_backup(th.d, B[num_sims & 1], ec, 0, s);
+    launch_backup(th.d, B[num_sims & 1], ec, s);
 }
 
 void resolve_profile(az_engine* e) {
@@ -652,12 +692,11 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("conv2_table") && (value == 0 || value == 1)) { e->netopt.conv2_table = (int)value; return AZ_OK; }
     if (is("conv3_small") && (value == 0 || value == 1)) { e->netopt.conv3_small = (int)value; return AZ_OK; }
     if (is("conv3_tail") && (value == 0 || value == 1)) { e->netopt.conv3_tail = (int)value; return AZ_OK; }
-    if (is("conv4_image") && (value == 0 || value == 1)) { e->netopt.conv4_image = (int)value; return AZ_OK; }
-    if (is("conv4_image_min_rows") && value >= 0 && value <= 1000000) { e->netopt.conv4_image_min_rows = (int)value; return AZ_OK; }
+    if (is("narrow_rows") && value >= 0 && value <= 65536) { e->netopt.narrow_rows = (int)value; return AZ_OK; }
     if (is("tree_block4") && (value == 0 || value == 1)) { e->tree_block4 = (int)value; return AZ_OK; }
     if (is("dedup_stats") && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }
     if (is("profile_every") && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
-    if (is("dedup_epoch_max") && value >= 3 && value <= 0x7FFF) { e->dedup_epoch_max = (int)value; return AZ_OK; }
+    if (is("search_graph") && value >= 0 && value <= 1000 && value % 2 == 0) { e->search_graph = (int)value; return AZ_OK; }
     if (is("fused_search") && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
     if (is("eval_dedup") && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
     if (is("eval_cache_log2") && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }

@@ -70,9 +70,9 @@ void netws_resolve_profile(NetWorkspace* ws, NetProfile* prof);
 struct NetOptions {
     int conv2_table = 1;    // 1: conv1 + conv2 as table gathers (k_conv2_table_x); 0: conv2 as the MFMA implicit GEMM (same function, other rounding)
     int conv3_small = 1;    // conv3 of a small expected batch on the 4-stage LDS-DMA ring (bit-identical)
-    int conv3_tail = 1;     // conv3: a last round of at most 256 workgroups is cut into half tiles (two per CU again); 0 = full tiles only (bit-identical)
-    int conv4_image = 1;    // conv4 image-resident (k_conv4_img) from conv4_image_min_rows expected rows; 0 = always the ring (bit-identical)
-    int conv4_image_min_rows = 600;
+    int conv3_tail = 1;     // conv3: a short last round of workgroups is cut into half tiles (k_conv3_auto); 0 = full tiles only (bit-identical)
+    int narrow_rows = 32;   // conv3 / conv4 / fc1 / fc2 of a batch of at most this many rows (x 2 for conv4, x 4 for the FCs) run as the register-fed
+                            // skinny GEMM (k_gemm_skinny), decided on the device from the exact row count; 0 = never (bit-identical)
     // ---- diagnostic library only ----
     int gemm_variant = 5;   // 0 128x128 register-staged tiles everywhere; 1 / 2 256x256 LDS-DMA tiles; 3 conv2 image-resident, one 8-wave
                             // workgroup per CU; 5 the shipped set; 11-17 timing ablations of variant 2 (WRONG results)
@@ -87,6 +87,9 @@ struct NetOptions {
 };
 // diagnostic variant 13 only: per-block {shader cycles, 100 MHz ticks} of the conv2 K loop
 bool netws_read_clock_stamps(NetWorkspace* ws, unsigned long long* out2048);
+// allocate what a forward under `opt` may need later (conv1's haloed image for the kernel sets that run conv1 as a kernel), so that
+// convnet_forward never allocates -- it may run inside a stream capture
+bool convnet_prepare(NetWorkspace* ws, const NetOptions& opt);
 // forward for rows [0, *eb.n) of model n in workspace ws; n_rows_hint = host-side upper bound used to size the grids.
 // If prof != nullptr the forward and its conv2 launch are bracketed with HIP events (resolved later).
 // n_rows_typ = expected row count (kernel / tile choice only; 0 = n_rows_hint).

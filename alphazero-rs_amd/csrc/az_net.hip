@@ -270,6 +270,10 @@ struct GemmDesc {
     unsigned long long* dbg;   // diagnostic builds only (ABLATE == 3): per-block {shader cycles, 100 MHz ticks}
     const ulonglong2* states;  // k_conv_img2<.., true> only: the batch's canonical bitboards (A is then the conv1 table)
     int out_f16;               // k_gemm_mfma only: store the raw f32 accumulators as f16 (no bias, no ReLU): the conv2 table build
+    // device-side hand-over between the small-batch kernel and the tiled kernels of a layer (both may be launched when the host's
+    // estimate cannot tell; exactly one of them finds the batch's row count on its side of the line and runs):
+    int m_min;                 // tiled kernels: do nothing when the batch has at most this many output rows (0 = always run)
+    int m_max;                 // k_gemm_skinny: do nothing when the batch has more than this many output rows
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -562,6 +566,7 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring_auto(const
     constexpr int BMAX = NS == 2 ? 192 : 128;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BMAX * 128 + 16384)];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    if (M <= d.m_min) return;                          // the small-batch kernel launched beside this one takes the batch
     const int bm = __builtin_amdgcn_readfirstlane(ring_pick_bm(M, d.N / GBN, NS, d.tap_w > 1));
     if constexpr (NS == 2) {
         if (bm == 96) gemm_ring_body<2, 96>(d, smem, M);
@@ -838,6 +843,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[IMG_BYTES + NCOL * 128];   // img | w
     const int n_boards = (int)(*d.n_dev);
     const int M = n_boards * OUT_PER;
+    if (M <= d.m_min) return;                          // the small-batch kernel launched beside this one takes the batch
     const int C = d.cin;
     const int NT = d.N / NCOL;
     const int id = blockIdx.x;
@@ -1038,7 +1044,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
 //   conv3 full tile   NB 12, 6x7, MT 8, NTW 4   240 of 256 rows x 128 channels, 63 + 16 KiB (= k_conv_valid_pipe)
 //   conv3 half tile   NB 12, 6x7, MT 8, NTW 2   the same boards x 64 channels, 63 + 8 KiB: two of them share a CU where a full tile would
 //                                               run alone (k_conv3_auto)
-//   conv4             NB 20, 4x5, MT 4, NTW 4   120 of 128 rows x 128 channels, 50 + 16 KiB
+//   (conv4 as NB 20, 4x5, MT 4, NTW 4 -- 120 of 128 rows x 128 channels, 50 + 16 KiB -- was built and measured in round 3: bit-identical and
+//    slower than the ring at every batch size, 64 against 59 us at 2300 rows, 258 against 197 at 8192: profiles/README.md; removed)
 template <int NB, int IH, int IW, int MT, int NTW>
 struct ConvTile {
     static constexpr int OH = IH - 2, OW = IW - 2, OUT_PER = OH * OW, IN_PER = IH * IW;
@@ -1218,18 +1225,22 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
     }
 }
 
-// conv3 with a HALF-TILE TAIL.  Two 4-wave workgroups per CU is what lets one workgroup's MFMA clusters run under the other's waits; a
-// launch's workgroups arrive in rounds of 512 (two per CU), and when the last round holds at most 256 of them each runs ALONE on its CU
-// (76 us for such a level of 768 rows against 56 us for a paired one: profiles/README.md).  Here the tiles of such a last round are cut
-// in two along the CHANNELS (12 boards x 64 channels, the same image, half the weights and half the MFMAs per step): twice as many
-// workgroups, two per CU again.  The role of a workgroup follows from the batch's row count, read on the device; the host launches the
-// full grid for its upper bound plus 256 extra workgroups (the second halves), which exit at once when no tile is cut.
-constexpr int C3_TAIL = 256;
+// conv3 with a HALF-TILE TAIL.  A launch's workgroups arrive in rounds of 512 (two per CU); a short last round keeps a few CUs busy for a
+// whole workgroup's duration while the rest of the chip idles.  The tiles of such a round are cut in two along the CHANNELS (12 boards x
+// 64 channels: the same image, half the weights and half the MFMAs per step), so the tail lasts about 0.6 of a full tile.  The role of a
+// workgroup follows from the batch's row count, read on the device; the host launches the full grid for its upper bound plus C3_TAIL
+// extra workgroups (the second halves), which exit at once when no tile is cut.
+// Measured (tools/layer_times.py, round 3): cutting pays when the halves still run alone on their CUs, i.e. for a last round of at most
+// 128 workgroups (3100 rows: 254 -> 240 us; 700 rows: 77 -> 71); a last round of 129-256 cut into 258-512 halves runs two halves per CU
+// and is slower than the uncut round (2300 rows: 160 -> 170 us) -- a workgroup alone on its CU is not the 76-us level round 2's notes
+// priced it at, so those rounds stay uncut.
+constexpr int C3_TAIL = 128;
 template <int LAYER>
 __global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const int full_grid) {
     using TF = ConvTile<C3_NB, 6, 7, 8, 4>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TF::LDS_BYTES];
     const int n_boards = (int)(*d.n_dev);
+    if (n_boards * d.rows_per_sample <= d.m_min) return;      // the small-batch kernel launched beside this one takes the batch
     const int NT = d.N / 128;
     const int tiles8 = ((n_boards + C3_NB - 1) / C3_NB + 7) / 8 * 8;
     const int wid = tiles8 * NT;                       // workgroup ids that map to a tile of this batch (the last group of 8 row tiles may be partly empty)
@@ -1251,22 +1262,116 @@ __global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const i
     else conv_valid_tile<C3_NB, 6, 7, 8, 2>(d, smem, b0, n0 + half * 64, n_boards);
 }
 
-// conv4 image-resident: 20 boards (120 of 128 output rows) x 128 channels per workgroup, two workgroups per CU.  The ring kernel it
-// replaces re-fetches every input row for each of the up to 9 taps it serves (6 outputs x 9 taps over 20 inputs: 2.7x): 36 KB L2 -> LDS
-// per K-step of a 160-row tile against 50 KB once per channel block + 16 KB of weights per step here (21.6 KB per step).
-constexpr int C4_NB = 20;
-template <int LAYER>
-__global__ __launch_bounds__(256, 2) void k_conv4_img(const GemmDesc d) {
-    using TF = ConvTile<C4_NB, 4, 5, 4, 4>;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TF::LDS_BYTES];
-    const int n_boards = (int)(*d.n_dev);
-    const int NT = d.N / 128;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
-    const int b0 = mtile * C4_NB, n0 = ntile * 128;
-    if (b0 >= n_boards) return;
-    conv_valid_tile<C4_NB, 4, 5, 4, 4>(d, smem, b0, n0, n_boards);
+// ---- SKINNY GEMM for small batches: operands straight into registers, no LDS, no barrier ---------------------------------------------
+// The arena (temp 0: ~20 executed rows per step and model), the drain of a self-play call and single-tree calls run the forward on a
+// few dozen rows.  The tiled kernels are then a chain of K / 64 dependent steps of { DMA, wait, barrier, fragment reads, MFMAs } run by
+// a handful of workgroups: conv3 took 32 us, conv4 32, fc1 21 whatever the rows (32 x 32 tiles on an 8-stage ring, built first in
+// round 3, still took 20 us per layer: the step is latency, not bytes).  Here a WAVE is the unit: it owns MR x NR accumulators of
+// 16 x 16 and loads the operand fragments of a K-step directly in the MFMA register layout (lane = row lane & 15, k-group lane >> 4: 16
+// contiguous bytes per lane), D K-steps ahead in a register ring; the compiler's counted vmcnt waits retire them; no wave waits for
+// another.  A CU takes register loads in at only ~10 B/clk (MI355X_MICROARCH.md; four waves of one CU streaming 64 columns measured
+// 36 us for conv3 at ONE row, bound by exactly that), so the point is how many CUs share the weight stream:
+//   1 x 1 tiles, D = 8   ceil(M / 16) x N / 16 waves, 2 loads per MFMA: up to 256 waves (conv3 at one row: 64 waves, 13 us)
+//   2 x 2 tiles, D = 4   a quarter of the waves, 1 load per MFMA: beyond that
+// chosen on the device from the batch's exact row count.  Same K order per accumulator (channel block outer, tap inner; k 0..31 then
+// 32..63 of a block) as every other kernel of the layer: bit-identical.
+template <int MR, int NR, int D>
+__device__ __forceinline__ void gemm_skinny_tile(const GemmDesc& d, const int M, const int mtile, const int ntile, const int lane) {
+    const int m0 = mtile * (16 * MR), n0 = ntile * (16 * NR);
+    const int frow = lane & 15, fq = lane >> 4;
+    const uint16_t* a_ptr[MR];
+    const uint16_t* w_ptr[NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        int m = m0 + i * 16 + frow;
+        m = m < M ? m : M - 1;
+        const int b = m / d.rows_per_sample, r = m - b * d.rows_per_sample;
+        const int y = r / d.out_w, x = r - y * d.out_w;
+        a_ptr[i] = d.A + (size_t)((b * d.in_h + y) * d.in_w + x) * d.in_c + fq * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) w_ptr[j] = d.W + (size_t)(n0 + j * 16 + frow) * d.K + fq * 8;
+    const int ntaps = d.K / d.cin;
+    const int nk = d.K / GBK;
+    // K-step walker (channel block outer, tap inner), scalars only
+    int ks_tap = 0, ks_kx = 0;
+    uint32_t ks_c0 = 0, ks_toff = 0, ks_kk = 0;
+    bf16x8 fa0[D][MR], fa1[D][MR], fb0[D][NR], fb1[D][NR];
+#define AZ_SLOAD(s_)                                                                                    \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < MR; ++i_) {                                             \
+            fa0[s_][i_] = *(const bf16x8*)(a_ptr[i_] + ks_toff); fa1[s_][i_] = *(const bf16x8*)(a_ptr[i_] + ks_toff + 32); }  \
+        _Pragma("unroll") for (int j_ = 0; j_ < NR; ++j_) {                                             \
+            fb0[s_][j_] = *(const bf16x8*)(w_ptr[j_] + ks_kk); fb1[s_][j_] = *(const bf16x8*)(w_ptr[j_] + ks_kk + 32); }      \
+        ++ks_tap; ++ks_kx; ks_toff += (uint32_t)d.in_c; ks_kk += (uint32_t)d.cin;                       \
+        if (ks_kx == d.tap_w) { ks_kx = 0; ks_toff += (uint32_t)((d.in_w - d.tap_w) * d.in_c); }        \
+        if (ks_tap == ntaps) { ks_tap = 0; ks_kx = 0; ks_c0 += GBK; ks_toff = ks_c0; ks_kk = ks_c0; }   \
+    }
+#define AZ_SMMA(s_)                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < MR; ++i_)                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < NR; ++j_) {                                             \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[s_][j_], fa0[s_][i_], acc[i_][j_], 0, 0, 0); \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[s_][j_], fa1[s_][i_], acc[i_][j_], 0, 0, 0); \
+        }
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < D; ++st) AZ_SLOAD(st);
+    // steady state: straight-line body (every slot is used, then refilled D steps ahead), so the waits stay counted
+    for (int kt = D; kt < nk; kt += D) {
+#pragma unroll
+        for (int st = 0; st < D; ++st) { AZ_SMMA(st); AZ_SLOAD(st); }
+    }
+#pragma unroll
+    for (int st = 0; st < D; ++st) AZ_SMMA(st);          // the last D steps: nothing left to fetch
+#undef AZ_SLOAD
+#undef AZ_SMMA
+    // epilogue: a lane holds 4 consecutive output channels of one row
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int mo = m0 + i * 16 + frow;
+        if (mo >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int n = n0 + j * 16 + fq * 4;
+            const float4 bv = *(const float4*)(d.bias + n);
+            float r0 = acc[i][j][0] + bv.x, r1 = acc[i][j][1] + bv.y, r2 = acc[i][j][2] + bv.z, r3 = acc[i][j][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(d.out + (size_t)mo * d.N + n) = o;
+        }
+    }
+}
+constexpr int SK_SMALL_WAVES = 256;         // 1 x 1 tiles while they make at most this many waves, 2 x 2 beyond
+static inline int skinny_waves_max(int M, int N) {     // a grid that covers either tiling of any batch of up to M output rows
+    const int w1 = (std::min(M, SK_SMALL_WAVES * 16 * 16 / N) + 15) / 16 * (N / 16), w2 = (M + 31) / 32 * (N / 32);
+    return std::max(std::max(w1, w2), 1);
+}
+AZ_HD int skinny_waves(int M, int N) {        // waves the launch runs on a batch of M output rows
+    const int w1 = (M + 15) / 16 * (N / 16);
+    return w1 <= SK_SMALL_WAVES ? w1 : (M + 31) / 32 * (N / 32);
+}
+template <int LAYER, int D1>      // D1 (ring depth of the 1 x 1 tiles) and D1 / 2 divide K / 64: 8 at C = 512 (72 / 48 / 16 steps), else 6 or 2
+__global__ __launch_bounds__(64) void k_gemm_skinny(const GemmDesc d) {
+    const int M = (int)(*d.n_dev) * d.rows_per_sample;
+    if (M > d.m_max || M <= 0) return;
+    const int lane = threadIdx.x;
+    if ((M + 15) / 16 * (d.N / 16) <= SK_SMALL_WAVES) {
+        const int NT = d.N / 16;
+        const int ntile = blockIdx.x % NT, mtile = blockIdx.x / NT;
+        if (mtile * 16 >= M) return;
+        gemm_skinny_tile<1, 1, D1>(d, M, mtile, ntile, lane);
+    } else {
+        const int NT = d.N / 32;
+        const int ntile = blockIdx.x % NT, mtile = blockIdx.x / NT;
+        if (mtile * 32 >= M) return;
+        gemm_skinny_tile<2, 2, (D1 >= 4 ? D1 / 2 : D1)>(d, M, mtile, ntile, lane);
+    }
 }
 
 #ifdef AZ_DIAG
@@ -1409,7 +1514,7 @@ NetWorkspace* netws_create(int channels, int max_batch, const char** err) {
     const size_t B = (size_t)max_batch;
     bool ok = true;
     ok &= (n->act2 = n->dalloc<uint16_t>((B + 16) * 42 * C)) != nullptr;     // + 16 boards: k_conv_valid_pipe reads its last tile unclamped
-    ok &= (n->act3 = n->dalloc<uint16_t>((B + 32) * 20 * C)) != nullptr;      // + 32 boards: k_conv4_img reads its last tile unclamped
+    ok &= (n->act3 = n->dalloc<uint16_t>(B * 20 * C)) != nullptr;
     ok &= (n->act4 = n->dalloc<uint16_t>(B * 6 * C)) != nullptr;
     ok &= (n->fc1o = n->dalloc<uint16_t>(B * 1024)) != nullptr;
     ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
@@ -1432,6 +1537,13 @@ static bool netws_need_act1(NetWorkspace* n) {
     const size_t bytes = (size_t)n->max_batch * 72 * n->C * sizeof(uint16_t);
     n->act1 = n->dalloc<uint16_t>(bytes / sizeof(uint16_t));
     return n->act1 && hipMemset(n->act1, 0, bytes) == hipSuccess;   // the zero halo
+}
+
+bool convnet_prepare(NetWorkspace* ws, const NetOptions& o) {
+    const bool shipped_set = o.gemm_variant == 5;
+    const bool table2 = o.conv2_table && shipped_set;
+    const bool table = !table2 && o.conv1_table && shipped_set && ws->C % HBN_ == 0;
+    return (table || table2) ? true : netws_need_act1(ws);
 }
 
 void netws_destroy(NetWorkspace* n) {
@@ -1578,11 +1690,7 @@ static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s, 
     if (tail) hipLaunchKernelGGL((k_conv3_auto<2>), dim3(full_grid + C3_TAIL), dim3(256), 0, s, d, full_grid);
     else hipLaunchKernelGGL((k_conv_valid_pipe<2, C3_NB, 6, 7, false, 0, true>), dim3(full_grid), dim3(256), 0, s, d);
 }
-static void launch_conv4_image(const GemmDesc& d, int rows_hint, hipStream_t s) {
-    const int tiles = (rows_hint + C4_NB - 1) / C4_NB;
-    const int t8 = (tiles + 7) / 8 * 8;
-    hipLaunchKernelGGL((k_conv4_img<3>), dim3(t8 * (d.N / 128)), dim3(256), 0, s, d);
-}
+
 // The LDS-DMA ring with the tile rows picked on the device.  The host picks the FAMILY from its estimate (NS = 4: one workgroup per CU,
 // for grids of at most 256 tiles; the estimate + 15 %: a batch over the limit would pay a whole second round), the kernel picks the
 // tile rows from the exact count (measured: tools/ring_tiles.py, profiles/README.md).
@@ -1709,22 +1817,39 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
 #ifdef AZ_DIAG
     if (launch_gemm_diag<LAYER>(d, rows_hint, rows_typ, s, o)) return;
 #endif
+    // Small batches: the register-fed skinny GEMM (k_gemm_skinny) for batches of at most `lim` boards (per layer: a conv3 row is 20
+    // output rows, a conv4 row 6, an fc row 1).  The host only knows an estimate (the largest batch of the previous move), and in the arena
+    // or a draining self-play call most steps are far smaller than that: unless the estimate is far above the line BOTH kernels are
+    // launched and each checks the batch's exact row count on the device (m_max / m_min): one runs, the other exits at once.
+    GemmDesc dd = d;
+    if constexpr (LAYER >= 2) if (o.narrow_rows > 0 && d.N % 32 == 0) {
+        const int lim = o.narrow_rows * (LAYER == 2 ? 1 : LAYER == 3 ? 2 : 4);
+        const int est = rows_typ > 0 ? rows_typ : rows_hint;
+        if (est <= 16 * lim) {
+            dd.m_max = lim * d.rows_per_sample;
+            const int rows_cov = rows_hint < lim ? rows_hint : lim;
+            const dim3 grid((unsigned)skinny_waves_max(rows_cov * d.rows_per_sample, d.N)), block(64);
+            const int nk = d.K / GBK;
+            if (nk % 8 == 0) hipLaunchKernelGGL((k_gemm_skinny<LAYER, 8>), grid, block, 0, s, dd);
+            else if (nk % 6 == 0) hipLaunchKernelGGL((k_gemm_skinny<LAYER, 6>), grid, block, 0, s, dd);
+            else hipLaunchKernelGGL((k_gemm_skinny<LAYER, 2>), grid, block, 0, s, dd);
+            if (rows_hint <= lim) return;                 // the bound itself is small: nothing else can be needed
+            dd.m_min = dd.m_max;
+        }
+    }
+    const GemmDesc& d2 = dd;
     if constexpr (LAYER == 1) if (d.N % HBN_ == 0 && d.cin % 64 == 0) {      // conv2 as a GEMM, image-resident (needs 256-channel multiples)
-        if (d.states) launch_conv2_gemm<true>(d, rows_hint, s);
-        else launch_conv2_gemm<false>(d, rows_hint, s);
+        if (d.states) launch_conv2_gemm<true>(d2, rows_hint, s);
+        else launch_conv2_gemm<false>(d2, rows_hint, s);
         return;
     }
     if constexpr (LAYER == 2) {
-        if (o.conv3_small && conv3_is_small(d, rows_hint, rows_typ)) launch_ring_auto<LAYER>(d, rows_hint, rows_typ, s, true);
-        else launch_conv3_image(d, rows_hint, s, o.conv3_tail != 0);
+        if (o.conv3_small && conv3_is_small(d2, rows_hint, rows_typ)) launch_ring_auto<LAYER>(d2, rows_hint, rows_typ, s, true);
+        else launch_conv3_image(d2, rows_hint, s, o.conv3_tail != 0);
         return;
     }
-    if constexpr (LAYER == 3) if (o.conv4_image && d.rows_per_sample == 6 &&
-                                  (rows_typ > 0 ? (long long)rows_typ : (long long)rows_hint) >= o.conv4_image_min_rows) {
-        launch_conv4_image(d, rows_hint, s);
-        return;
-    }
-    launch_ring_auto<LAYER>(d, rows_hint, rows_typ, s);
+
+    launch_ring_auto<LAYER>(d2, rows_hint, rows_typ, s);
 }
 
 static hipEvent_t net_event(NetWorkspace* n) {

@@ -24,7 +24,8 @@ constexpr int ST_ABANDONED = ST_COUNT;      // k_harvest's 7th total: simulation
 constexpr int ST_TOTALS = ST_COUNT + 1;     // (several simulations in flight only; counted in the per-thread lines, not in TreeHead.stat)
 constexpr int MAX_SIM_THREADS = 8;
 enum ErrIdx { ERR_CAPACITY = 0, ERR_TERMINAL_ROOT = 1, ERR_PATH = 2, ERR_HASH_FULL = 3, ERR_COUNT = 4 };
-enum LeafKind { LEAF_NONE = 0, LEAF_VALUE = 1, LEAF_EVAL = 2 };
+// LEAF_ROOT: the root's own evaluation (S1 / S10: no simulation, its backup only stores the prior)
+enum LeafKind { LEAF_NONE = 0, LEAF_VALUE = 1, LEAF_EVAL = 2, LEAF_ROOT = 3 };
 
 constexpr int BLOCK_SLOTS = 8;         // slots of a child block (== Game::GROUP)
 
@@ -95,11 +96,11 @@ struct EvalBatch {
     // row's K-sum has one order), so evaluating a state once per batch -- or once per call, through the engine's evaluation
     // cache -- is bit-exact.  The per-tree analogue in the reference is `seen` (src/node.rs:282-289).
     // Election table (open addressing, linear probe): the first tree to CAS its state key in takes a row; later trees with
-    // the same key point at the winner's slot.  A slot whose epoch is not this launch's counts as empty, so the table is
-    // never cleared between launches (the host clears it when the 15-bit epoch wraps).
+    // the same key point at the winner's slot.  The launch that CONSUMES a batch (its backups read tuniq, nothing reads tkey any
+    // more) clears the batch's keys, so every launch that requests leaves finds its table empty and every launch of a search
+    // takes the same arguments -- what lets a run of simulation steps be one hipGraph.
     int32_t dedup;
-    uint32_t epoch;             // [1, 32767]
-    unsigned long long* tkey;   // [tmask+1] (epoch << 49) | state key
+    unsigned long long* tkey;   // [tmask+1] state key (never 0), 0 = empty
     uint32_t* tuniq;            // [tmask+1] row of the slot's winner
     uint32_t tmask;
 };
@@ -173,14 +174,14 @@ void launch_set_active(const TreeDev& t, uint32_t value, hipStream_t s);
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s,
                         const ulonglong2* roots = nullptr /*[G] root states, nullptr = initial board*/);
 void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, const ulonglong2* root_states, hipStream_t s);
-void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s);
+void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, hipStream_t s);
 // backup of simulation i (batch eb_prev) + select of simulation i+1 (leaf requested in eb_next) in one launch
 #ifdef AZ_DIAG
 bool tree_set_stamps(int on);                                       // diagnostic library: per-wave phase stamps of k_backup_select
 bool tree_read_stamps(unsigned long long* out /*[4096 * 8]*/);
 #endif
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
-                          int apply_only, hipStream_t s);
+                          hipStream_t s);
 // T > 1: one lock-step STEP of the tree-parallel search: the backups of the previous step's T leaves in thread order (first = 1: the
 // root's priors only), then -- unless last -- T selections in thread order, each seeing the earlier ones' visits, virtual losses and locks
 void launch_step_mt(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,

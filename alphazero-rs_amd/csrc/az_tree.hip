@@ -207,14 +207,14 @@ AZ_D uint32_t leaf_request(const EvalBatch& eb, const EvalCache& ec, bool want, 
             if (want && ways) { hit = true; take = false; src = SRC_CACHE | (bucket * 8u + (uint32_t)__ffs((int)ways) - 1u); }
         }
         if (take && sub == 0) {
-            const unsigned long long mine = key | ((unsigned long long)eb.epoch << 49);
+            const unsigned long long mine = key;                           // never 0 (Game::pack)
             uint32_t pos = pos0;
             unsigned long long cur = cur0;
             for (;; cur = eb.tkey[pos]) {
-                if ((cur >> 49) != (unsigned long long)eb.epoch) {          // empty or stale: try to take it
-                    const unsigned long long prev = atomicCAS(&eb.tkey[pos], cur, mine);
-                    if (prev == cur) break;                                // won the slot
-                    cur = prev;                                            // somebody else took it first (in this launch: epoch is current)
+                if (cur == 0ull) {                                         // empty: try to take it
+                    const unsigned long long prev = atomicCAS(&eb.tkey[pos], 0ull, mine);
+                    if (prev == 0ull) break;                               // won the slot
+                    cur = prev;                                            // somebody else took it first
                 }
                 if (cur == mine) { dup = true; break; }
                 pos = (pos + 1u) & eb.tmask;
@@ -302,7 +302,7 @@ AZ_D typename G::State root_prepare_body(const TreeDev& t, TreeHead& h, const ul
                 // terminal root: the reference panics at root.mu.p.unwrap() (src/async_mcts.rs:85)
                 if (sub == 0) atomicOr(&t.err[ERR_TERMINAL_ROOT], 1u);
             } else if (!(meta & META_HAS_PRIOR)) {
-                kind = LEAF_EVAL;  // S1 (A1): evaluate the root once so best_child has a prior
+                kind = LEAF_ROOT;  // S1 (A1): evaluate the root once so best_child has a prior (not a simulation: nothing is backed up)
             }
         }
         h.root = (root == NONE) ? 0u : root;
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(64) void k_root_prepare(TreeDev t, EvalBatch eb, Ev
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     const typename G::State s = root_prepare_body<G>(t, h, root_states, g, sub);
-    const uint32_t src = leaf_request<G>(eb, ec, h.leaf_kind == LEAF_EVAL, s, sub);
-    if (h.leaf_kind == LEAF_EVAL) h.src = src;
+    const uint32_t src = leaf_request<G>(eb, ec, h.leaf_kind == LEAF_ROOT, s, sub);
+    if (h.leaf_kind == LEAF_ROOT) h.src = src;
     if (sub == 0) head_store(t, g, h);
 }
 
@@ -522,7 +522,7 @@ AZ_D void cache_claim_finish(const EvalCache& ec, CacheClaim c, float pv, int su
 // INLINE_PV: the leaf's (pi, v) row is handed over in a register (pv_in: lane a < ACTIONS holds pi[a], lane ACTIONS holds v)
 // instead of being read through TreeHead.src -- the fused search of the fixture nets.
 template <class G, bool INLINE_PV = false>
-AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const EvalBatch& eb, const EvalCache& ec, int apply_only, int g,
+AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const EvalBatch& eb, const EvalCache& ec, int g,
                       int sub, const uint32_t* path, float pv_in = 0.0f) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
@@ -534,7 +534,8 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const 
     float pv = 0.0f;                                // lanes 0..NA-1: pi[sub], lane NA: v
     CacheClaim claim{0ull, 0ull, 0u, false};
     bool publish = false;
-    if (kind == LEAF_EVAL) {
+    const bool apply_only = kind == LEAF_ROOT;            // the root's own evaluation: store the prior, back nothing up
+    if (kind == LEAF_EVAL || kind == LEAF_ROOT) {
         uint4* lp = node_ptr(t, base, leaf);
         const NodeRec lr = node_load(lp);
         const typename G::State s = G::unpack(lr.key);
@@ -653,16 +654,23 @@ AZ_D RootPolicy root_policy(const TreeDev& t, uint32_t root, int g, int sub, flo
     return out;
 }
 
+// the batch a launch consumes gets its election table cleared (nothing reads the keys any more: the backups read tuniq)
+AZ_D void clear_election_keys(const EvalBatch& eb) {
+    if (!eb.dedup) return;
+    const uint32_t total = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= eb.tmask; i += total) eb.tkey[i] = 0ull;
+}
 template <class G>
-__global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCache ec, int apply_only) {
+__global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCache ec) {
     constexpr int GW = G::GROUP;
     const int tid = blockIdx.x * 64 + threadIdx.x;
     const int g = tid / GW, sub = tid % GW;
     if (tid == 0) { if (eb.max_n && *eb.n > *eb.max_n) *eb.max_n = *eb.n; *eb.n = 0; }   // the batch has been consumed (nothing in this kernel reads the count)
+    clear_election_keys(eb);
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     const PathRegs pth = path_load(t, g, sub);
-    backup_body<G>(t, h, pth, eb, ec, apply_only, g, sub, t.path + (size_t)g * PATH_CAP);
+    backup_body<G>(t, h, pth, eb, ec, g, sub, t.path + (size_t)g * PATH_CAP);
     h.leaf_kind = LEAF_NONE;
     if (sub == 0) head_store(t, g, h);
 }
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(64) void k_backup(TreeDev t, EvalBatch eb, EvalCach
 // zeroed by the previous launch, this one zeroes eb_prev's), so the two ping-pong.
 template <class G, bool STAMP = false>      // STAMP: diagnostic build, per-wave s_memtime stamps of the kernel's phases into dbg[wave][8]
 __global__ __launch_bounds__(256) void k_backup_select(TreeDev t, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec,
-                                                       SearchParams sp, int apply_only, unsigned long long* dbg) {
+                                                       SearchParams sp, unsigned long long* dbg) {
     constexpr int GW = G::GROUP;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;      // 64 or 256 threads (256 only when every wave of the grid holds trees)
     const int g = tid / GW, sub = tid % GW;
@@ -680,11 +688,12 @@ __global__ __launch_bounds__(256) void k_backup_select(TreeDev t, EvalBatch eb_p
 #define AZ_TSTAMP(i_) if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[i_] = __builtin_amdgcn_s_memtime(); }
     AZ_TSTAMP(0);
     if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
+    clear_election_keys(eb_prev);
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     PathRegs pth = path_load(t, g, sub);
     AZ_TSTAMP(1);
-    backup_body<G>(t, h, pth, eb_prev, ec, apply_only, g, sub, t.path + (size_t)g * PATH_CAP);
+    backup_body<G>(t, h, pth, eb_prev, ec, g, sub, t.path + (size_t)g * PATH_CAP);
     AZ_TSTAMP(2);
     // the counters this tree's other lanes just wrote are read by the selection below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -731,6 +740,7 @@ __global__ __launch_bounds__(64) void k_step_mt(TreeDev t, EvalBatch eb_prev, Ev
     const int tid = blockIdx.x * 64 + threadIdx.x;
     const int g = tid / GW, sub = tid % GW;
     if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
+    clear_election_keys(eb_prev);
     if (g >= t.G) return;
     TreeHead h = head_load(t, g);
     const ThreadRegs root_req = head_to_thread(h);          // first: k_root_prepare left the root's evaluation request in the head (S1)
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(64) void k_step_mt(TreeDev t, EvalBatch eb_prev, Ev
             pth = PathRegs{tl->path16[sub], tl->path16[8 + sub]};
         }
         thread_to_head(h, r);
-        backup_body<G>(t, h, pth, eb_prev, ec, first, g, sub, t.path + ((size_t)g * T + tt) * PATH_CAP);
+        backup_body<G>(t, h, pth, eb_prev, ec, g, sub, t.path + ((size_t)g * T + tt) * PATH_CAP);
     }
     h.leaf_kind = LEAF_NONE;
     for (int tt = 0; tt < T; ++tt) {                        // selections in thread order
@@ -811,8 +821,8 @@ __global__ __launch_bounds__(64) void k_search_fixture(TreeDev t, const ulonglon
     for (int i = 0; i <= num_sims; ++i) {
         group_memory_sync();
         // backup of the previous leaf (i == 0: the root's priors only, S1), then the next selection
-        const float pv = h.leaf_kind == LEAF_EVAL ? fixture_row<G>(ls, kind, salt, sub) : 0.0f;
-        backup_body<G, true>(t, h, pth, no_eb, no_ec, i == 0 ? 1 : 0, g, sub, t.path + (size_t)g * PATH_CAP, pv);
+        const float pv = (h.leaf_kind == LEAF_EVAL || h.leaf_kind == LEAF_ROOT) ? fixture_row<G>(ls, kind, salt, sub) : 0.0f;
+        backup_body<G, true>(t, h, pth, no_eb, no_ec, g, sub, t.path + (size_t)g * PATH_CAP, pv);
         if (i == num_sims) break;
         group_memory_sync();
         ls = select_body<G>(t, h, pth, sp, g, sub, t.path + (size_t)g * PATH_CAP);
@@ -1082,20 +1092,20 @@ void launch_reset_trees(const TreeDev& t, const uint8_t* flags, hipStream_t s, c
 void launch_root_prepare(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, const ulonglong2* root_states, hipStream_t s) {
     AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_root_prepare<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, root_states));
 }
-void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, int apply_only, hipStream_t s) {
-    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_backup<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec, apply_only));
+void launch_backup(const TreeDev& t, const EvalBatch& eb, const EvalCache& ec, hipStream_t s) {
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_backup<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, eb, ec));
 }
 void launch_backup_select(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
-                          int apply_only, hipStream_t s) {
+                          hipStream_t s) {
     const bool four = t.block4 && (t.G * 8) % 256 == 0;     // whole 4-wave workgroups: one row-counter atomic per workgroup (leaf_request)
     const dim3 grid(four ? (unsigned)(t.G * 8 / 256) : group_blocks(t.G)), block(four ? 256 : 64);
 #ifdef AZ_DIAG
     if (g_tree_dbg && t.G * 8 / 64 <= TREE_DBG_WAVES) {
-        AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, true>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, apply_only, g_tree_dbg));
+        AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, true>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, g_tree_dbg));
         return;
     }
 #endif
-    AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, false>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, apply_only, nullptr));
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL((k_backup_select<TG, false>), grid, block, 0, s, t, eb_prev, eb_next, ec, sp, nullptr));
 }
 void launch_step_mt(const TreeDev& t, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
                     int first, int last, hipStream_t s) {

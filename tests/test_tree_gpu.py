@@ -580,12 +580,12 @@ def test_dedup_counters_and_cache_corner_cases(engine, oracle, dedup_mode):
                     hits_first = st["eval_cache_hits"]
             if log2 == 10:
                 assert st["eval_cache_inserts"] <= 1024
-        # the election tables are never cleared between launches: a slot whose 15-bit epoch is stale counts as empty, and the
-        # host clears the tables when the epoch wraps (every 32767 launches: once per bench step).  Force a wrap every 37.
+        # runs of simulation steps are replayed as one hipGraph ("search_graph" steps per launch; the launch that consumes a
+        # batch clears its election table, so every step takes the same arguments): any chunking gives the same games
         engine.set_option("eval_cache_persist", 0)
-        engine.set_option("dedup_epoch_max", 37)
-        _compare_selfplay(engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=8, concurrent=48), ref)
-        engine.set_option("dedup_epoch_max", 0x7FFF)
+        for chunk in (0, 2, 6, 20):
+            engine.set_option("search_graph", chunk)
+            _compare_selfplay(engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=8, concurrent=48), ref)
         engine.set_option("eval_cache_persist", 1)
         # a new net under the same model id must not see the old net's cached rows (persist is still on)
         engine.net_set_kind(10, 1, HASH_SALT + 1)
@@ -597,7 +597,7 @@ def test_dedup_counters_and_cache_corner_cases(engine, oracle, dedup_mode):
         engine.set_option("eval_cache_log2", 27)
         engine.set_option("eval_cache_max_stones", 42)
         engine.set_option("eval_cache_persist", 0)
-        engine.set_option("dedup_epoch_max", 0x7FFF)
+        engine.set_option("search_graph", 20)
 
 
 def test_tree_arena_is_kept_across_calls(engine, oracle, dedup_mode):
