@@ -102,10 +102,43 @@ def cpu_baseline(params, channels, sims, mean_plies=None, budget_s=20.0, seed=1)
     }
 
 
+def config1_dropin(episodes=20, sims=25):
+    import subprocess
+    import tempfile
+    from alphazero_rs_amd import engine as azeng
+    libdir = os.path.dirname(azeng.LIB_PATH)
+    exe = os.path.join(tempfile.mkdtemp(prefix="az_dropin_"), "config1_dropin")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "config1_dropin.cpp"),
+                           "-o", exe, "-L", libdir, "-laz_engine", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe, str(episodes), str(sims)], check=True, stdout=subprocess.PIPE, text=True, timeout=300).stdout
+    res = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    res["host"] = "C++ host (include/az_host.hpp): Coach::execute_episode over one az_host::AsyncMcts (n_games = 1), move by move through the C ABI"
+    # the CPU side of the same shape: the oracle's execute_episode with the stub net, one thread
+    from oracle import oracle_py as orc
+    t0 = time.perf_counter()
+    r = orc.selfplay(episodes, sims, net_kind=orc.NET_STUB, seed=0, threads=1, want_samples=False)
+    dt = time.perf_counter() - t0
+    res["cpu_port_stub_net"] = {"moves_per_sec": float(r["game_len"].sum()) / dt, "episodes": episodes, "cores": 1,
+                                "note": "oracle execute_episode, stub net, one host core (examples/connect_four.rs:55-71 verbatim)"}
+    return res
+
+
 def tree_gbps(st):
     """Algorithmic tree bytes per launch (all launches) over the mean duration of the HIP-event-timed launches."""
     per_launch = st["tree_bytes"] / max(1, st["tree_launches"])
     return per_launch / (st["tree_ms"] * 1e-3 / max(1, st["tree_launches_timed"])) / 1e9
+
+
+def csrc_sha():
+    """Content hash of the kernel sources: what a committed PMC fold must have been collected at to describe THIS build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "alphazero-rs_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def committed_pmc():
@@ -116,7 +149,10 @@ def committed_pmc():
     if not files:
         return None, None
     try:
-        return json.load(open(files[-1])), os.path.basename(files[-1])
+        pmc = json.load(open(files[-1]))
+        # the fold records the source hash (and commit) it was collected at: anything else is flagged, never quoted silently
+        pmc["_stale"] = pmc.get("csrc_sha") != csrc_sha()
+        return pmc, os.path.basename(files[-1])
     except Exception:
         return None, None
 
@@ -298,7 +334,10 @@ def main():
                                    f"{args.sims} sims/move, temp_threshold 15, cpuct 1, "
                                    + (f"bf16 policy+value net C={args.channels} (random init)" if args.net == "conv" else "stub net"),
                        "concurrent_games_per_gpu": args.games, "episodes_per_gpu_per_step": episodes,
-                       "sims_per_move": args.sims, "net": args.net, "parallelism": f"games-sharded x{world}"},
+                       "sims_per_move": args.sims, "net": args.net, "parallelism": f"games-sharded x{world}",
+                       "symmetries": "identity only in the timed region (the mirrored twin of every tuple is regenerated where the tuples are consumed: "
+                                     "k_emit_samples' mirror pass is 0.004 % of device time)",
+                       "csrc_sha": csrc_sha()},
             "node_expansions_per_sec": expansions / dt, "simulations_per_sec": simulations / dt,
             "leaf_evals_per_sec": leaf_evals / dt, "mean_plies": plies_all / games,
             # leaf de-duplication (bit-exact, az_engine.h "eval_dedup"): the trees REQUEST leaf_evals rows, the net EXECUTES
@@ -326,6 +365,8 @@ def main():
                         return v["hbm_bytes_per_leaf"] * (flop_sum / st["net_launches"]) / flop_per_row, pmc_name
                 return None, None
             common = {"peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": st["net_launches"],
+                      "traffic_source": {"file": f"profiles/{pmc_name}", "csrc_sha": pmc.get("csrc_sha"), "git_sha": pmc.get("git_sha")} if pmc else None,
+                      "traffic_stale": bool(pmc["_stale"]) if pmc else None,
                       "launches_are": f"every {args.profile_every}th simulation step of the timed region (HIP events on the engine's stream)",
                       "net_forward_tflops": st["net_total_flops"] / (st["net_total_ms"] * 1e-3) / 1e12,
                       "net_forward_ms": st["net_total_ms"] / st["net_launches"]}
@@ -361,6 +402,29 @@ def main():
             roof = {"bound": "hbm", "kernel": "k_search_fixture (tree traversal: the whole search of a move in one launch; stub net evaluated in registers)", "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
         line["roofline"] = roof
+        if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:
+            # the step's kernels from the live HIP-event brackets of the timed region (the same sample of launches as `roofline`):
+            # average duration per launch, share of the bracketed step, and the fraction of the roofline that bounds each
+            L = st["net_launches"]
+            rows = st["net_rows_timed"] / L
+            tree_us = st["tree_ms"] * 1e3 / max(1, st["tree_launches_timed"])
+            us = {"conv1+conv2 (k_conv2_table_x)" if args.conv2_table else "conv2 (k_conv_same_pipe)": st["net_conv2_ms"] * 1e3 / L,
+                  "conv3": st["net_conv3_ms"] * 1e3 / L, "conv4": st["net_conv4_ms"] * 1e3 / L, "fc1+fc2+heads": st["net_fc_ms"] * 1e3 / L,
+                  "tree (k_backup_select)": tree_us}
+            step_us = st["net_total_ms"] * 1e3 / L + tree_us
+            def mf(flops, ms):
+                return flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if ms > 0 else None
+            frac = {"conv3": mf(st["net_conv3_flops"], st["net_conv3_ms"]), "conv4": mf(st["net_conv4_flops"], st["net_conv4_ms"]),
+                    "fc1+fc2+heads": mf(st["net_fc_flops"], st["net_fc_ms"]), "tree (k_backup_select)": tree_gbps(st) / HBM_PEAK_GBS}
+            if args.conv2_table:
+                frac["conv1+conv2 (k_conv2_table_x)"] = st["net_conv2_bytes"] / (st["net_conv2_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            else:
+                frac["conv2 (k_conv_same_pipe)"] = mf(st["net_conv2_flops"], st["net_conv2_ms"])
+            line["kernels"] = {"mean_rows_per_launch": rows, "step_us": step_us,
+                               "per_kernel": {k: {"avg_us": v, "share_of_step": v / step_us, "frac_of_roofline": frac.get(k),
+                                                  "bound": "hbm (cache-side bytes; > 1 = served from L2 / Infinity Cache)" if "table" in k else ("hbm" if "tree" in k else "mfma")}
+                                              for k, v in us.items()},
+                               "note": f"HIP events on the engine's stream around every {args.profile_every}th simulation step of the timed region"}
         if not args.no_profile and st["tree_ms"] > 0:
             tree_counter = None
             pmc, pmc_name = committed_pmc()
@@ -370,6 +434,7 @@ def main():
                         # counter bytes per launch of the committed PMC pass over this run's mean launch time
                         launch_s = st["tree_ms"] * 1e-3 / max(1, st["tree_launches_timed"])
                         tree_counter = {"hbm_bytes_per_launch_pmc": v["hbm_bytes_per_launch"], "source": f"profiles/{pmc_name}",
+                                        "source_csrc_sha": pmc.get("csrc_sha"), "source_git_sha": pmc.get("git_sha"), "stale": bool(pmc["_stale"]),
                                         "mean_launch_us_this_run": launch_s * 1e6,
                                         "counter_GBps": v["hbm_bytes_per_launch"] / launch_s / 1e9,
                                         "counter_over_algorithmic": v["hbm_bytes_per_launch"] / max(1.0, st["tree_bytes"] / max(1, st["tree_launches"]))}
@@ -447,14 +512,20 @@ def main():
                 line["mfma_conv2"] = {"error": repr(ex)}
             finally:
                 e.set_option("conv2_table", args.conv2_table)
-            # (b) BASELINE config 3: arena.rs head-to-head, 4096 paired games new-vs-old net, 400 sims/move, two seeded bf16 nets
+            # (b) BASELINE config 3: arena.rs head-to-head, 4096 paired games new-vs-old net, 400 sims/move, two seeded bf16 nets.
+            # On an engine of its own WITHOUT the profiling brackets: the arena is a chain of 33,600 tiny dependent steps whose pace
+            # the host's launch calls set, so its searches run as hipGraph launches -- which the brackets of profile mode preclude.
             try:
-                e.net_init_random(2, seed=args.seed + 1)
-                e.reset_stats()
+                ea = azeng.Engine(device=local_rank, max_batch=4096, net_channels=args.channels, profile=False)
+                ea.net_set_params(0, e.net_get_params(0))
+                ea.net_init_random(2, seed=args.seed + 1)
+                ea.arena(num_games=64, num_sims=50, new_model_id=2, old_model_id=0, seed=args.seed)       # warm-up: arenas, graphs
+                ea.reset_stats()
                 t1 = time.perf_counter()
-                wld, _res = e.arena(num_games=4096, num_sims=400, new_model_id=2, old_model_id=0, seed=args.seed)
+                wld, _res = ea.arena(num_games=4096, num_sims=400, new_model_id=2, old_model_id=0, seed=args.seed)
                 dta = time.perf_counter() - t1
-                sa = e.stats()
+                sa = ea.stats()
+                ea.close()
                 line["arena"] = {"games_per_sec": 4096 / dta, "seconds": dta, "games": 4096, "sims_per_move": 400, "wld_new_model": [int(x) for x in wld],
                                  "simulations_per_sec": sa["simulations"] / dta,
                                  "leaf_rows_executed_over_requested": sa["leaf_rows_executed"] / max(1, sa["leaf_rows_requested"]),
@@ -462,6 +533,13 @@ def main():
                                          "tie-break RNG does, so most leaf rows are duplicates the evaluation cache answers"}
             except Exception as ex:
                 line["arena"] = {"error": repr(ex)}
+            # (c) BASELINE config 1 as the fine-grained drop-in: one az_tree of ONE game behind az_host::AsyncMcts::get_action_prob,
+            # Coach::execute_episode move by move in the C++ host (examples/config1_dropin.cpp), 25 sims/move, stub net and conv net;
+            # beside it the oracle's AsyncMcts with the stub net on one host core (the reference's own configuration, examples/connect_four.rs:55-71)
+            try:
+                line["config1_dropin"] = config1_dropin()
+            except Exception as ex:
+                line["config1_dropin"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
     e.close()
     if use_dist:

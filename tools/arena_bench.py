@@ -4,7 +4,9 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 from alphazero_rs_amd import engine as azeng
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sims = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-e = azeng.Engine(device=0, max_batch=games, profile=True)
+e = azeng.Engine(device=0, max_batch=games, profile=bool(os.environ.get("PROFILE")))
+for kv in [x for x in os.environ.get("OPT", "").split(",") if x]:
+    e.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 e.net_init_random(0, 1)
 e.net_init_random(1, 2)
 e.arena(64, 25, new_model_id=1, old_model_id=0)        # warm-up

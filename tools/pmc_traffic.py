@@ -35,7 +35,9 @@ def main():
            "units": "FETCH_SIZE / WRITE_SIZE in KB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports "
                     "half the bytes of 16-B-per-lane streaming reads, MI355X_MICROARCH.md HBM section; WRITE_SIZE of the 8-B-per-lane "
                     "epilogue stores is uncalibrated)",
-           "avg_leaves_per_launch": per_launch_leaves, "kernels": {}}
+           "avg_leaves_per_launch": per_launch_leaves, "kernels": {},
+           # what the fold describes: bench.py flags it as stale when the kernel sources have changed since
+           "csrc_sha": line.get("config", {}).get("csrc_sha"), "git_sha": (sys.argv[5] if len(sys.argv) > 5 else None)}
     for k in fetch:
         if nf[k] == 0:
             continue
