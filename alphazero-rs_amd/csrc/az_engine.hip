@@ -306,9 +306,15 @@ struct az_tree {
     DeviceMem mem;
     int num_sims = 0, max_depth = 0, model_id = 0, cpuct = 0;
     ulonglong2* d_root_states = nullptr;
-    float* d_pi = nullptr;
-    uint16_t* d_counts = nullptr;
-    float* d_q = nullptr;
+    // pinned host block of one get_action_prob call: the roots go up from it and k_root_policy / k_call_readback write the
+    // results and counters straight into it, so a call costs one stream synchronisation instead of eight blocking copies
+    void* h_io = nullptr;
+    CallReadback* h_rb = nullptr;
+    ulonglong2* h_states = nullptr;
+    float* h_pi = nullptr;
+    float* h_q = nullptr;
+    uint16_t* h_counts = nullptr;
+    ~az_tree() { if (h_io) (void)hipHostFree(h_io); }
 };
 
 namespace {
@@ -459,6 +465,13 @@ struct ScopedEvalLog {
 };
 
 // fold the device-side de-duplication counters into the engine stats (after a stream sync)
+void fold_dedup(az_engine* e, const unsigned long long* h) {
+    e->stats.leaf_rows_requested += h[DD_REQUESTED];
+    e->stats.leaf_rows_executed += h[DD_EXECUTED];
+    e->stats.eval_cache_hits += h[DD_CACHE_HITS];
+    e->stats.eval_batch_dups += h[DD_BATCH_DUPS];
+    e->stats.eval_cache_inserts += h[DD_INSERTS];
+}
 void harvest_dedup(az_engine* e) {
     if (!e->cache.stat) return;
     unsigned long long rep[DD_REPLICAS * DD_STRIDE], h[DD_COUNT] = {};
@@ -466,11 +479,7 @@ void harvest_dedup(az_engine* e) {
     HIPCHK(hipMemset(e->cache.stat, 0, sizeof rep));
     for (int r = 0; r < DD_REPLICAS; ++r)
         for (int i = 0; i < DD_COUNT; ++i) h[i] += rep[r * DD_STRIDE + i];
-    e->stats.leaf_rows_requested += h[DD_REQUESTED];
-    e->stats.leaf_rows_executed += h[DD_EXECUTED];
-    e->stats.eval_cache_hits += h[DD_CACHE_HITS];
-    e->stats.eval_batch_dups += h[DD_BATCH_DUPS];
-    e->stats.eval_cache_inserts += h[DD_INSERTS];
+    fold_dedup(e, h);
 }
 
 // get_action_prob body shared by every entry point: S10/S1 prologue, then num_sims x
@@ -585,6 +594,7 @@ void resolve_profile(az_engine* e) {
     for (NetWorkspace* w : e->ws) netws_resolve_profile(w, &e->netprof);
 }
 
+void fold_tree_totals(az_engine* e, const unsigned long long* h, bool dedup);
 // fold the per-tree counters into the engine stats and clear them (k_harvest sums on the device)
 void harvest_stats(az_engine* e, TreeHost& th, const NetModel& net) {
     harvest_dedup(e);
@@ -594,6 +604,9 @@ void harvest_stats(az_engine* e, TreeHost& th, const NetModel& net) {
     HIPCHK(hipMemcpyAsync(h, th.d_totals, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemsetAsync(th.d_totals, 0, sizeof h, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    fold_tree_totals(e, h, dedup);
+}
+void fold_tree_totals(az_engine* e, const unsigned long long* h, bool dedup) {
     e->stats.simulations += h[ST_SIMS];
     e->stats.expansions += h[ST_EXPANSIONS];
     e->stats.leaf_evals += h[ST_LEAF_EVALS];
@@ -606,11 +619,15 @@ void harvest_stats(az_engine* e, TreeHost& th, const NetModel& net) {
     e->stats.tree_bytes += 128.0 * (double)h[ST_DEPTH_SUM] + 356.0 * (double)h[ST_SIMS];
 }
 
+az_status report_tree_errors(az_engine* e, TreeHost& th, const uint32_t* h);
 az_status check_tree_errors(az_engine* e, TreeHost& th) {
     uint32_t h[ERR_COUNT];
     HIPCHK(hipMemcpy(h, th.d.err, sizeof h, hipMemcpyDeviceToHost));
+    return report_tree_errors(e, th, h);
+}
+az_status report_tree_errors(az_engine* e, TreeHost& th, const uint32_t* h) {
     if (h[ERR_CAPACITY] || h[ERR_HASH_FULL] || h[ERR_PATH] || h[ERR_TERMINAL_ROOT])
-        HIPCHK(hipMemset(th.d.err, 0, sizeof h));
+        HIPCHK(hipMemset(th.d.err, 0, ERR_COUNT * sizeof(uint32_t)));
     if (h[ERR_CAPACITY]) return fail(e, AZ_ERR_CAPACITY, "node arena exhausted (reserve too small; src/node.rs:237)");
     if (h[ERR_HASH_FULL]) return fail(e, AZ_ERR_CAPACITY, "transposition table full");
     if (h[ERR_PATH]) return fail(e, AZ_ERR_CAPACITY, "node_path overflow");
@@ -1103,9 +1120,16 @@ az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_
         const uint64_t nodes = std::min<uint64_t>(reserve, reachable_slots(num_sims, AZ_MAX_PLIES));
         t->th.create(n_games, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(num_sims, AZ_MAX_PLIES), num_threads, e->cfg.game);
         t->d_root_states = t->mem.alloc<ulonglong2>(n_games);
-        t->d_pi = t->mem.alloc<float>((size_t)n_games * 7);
-        t->d_counts = t->mem.alloc<uint16_t>((size_t)n_games * 7);
-        t->d_q = t->mem.alloc<float>((size_t)n_games * 7);
+        {
+            const size_t G = (size_t)n_games, head = (sizeof(CallReadback) + 63) / 64 * 64;
+            HIPCHK(hipHostMalloc(&t->h_io, head + G * 16 + G * 7 * 4 * 2 + G * 7 * 2, hipHostMallocDefault));
+            char* p = (char*)t->h_io;
+            t->h_rb = (CallReadback*)p; p += head;
+            t->h_states = (ulonglong2*)p; p += G * 16;
+            t->h_pi = (float*)p; p += G * 7 * 4;
+            t->h_q = (float*)p; p += G * 7 * 4;
+            t->h_counts = (uint16_t*)p;
+        }
         launch_reset_trees(t->th.d, nullptr, e->stream);
         HIPCHK(hipStreamSynchronize(e->stream));
         *out = t.release();
@@ -1200,21 +1224,25 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
         HIPCHK(hipSetDevice(e->device));
         TreeDev& d = t->th.d;
         const int G = d.G;
-        HIPCHK(hipMemcpyAsync(t->d_root_states, states, (size_t)G * 16, hipMemcpyDefault, e->stream));
+        std::memcpy(t->h_states, states, (size_t)G * 16);
+        HIPCHK(hipMemcpyAsync(t->d_root_states, t->h_states, (size_t)G * 16, hipMemcpyHostToDevice, e->stream));
         launch_set_active(d, 1u, e->stream);
         SearchParams sp{(uint32_t)t->max_depth, (float)t->cpuct};
         prepare_cache(e, dedup_applies(e, *net), (uint64_t)G * ((uint64_t)t->num_sims + 1), e->stream);
         run_search(e, t->th, t->d_root_states, t->num_sims, sp, *net, G);
-        launch_root_policy(d, temp, seed, first_game_id, t->d_pi, t->d_counts, t->d_q, e->stream);
+        launch_root_policy(d, temp, seed, first_game_id, t->h_pi, t->h_counts, t->h_q, e->stream);
+        launch_harvest(d, t->th.d_totals, t->th.d_counts, e->stream);
+        launch_call_readback(t->th.d_totals, e->cache.stat, d.err, t->h_rb, e->stream);
         HIPCHK(hipStreamSynchronize(e->stream));
         resolve_profile(e);
-        harvest_stats(e, t->th, *net);
+        fold_dedup(e, t->h_rb->dd);
+        fold_tree_totals(e, t->h_rb->totals, dedup_applies(e, *net));
         e->stats.moves += (uint64_t)G;
-        st = check_tree_errors(e, t->th);
+        st = report_tree_errors(e, t->th, t->h_rb->err);
         if (st) return st;
-        HIPCHK(hipMemcpy(pi, t->d_pi, (size_t)G * 7 * sizeof(float), hipMemcpyDefault));
-        if (counts) HIPCHK(hipMemcpy(counts, t->d_counts, (size_t)G * 7 * sizeof(uint16_t), hipMemcpyDefault));
-        if (q) HIPCHK(hipMemcpy(q, t->d_q, (size_t)G * 7 * sizeof(float), hipMemcpyDefault));
+        std::memcpy(pi, t->h_pi, (size_t)G * 7 * sizeof(float));
+        if (counts) std::memcpy(counts, t->h_counts, (size_t)G * 7 * sizeof(uint16_t));
+        if (q) std::memcpy(q, t->h_q, (size_t)G * 7 * sizeof(float));
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }

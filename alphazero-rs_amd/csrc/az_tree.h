@@ -192,6 +192,15 @@ void launch_search_fixture(const TreeDev& t, const ulonglong2* root_states, Sear
                            hipStream_t s);
 void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t first_game_id, float* pi,
                         uint16_t* counts, float* q, hipStream_t s);
+// what one get_action_prob call hands back besides pi / counts / q: written into PINNED host memory by k_call_readback
+struct CallReadback {
+    unsigned long long totals[ST_TOTALS];
+    unsigned long long dd[DD_COUNT];
+    uint32_t err[ERR_COUNT];
+};
+// copies totals (k_harvest's sums), the de-duplication counters' replicas (summed; dd_stat may be nullptr) and the error words to
+// out and clears totals and dd_stat: one launch where the host used to issue three blocking copies and two memsets
+void launch_call_readback(unsigned long long* totals, unsigned long long* dd_stat, const uint32_t* err, CallReadback* out, hipStream_t s);
 // sums the trees' counters into totals[ST_TOTALS] (u64, accumulated) and clears them; node_counts [G] may be nullptr
 void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);

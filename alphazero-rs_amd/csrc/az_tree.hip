@@ -875,6 +875,25 @@ __global__ __launch_bounds__(256) void k_harvest(TreeDev t, unsigned long long* 
     }
 }
 
+__global__ __launch_bounds__(256) void k_call_readback(unsigned long long* totals, unsigned long long* dd_stat, const uint32_t* err,
+                                                       CallReadback* out) {
+    __shared__ unsigned long long dd[DD_COUNT];
+    const int tid = threadIdx.x;
+    if (tid < DD_COUNT) dd[tid] = 0;
+    __syncthreads();
+    if (dd_stat && tid < DD_REPLICAS) {
+#pragma unroll
+        for (int i = 0; i < DD_COUNT; ++i) {
+            const unsigned long long v = dd_stat[tid * DD_STRIDE + i];
+            if (v) { atomicAdd(&dd[i], v); dd_stat[tid * DD_STRIDE + i] = 0; }
+        }
+    }
+    __syncthreads();
+    if (tid < ST_TOTALS) { out->totals[tid] = totals[tid]; totals[tid] = 0; }
+    if (tid < DD_COUNT) out->dd[tid] = dd[tid];
+    if (tid < ERR_COUNT) out->err[tid] = err[tid];
+}
+
 // ---- Coach::execute_episode, one ply for every slot (src/coach.rs:118-156) -------------------
 template <class G>
 __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, SelfplayMoveParams mp) {
@@ -1122,6 +1141,10 @@ void launch_root_policy(const TreeDev& t, float temp, uint64_t seed, uint64_t fi
 }
 void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s) {
     hipLaunchKernelGGL(k_harvest, dim3((t.G + 255) / 256), dim3(256), 0, s, t, totals, node_counts);
+}
+void launch_call_readback(unsigned long long* totals, unsigned long long* dd_stat, const uint32_t* err, CallReadback* out, hipStream_t s) {
+    static_assert(DD_REPLICAS <= 256, "one thread per replica");
+    hipLaunchKernelGGL(k_call_readback, dim3(1), dim3(256), 0, s, totals, dd_stat, err, out);
 }
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s) {
     AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_selfplay_move<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, gd, mp));
