@@ -709,6 +709,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("conv2_table") && (value == 0 || value == 1)) { e->netopt.conv2_table = (int)value; return AZ_OK; }
     if (is("conv3_small") && (value == 0 || value == 1)) { e->netopt.conv3_small = (int)value; return AZ_OK; }
     if (is("conv3_tail") && (value == 0 || value == 1)) { e->netopt.conv3_tail = (int)value; return AZ_OK; }
+    if (is("conv3_planes") && (value == 0 || value == 1)) { e->netopt.conv3_planes = (int)value; return AZ_OK; }
     if (is("narrow_rows") && value >= 0 && value <= 65536) { e->netopt.narrow_rows = (int)value; return AZ_OK; }
     if (is("tree_block4") && (value == 0 || value == 1)) { e->tree_block4 = (int)value; return AZ_OK; }
     if (is("dedup_stats") && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }

@@ -274,6 +274,7 @@ struct GemmDesc {
     // estimate cannot tell; exactly one of them finds the batch's row count on its side of the line and runs):
     int m_min;                 // tiled kernels: do nothing when the batch has at most this many output rows (0 = always run)
     int m_max;                 // k_gemm_skinny: do nothing when the batch has more than this many output rows
+    const uint16_t* c3tab;     // conv_valid_tile<.., PLANES>: the LDS image's cell maps (Conv3Tables, built by convnet_prepare's workspace)
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -817,6 +818,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_same_pipe(const GemmDesc d) {
 // fragments are read into registers first, a barrier behind those reads frees the buffer, and the next weight tile is
 // DMA'd under the rest of the step.  A 'valid' conv needs no padding logic: output (y, x) of a board reads image row
 // (y+ky)*IW + (x+kx).  Same K order: bit-identical.
+// The PLANES layout of the conv3 LDS image (conv_valid_tile<.., true>), see Conv3Tables
+constexpr int C3_PLANE_BYTES = 32768;         // one chunk-parity plane: 512 cells of 64 B
+constexpr int C3_TAB_INV = 512;               // uint16 per LDS row cell: source image row | swizzle << 10
+constexpr int C3_TAB_RD = 9 * 2 * 16 * 8;     // uint16 per (tap, wave row, fragment row, row tile): the cell's byte offset in its plane
 constexpr int C3_NB = 12;     // (conv4 as <L, 19, 4, 5, 4> is bit-identical too and was measured neutral: it stays on k_gemm256)
 
 // ---- the same tile with the LDS-DMA issued from inline asm and a software-pipelined K-step ---------------------------
@@ -1046,12 +1051,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_valid_pipe(const GemmDesc d) {
 //                                               run alone (k_conv3_auto)
 //   (conv4 as NB 20, 4x5, MT 4, NTW 4 -- 120 of 128 rows x 128 channels, 50 + 16 KiB -- was built and measured in round 3: bit-identical and
 //    slower than the ring at every batch size, 64 against 59 us at 2300 rows, 258 against 197 at 8192: profiles/README.md; removed)
-template <int NB, int IH, int IW, int MT, int NTW>
+template <int NB, int IH, int IW, int MT, int NTW, bool PLANES = false>
 struct ConvTile {
     static constexpr int OH = IH - 2, OW = IW - 2, OUT_PER = OH * OW, IN_PER = IH * IW;
     static constexpr int OUT_ROWS = NB * OUT_PER, IMG_R = NB * IN_PER;
     static constexpr int NCOL = 32 * NTW, WROWS = 16 * MT;
-    static constexpr int IMG_BYTES = (IMG_R * 128 + 1023) / 1024 * 1024;
+    static constexpr int IMG_BYTES = PLANES ? 2 * C3_PLANE_BYTES : (IMG_R * 128 + 1023) / 1024 * 1024;
     static constexpr int LDS_BYTES = IMG_BYTES + NCOL * 128;
     static constexpr int EP_STRIDE = NCOL * 2 + 16;
     static_assert(OUT_ROWS <= 2 * WROWS && IMG_R % 8 == 0 && MT % 2 == 0, "tile");
@@ -1059,10 +1064,11 @@ struct ConvTile {
     static_assert(OUT_ROWS * EP_STRIDE <= LDS_BYTES, "the output tile must fit the dead buffers");
 };
 
-template <int NB, int IH, int IW, int MT, int NTW>
+template <int NB, int IH, int IW, int MT, int NTW, bool PLANES = false>
 __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char* smem, const int b0 /*first board*/, const int n0 /*first column*/,
                                                 const int n_boards) {
-    using T = ConvTile<NB, IH, IW, MT, NTW>;
+    using T = ConvTile<NB, IH, IW, MT, NTW, PLANES>;
+    static_assert(!PLANES || (NB == C3_NB && IH == 6 && IW == 7 && MT == 8), "the cell maps are conv3's");
     constexpr int OUT_PER = T::OUT_PER, IN_PER = T::IN_PER, OUT_ROWS = T::OUT_ROWS, IMG_R = T::IMG_R, NCOL = T::NCOL, OW = T::OW;
     constexpr int IMG_BYTES = T::IMG_BYTES;
     constexpr int IPIECES = (IMG_R + 31) / 32, WPIECES = NCOL / 32;       // 1 KiB DMA pieces per wave
@@ -1079,6 +1085,16 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
     // DMA addresses: one loop-invariant 32-bit lane offset per operand; piece q adds a uniform stride to the SGPR base.  Image rows past
     // the batch's last board are read unclamped (the workspace keeps a tile of slack; their output rows are never stored).
     const uint32_t i_ob = (uint32_t)((b0 * IN_PER + wave * 8 + lrow) * C + chunk * 8) * 2u;
+    // PLANES: LDS cell n = q * 256 + wave * 64 + lane of piece q is chunk position lane & 3 of LDS row (q & 7) * 64 + wave * 16 + (lane >> 2)
+    // in plane q >> 3; the row's source (image row, swizzle) comes from the table, the plane is the chunk's low bit (16 bytes, uniform)
+    uint32_t i_obp[8];
+    if constexpr (PLANES) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t e = d.c3tab[j * 64 + wave * 16 + (lane >> 2)];
+            i_obp[j] = (uint32_t)((b0 * IN_PER + (int)(e & 1023u)) * C + (int)((((uint32_t)lane & 3u) ^ ((e >> 10) & 3u)) << 4)) * 2u;
+        }
+    }
     const uint32_t w_ob = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;
     const uint32_t lds_img = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
     const uint32_t lds_w = (uint32_t)(uintptr_t)(lds_ptr)(smem + IMG_BYTES + wave * 1024);
@@ -1091,9 +1107,13 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
 #define AZ_TDMA_IMG(cb_)                                                                                     \
     {                                                                                                        \
         const char* ibase = (const char*)(d.A + (cb_) * 64);                                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < IPIECES; ++q_)                                               \
-            if ((q_ * 4 + 3) * 8 + 7 < IMG_R || (q_ * 4 + wave) * 8 + 7 < IMG_R)                             \
-                lds_dma16(ibase + q_ * i_stride, i_ob, lds_img + q_ * 4096);                                 \
+        if constexpr (PLANES) {                                                                              \
+            _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) lds_dma16(ibase + (q_ >> 3) * 16, i_obp[q_ & 7], lds_img + q_ * 4096); \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int q_ = 0; q_ < IPIECES; ++q_)                                           \
+                if ((q_ * 4 + 3) * 8 + 7 < IMG_R || (q_ * 4 + wave) * 8 + 7 < IMG_R)                         \
+                    lds_dma16(ibase + q_ * i_stride, i_ob, lds_img + q_ * 4096);                             \
+        }                                                                                                    \
     }
     f32x4 acc[MT][NTW];
 #pragma unroll
@@ -1111,10 +1131,21 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
     }
     const int b_row0 = IMG_BYTES + (wc * (16 * NTW) + frow) * 128;
     const int coffB0 = ((0 + fq) ^ fsw) << 4, coffB1 = ((4 + fq) ^ fsw) << 4;
-#define AZ_TLDA(dst_, mt0_, ks_, dt_)                                                                        \
+    // PLANES: the 8 row tiles' cells of one tap are one 16-byte table entry per lane (tq: this step's tap, ntq: the next step's, loaded a
+    // step ahead); chunk c = ks * 4 + fq of a cell: plane c & 1, position (c >> 1) ^ swizzle (the swizzle is folded into the table value)
+    const uint4* rdtab = (const uint4*)(d.c3tab + C3_TAB_INV) + (wr * 16 + frow);
+    const uint32_t lane_x = (((uint32_t)fq & 1u) << 15) | (((uint32_t)fq >> 1) << 4);
+    uint32_t tq[4] = {0, 0, 0, 0}, ntq[4] = {0, 0, 0, 0};
+    if constexpr (PLANES) { const uint4 v = rdtab[0]; tq[0] = v.x; tq[1] = v.y; tq[2] = v.z; tq[3] = v.w; }
+#define AZ_TCELL(q_, mt_) ((((mt_) & 1) ? q_[(mt_) >> 1] >> 16 : q_[(mt_) >> 1] & 0xFFFFu) ^ lane_x)
+#define AZ_TLDA(dst_, mt0_, ks_, dt_, q_)                                                                    \
     _Pragma("unroll") for (int i_ = 0; i_ < MH; ++i_) {                                                      \
-        const int r_ = rbase[(mt0_) + i_] + (dt_);                                                           \
-        dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));                 \
+        if constexpr (PLANES) {                                                                              \
+            dst_[i_] = *(const bf16x8*)(smem + (AZ_TCELL(q_, (mt0_) + i_) ^ ((ks_) << 5)));                  \
+        } else {                                                                                             \
+            const int r_ = rbase[(mt0_) + i_] + (dt_);                                                       \
+            dst_[i_] = *(const bf16x8*)(smem + r_ * 128 + ((((ks_) * 4 + fq) ^ (r_ & 7)) << 4));             \
+        }                                                                                                    \
     }
 #define AZ_TLDB(dst_, coff_)                                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < NTW; ++i_)                                                       \
@@ -1141,7 +1172,7 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
     __syncthreads();
     bf16x8 fbX[NTW], fbY[NTW], faX[MH], faY[MH];
     AZ_TLDB(fbX, coffB0);
-    AZ_TLDA(faX, 0, 0, 0);
+    AZ_TLDA(faX, 0, 0, 0, tq);
     const int ncb = C / 64;
     const int nk = ncb * 9;
     int cb = 0, tap = 0, dt = 0;
@@ -1150,8 +1181,9 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
         const int ntap = sw ? 0 : tap + 1, ncbi = sw ? cb + 1 : cb;
         const int nky = ntap / 3, ndt = nky * IW + (ntap - nky * 3);
         const int kk = kt + 1 < nk ? ntap * C + ncbi * 64 : 8 * C + cb * 64;      // last step: re-fetch its own tile (unused)
+        if constexpr (PLANES) { const uint4 v = rdtab[ntap * 32]; ntq[0] = v.x; ntq[1] = v.y; ntq[2] = v.z; ntq[3] = v.w; }
         AZ_TLDB(fbY, coffB1);
-        AZ_TLDA(faY, MH, 0, dt);
+        AZ_TLDA(faY, MH, 0, dt, tq);
         AZ_TMMA(0, fbX, faX);
         AZ_TMIX(NTW + MH);
         AZ_TSB;
@@ -1159,11 +1191,11 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
         __builtin_amdgcn_s_barrier();
         AZ_TSB;
         AZ_TDMA_W(kk);
-        AZ_TLDA(faX, 0, 1, dt);
+        AZ_TLDA(faX, 0, 1, dt, tq);
         AZ_TMMA(MH, fbX, faY);
         AZ_TMIX(MH);
         AZ_TSB;
-        AZ_TLDA(faY, MH, 1, dt);
+        AZ_TLDA(faY, MH, 1, dt, tq);
         AZ_TMMA(0, fbY, faX);
         AZ_TMIX(MH);
         AZ_TSB;
@@ -1178,15 +1210,17 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
         }
         AZ_TSB;
         AZ_TLDB(fbX, coffB0);                                    // next step's first fragments, under this step's last cluster
-        AZ_TLDA(faX, 0, 0, ndt);
+        AZ_TLDA(faX, 0, 0, ndt, ntq);
         AZ_TMMA(MH, fbY, faY);
         AZ_TMIX(NTW + MH);
         AZ_TSB;
         tap = ntap; cb = ncbi; dt = ndt;
+        if constexpr (PLANES) { tq[0] = ntq[0]; tq[1] = ntq[1]; tq[2] = ntq[2]; tq[3] = ntq[3]; }
     }
 #undef AZ_TDMA_W
 #undef AZ_TDMA_IMG
 #undef AZ_TLDA
+#undef AZ_TCELL
 #undef AZ_TLDB
 #undef AZ_TMMA
 #undef AZ_TSB
@@ -1235,9 +1269,9 @@ __device__ __forceinline__ void conv_valid_tile(const GemmDesc& d, unsigned char
 // and is slower than the uncut round (2300 rows: 160 -> 170 us) -- a workgroup alone on its CU is not the 76-us level round 2's notes
 // priced it at, so those rounds stay uncut.
 constexpr int C3_TAIL = 128;
-template <int LAYER>
-__global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const int full_grid) {
-    using TF = ConvTile<C3_NB, 6, 7, 8, 4>;
+template <int LAYER, bool PLANES>
+__global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const int full_grid, const int tail_wgs /* C3_TAIL, or 0: no tile is cut */) {
+    using TF = ConvTile<C3_NB, 6, 7, 8, 4, PLANES>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TF::LDS_BYTES];
     const int n_boards = (int)(*d.n_dev);
     if (n_boards * d.rows_per_sample <= d.m_min) return;      // the small-batch kernel launched beside this one takes the batch
@@ -1245,7 +1279,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const i
     const int tiles8 = ((n_boards + C3_NB - 1) / C3_NB + 7) / 8 * 8;
     const int wid = tiles8 * NT;                       // workgroup ids that map to a tile of this batch (the last group of 8 row tiles may be partly empty)
     const int full_rounds = wid / 512 * 512, rem = wid - full_rounds;
-    const bool cut = rem > 0 && rem <= C3_TAIL;        // the last round would run one workgroup per CU
+    const bool cut = rem > 0 && rem <= tail_wgs;       // the last round would run one workgroup per CU
     int id = blockIdx.x, half = -1;
     if (id >= full_grid) {                             // an extra workgroup: the second half of a cut tile
         if (!cut || id - full_grid >= rem) return;
@@ -1258,8 +1292,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const i
     const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
     const int b0 = mtile * C3_NB, n0 = ntile * 128;
     if (b0 >= n_boards) return;
-    if (half < 0) conv_valid_tile<C3_NB, 6, 7, 8, 4>(d, smem, b0, n0, n_boards);
-    else conv_valid_tile<C3_NB, 6, 7, 8, 2>(d, smem, b0, n0 + half * 64, n_boards);
+    if (half < 0) conv_valid_tile<C3_NB, 6, 7, 8, 4, PLANES>(d, smem, b0, n0, n_boards);
+    else conv_valid_tile<C3_NB, 6, 7, 8, 2, PLANES>(d, smem, b0, n0 + half * 64, n_boards);
 }
 
 // ---- SKINNY GEMM for small batches: operands straight into registers, no LDS, no barrier ---------------------------------------------
@@ -1446,6 +1480,51 @@ struct ConvNet {                      // the WEIGHTS of one model id (21 MB bf16
     }
 };
 
+// ---- Conv3Tables: the bank-conflict-free ("PLANES") layout of conv3's LDS image ---------------------------------------------------------
+// An A fragment of the image-resident conv3 is 16 CONSECUTIVE OUTPUT positions of a tap: output (y, x) of a 4 x 5 board reads image row
+// 7 (y + ky) + (x + kx) of its 6 x 7 board, so the 16 rows of a fragment skip two image rows after every five.  With the image rows in
+// order at 128 bytes each and the usual chunk ^ (row & 7) swizzle, a ds_read_b128 lane group (16 lanes: MI355X_MICROARCH.md, LDS) finds
+// rows r and r + 8 on the same 16-byte bank slot: 1.94 LDS cycles per group instead of 1 on average over the taps and tiles, the 38 % of
+// LDS cycles round 2's SQ_LDS_BANK_CONFLICT counter showed; no swizzle of whole 128-byte rows avoids it for all nine taps (a lane group
+// mixes two k chunks, and the row set moves by one slot from tap to tap).  The layout here gives every image row the LABEL
+// o' = 20 board + 5 y' + x' (mod 16) -- the output index a position would have, so the 16 rows of any fragment of any tap carry 16
+// consecutive labels -- and places the row where its slot IS its label:
+//   * two PLANES by the parity of the 16-byte k chunk (the two chunks a lane group mixes differ in exactly that bit; a plane is 32 KiB,
+//     a multiple of the 256-byte bank row, so both land on the same slots);
+//   * in a plane a row is one 64-byte cell (4 chunks); cell index rho = 4 m + (label >> 2), chunk position = pair index ^ (label & 3):
+//     slot = (rho & 3) * 4 + position = the label, XORed with a constant of the instruction.  16 distinct labels = 16 distinct slots.
+//   * m numbers the rows of a label class in image order: 126 rows per class, 504 of the 512 cells used -- 64 KiB, which with the
+//     16 KiB weight buffer is exactly half of a CU's LDS (two workgroups per CU, as before).
+// No closed form is needed on the device: the DMA side reads inv[rho] = (image row, label & 3) once per kernel (8 rows per lane), the
+// fragment side streams rd[tap][wave row][fragment row][row tile] = the cell's byte offset, one 16-byte entry per lane and K-step,
+// fetched a step ahead.  The global side of the DMA reads 64 contiguous bytes per image row and instruction instead of 128.
+static std::vector<uint16_t> conv3_tables() {
+    constexpr int NB = C3_NB, IH = 6, IW = 7, OW = 5, OUT_PER = 20, IN_PER = 42;
+    std::vector<uint16_t> t((size_t)C3_TAB_INV + C3_TAB_RD, 0);
+    int next_m[4] = {0, 0, 0, 0};
+    std::vector<int> cell(NB * IN_PER, 0);            // rho * 64 + (label & 3) * 16 per image row
+    for (int bl = 0; bl < NB; ++bl)
+        for (int y = 0; y < IH; ++y)
+            for (int x = 0; x < IW; ++x) {
+                const int label = (OUT_PER * bl + OW * y + x) & 15, cls = label >> 2, h2 = label & 3;
+                const int rho = 4 * next_m[cls]++ + cls;
+                if (rho >= C3_TAB_INV) return {};
+                const int r = bl * IN_PER + y * IW + x;
+                t[rho] = (uint16_t)(r | (h2 << 10));
+                cell[r] = rho * 64 + h2 * 16;
+            }
+    for (int tap = 0; tap < 9; ++tap)
+        for (int wr = 0; wr < 2; ++wr)
+            for (int frow = 0; frow < 16; ++frow)
+                for (int mt = 0; mt < 8; ++mt) {
+                    int ml = wr * 128 + mt * 16 + frow;
+                    if (ml >= NB * OUT_PER) ml = 0;           // rows past the tile: any valid cell (never stored)
+                    const int bl = ml / OUT_PER, p = ml % OUT_PER, y = p / OW + tap / 3, x = p % OW + tap % 3;
+                    t[(size_t)C3_TAB_INV + ((tap * 2 + wr) * 16 + frow) * 8 + mt] = (uint16_t)cell[bl * IN_PER + y * IW + x];
+                }
+    return t;
+}
+
 // Activation workspace of ONE stream (1.2 GB at 8192 rows, C = 512), shared by every model that runs on that stream:
 // model ids come and go with the Coach loop (src/coach.rs:296-390), the workspace does not grow with them.
 struct NetWorkspace {
@@ -1460,6 +1539,7 @@ struct NetWorkspace {
     uint32_t* d_nlog = nullptr;            // [pinned_cap] row count of every timed forward, written by its k_heads
     int pinned_cap = 0, pinned_next = 0;
     unsigned long long* dbg = nullptr;     // [2048] clock stamps of the diagnostic variant
+    uint16_t* c3tab = nullptr;             // Conv3Tables (the PLANES layout of conv3's LDS image)
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr;
         if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
@@ -1520,6 +1600,11 @@ NetWorkspace* netws_create(int channels, int max_batch, const char** err) {
     ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
     ok &= (n->dbg = n->dalloc<unsigned long long>(2048)) != nullptr;
     if (ok) ok = hipMemset(n->dbg, 0, 2048 * 8) == hipSuccess;
+    ok &= (n->c3tab = n->dalloc<uint16_t>(C3_TAB_INV + C3_TAB_RD)) != nullptr;
+    if (ok) {
+        const std::vector<uint16_t> tab = conv3_tables();
+        ok = !tab.empty() && hipMemcpy(n->c3tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok) ok = hipHostMalloc((void**)&n->pinned_n, 4096 * sizeof(uint32_t)) == hipSuccess;
     ok &= (n->d_nlog = n->dalloc<uint32_t>(4096)) != nullptr;
     n->pinned_cap = 4096;
@@ -1683,11 +1768,12 @@ static void launch_conv2_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     const int t8 = (tiles + 7) / 8 * 8;
     hipLaunchKernelGGL((k_conv_same_pipe<1, TABLE>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
 }
-static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s, bool tail) {
+static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s, bool tail, bool planes) {
     const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
     const int t8 = (tiles + 7) / 8 * 8;
     const int full_grid = t8 * (d.N / 128);
-    if (tail) hipLaunchKernelGGL((k_conv3_auto<2>), dim3(full_grid + C3_TAIL), dim3(256), 0, s, d, full_grid);
+    if (planes) hipLaunchKernelGGL((k_conv3_auto<2, true>), dim3(full_grid + (tail ? C3_TAIL : 0)), dim3(256), 0, s, d, full_grid, tail ? C3_TAIL : 0);
+    else if (tail) hipLaunchKernelGGL((k_conv3_auto<2, false>), dim3(full_grid + C3_TAIL), dim3(256), 0, s, d, full_grid, C3_TAIL);
     else hipLaunchKernelGGL((k_conv_valid_pipe<2, C3_NB, 6, 7, false, 0, true>), dim3(full_grid), dim3(256), 0, s, d);
 }
 
@@ -1845,7 +1931,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     }
     if constexpr (LAYER == 2) {
         if (o.conv3_small && conv3_is_small(d2, rows_hint, rows_typ)) launch_ring_auto<LAYER>(d2, rows_hint, rows_typ, s, true);
-        else launch_conv3_image(d2, rows_hint, s, o.conv3_tail != 0);
+        else launch_conv3_image(d2, rows_hint, s, o.conv3_tail != 0, o.conv3_planes != 0);
         return;
     }
 
@@ -1934,6 +2020,7 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.n_dev = eb.n;
     d.relu = 1;
     d.dbg = ws->dbg;
+    d.c3tab = ws->c3tab;
     // conv2: 3x3 same over the haloed [8][9][C] image (or the conv1 table) -> [6][7][C]
     d.A = table ? n->t1 : ws->act1; d.states = table ? eb.state : nullptr;
     d.W = n->wg[0]; d.bias = n->bg[0]; d.out = ws->act2;

@@ -372,7 +372,7 @@ def test_bench_scale_replay_parity_with_the_conv_net(engine, oracle):
 def test_shipped_kernel_choices_are_bit_identical(engine, oracle):
     """The shipped library's own kernel choices -- conv3 with / without the half-tile tail (k_conv3_auto cuts the tiles of a short last
     round in two along the channels), conv3 / conv4 / fc1 / fc2 as the register-fed skinny GEMM (k_gemm_skinny; forced at every size here), conv3 of a
-    small batch on the ring -- accumulate every output's K terms in the same order: identical bits at row counts that hit every role
+    small batch on the ring, conv3's LDS image in the bank-conflict-free PLANES layout or with its rows in order -- accumulate every output's K terms in the same order: identical bits at row counts that hit every role
     (no cut, a cut last round, a cut only round, ragged tiles, one row), for both conv2 kernel sets."""
     engine.net_init_random(26, seed=17)
     states = random_states(oracle, 8192, seed=123)
@@ -380,17 +380,18 @@ def test_shipped_kernel_choices_are_bit_identical(engine, oracle):
         for table in (1, 0):
             engine.set_option("conv2_table", table)
             for n in (8192, 5003, 3100, 2304, 1537, 771, 357, 300, 129, 64, 33, 13, 1):
-                for key in ("conv3_tail", "narrow_rows", "conv3_small"):
+                for key in ("conv3_tail", "narrow_rows", "conv3_small", "conv3_planes"):
                     engine.set_option(key, 0)
                 ref = engine.predict_states(states[:n], 26)
-                for t3, nr, s3 in ((1, 0, 0), (0, 8192, 0), (1, 32, 1), (0, 100, 1), (1, 16, 0)):
+                for t3, nr, s3, pl in ((1, 0, 0, 0), (0, 8192, 0, 0), (1, 32, 1, 0), (0, 100, 1, 1), (1, 16, 0, 1), (0, 0, 0, 1), (1, 0, 0, 1)):
                     engine.set_option("conv3_tail", t3)
                     engine.set_option("narrow_rows", nr)
                     engine.set_option("conv3_small", s3)
+                    engine.set_option("conv3_planes", pl)
                     got = engine.predict_states(states[:n], 26)
-                    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (table, n, t3, nr, s3)
+                    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (table, n, t3, nr, s3, pl)
     finally:
-        for key, val in (("conv2_table", 1), ("conv3_tail", 1), ("narrow_rows", 32), ("conv3_small", 1)):
+        for key, val in (("conv2_table", 1), ("conv3_tail", 1), ("narrow_rows", 32), ("conv3_small", 1), ("conv3_planes", 1)):
             engine.set_option(key, val)
 
 
