@@ -1518,7 +1518,7 @@ static std::vector<uint16_t> conv3_tables() {
             for (int frow = 0; frow < 16; ++frow)
                 for (int mt = 0; mt < 8; ++mt) {
                     int ml = wr * 128 + mt * 16 + frow;
-                    if (ml >= NB * OUT_PER) ml = 0;           // rows past the tile: any valid cell (never stored)
+                    if (ml >= NB * OUT_PER) ml = frow;        // rows past the tile (never stored): 16 distinct valid cells, conflict-free too
                     const int bl = ml / OUT_PER, p = ml % OUT_PER, y = p / OW + tap / 3, x = p % OW + tap % 3;
                     t[(size_t)C3_TAB_INV + ((tap * 2 + wr) * 16 + frow) * 8 + mt] = (uint16_t)cell[bl * IN_PER + y * IW + x];
                 }

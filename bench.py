@@ -373,9 +373,12 @@ def main():
             if args.conv2_table:
                 # conv2 is a table gather now; the dominant kernel (and the dominant MFMA kernel) is conv3
                 ach = st["net_conv3_flops"] / (st["net_conv3_ms"] * 1e-3) / 1e12
-                traffic, src = pmc_traffic("k_conv_valid_", st["net_conv3_flops"], 2.0 * 20 * 512 * 4608)
-                roof = {"bound": "mfma", "kernel": "k_conv_valid_pipe<2, 12, 6, 7> (conv3: 3x3 valid, 512->512, image-resident implicit GEMM on MFMA, 12 boards x 128 "
-                                                   "channels per tile, two 4-wave workgroups per CU, asm-issued LDS-DMA, fragment reads interleaved into the MFMA clusters)",
+                traffic, src = pmc_traffic("k_conv3_auto", st["net_conv3_flops"], 2.0 * 20 * 512 * 4608)
+                if traffic is None:
+                    traffic, src = pmc_traffic("k_conv_valid_", st["net_conv3_flops"], 2.0 * 20 * 512 * 4608)      # folds older than round 3
+                roof = {"bound": "mfma", "kernel": "k_conv3_auto<2, true> (conv3: 3x3 valid, 512->512, image-resident implicit GEMM on MFMA, 12 boards x 128 channels per tile "
+                                                   "(x 64 in a short last round), two 4-wave workgroups per CU, asm-issued LDS-DMA into a bank-conflict-free LDS image, "
+                                                   "fragment reads interleaved into the MFMA clusters; small batches run k_gemm_skinny / the ring instead)",
                         "achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{src}: bytes per executed row x "
                                         "this run's mean rows per launch)",

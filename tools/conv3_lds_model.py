@@ -24,7 +24,7 @@ def planes_cells():
     return cell
 
 
-def cost(addr_of):
+def cost(addr_of, planes):
     tot = n = 0
     for wr in (0, 1):
         for mt in range(8):
@@ -36,7 +36,7 @@ def cost(addr_of):
                             frow, fq = l & 15, l >> 4
                             ml = wr * 128 + mt * 16 + frow
                             if ml >= NB * OUT_PER:
-                                ml = 0
+                                ml = frow if planes else 0
                             bl, p = divmod(ml, OUT_PER)
                             r = bl * IN_PER + (p // OW + tap // 3) * IW + p % OW + tap % 3
                             a = addr_of(r, ks * 4 + fq)
@@ -48,8 +48,8 @@ def cost(addr_of):
 
 if __name__ == "__main__":
     cells = planes_cells()
-    a_rows = cost(lambda r, c: r * 128 + ((c ^ (r & 7)) << 4))
-    a_planes = cost(lambda r, c: (c & 1) * 32768 + cells[r][0] * 64 + (((c >> 1) ^ cells[r][1]) << 4))
+    a_rows = cost(lambda r, c: r * 128 + ((c ^ (r & 7)) << 4), False)
+    a_planes = cost(lambda r, c: (c & 1) * 32768 + cells[r][0] * 64 + (((c >> 1) ^ cells[r][1]) << 4), True)
     for name, a in (("rows", a_rows), ("planes", a_planes)):
         total = 16 * a + 8 * 1.0            # per K-step and wave: 16 A reads, 8 weight reads (conflict-free in both layouts)
         print(f"{name:7s} A fragment: {a:.3f} LDS cycles per lane group; conflict share of the K-step's LDS cycles {1 - 24 / total:.3f}")
