@@ -162,6 +162,200 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, i
     }
 }
 
+
+// ===================================================================================================================
+// bf16 x 3: the f32 GEMMs of a step on the bf16 matrix cores ("train_gemm" = 1, the default)
+// ===================================================================================================================
+// v_mfma_f32_16x16x4_f32 peaks at 157 TFLOP/s and the register-staged kernel above reaches about half of it (its tiles come in through
+// the ~10 B/clk/CU register-load path): 0.85 of the 1.58 ms step.  The bf16 matrix cores are 16 times faster per product, so every f32
+// operand x is split into two bf16 numbers, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo up to 2^-17 |x|), and
+//     A W  ~=  A_hi W_hi + A_hi W_lo + A_lo W_hi            (the dropped A_lo W_lo term is 2^-16 of a product)
+// is ONE bf16 GEMM over a contraction three times as long -- segments (A_hi, W_hi), (A_hi, W_lo), (A_lo, W_hi) -- accumulated in f32 by
+// the MFMA.  k_gemm3 is the inference side's LDS-DMA ring (az_net.hip gemm_ring_body: asm-issued global_load_lds_dwordx4 into an XOR-
+// swizzled image, two stages, one raw barrier per 64-deep K-step, both 32-deep halves' fragments requested up front) with a plain
+// row-major A, the segment walker, split-K over blockIdx.y and an f32 epilogue; k_splitk_reduce sums the slices in slice order, so a
+// step stays deterministic.  Both operands must be contiguous along the contraction:
+//     dgrad     dA = dz W^T    dz [M][N] (written split by k_bn_bwd_apply), W [K][N] as stored (k_split_weights)
+//     wgrad     dW = A^T dz    A^T [K][M'] and dz^T [N][M'] (k_transpose_split: f32 in, hi / lo out; M' = M rounded up to 64, zero-filled)
+// THE FORWARD GEMMS STAY ON THE f32 KERNEL: a 2^-17 error in a pre-activation flips the ReLU (and the dropout-free BatchNorm sign) of the
+// elements that lie that close to zero -- about one of fc2's 32 k activations per step and a few dozen per conv layer -- and ONE flip in an
+// FC layer moves every upstream gradient tensor by ~3e-4 (tools/train_check.py: the forward as bf16 x 3 measured 3e-3 against float64
+// autograd at batch 64, the f32 forward 1e-6).  The backward pass has no such discontinuity: its GEMMs' 1e-5 stays 1e-5.
+// conv1 (K = 18) stays on the f32 kernel too.  Measured error of a step's gradients against float64 autograd: DESIGN.md section 8.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+AZ_D uint16_t bf16_rne(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+AZ_D float bf16_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+AZ_D void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - bf16_f32(hi));
+}
+AZ_D void split4(const float4 v, uint2& hi, uint2& lo) {
+    uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+    split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+    hi = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+    lo = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+}
+
+// LDS-DMA from inline asm (az_net.hip lds_dma16: the compiler must not see the access, or every wait it inserts becomes vmcnt(0))
+AZ_D void train_dma16(const void* sbase /*uniform*/, uint32_t voff, uint32_t lds_addr /*uniform*/) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+struct Gemm3 {
+    const uint16_t *a_hi, *a_lo;    // [M][lda] bf16, contiguous along the contraction
+    const uint16_t *w_hi, *w_lo;    // [N][ldw] bf16, contiguous along the contraction
+    float* out;                     // splits == 1: [M][ldo] (+ bias); else partial sums [splits][M][N]
+    const float* bias;
+    int M, N, Kc;                   // Kc % 64 == 0, N % 128 == 0
+    int lda, ldw, ldo;
+    int steps_per_split;            // 64-deep K-steps of the 3 * Kc / 64 per blockIdx.y
+    int splits;
+};
+
+constexpr int G3_BM = 128, G3_STAGE = G3_BM * 128 + 16384;
+
+__global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G3_STAGE];
+    constexpr int MT = G3_BM / 32, NDMA = MT + 4;
+    const int NT = g.N / 128;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int m0 = mtile * G3_BM, n0 = ntile * 128;
+    if (m0 >= g.M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+    uint32_t a_ob[MT];
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+        int m = m0 + (q * 4 + wave) * 8 + lrow;
+        m = m < g.M ? m : g.M - 1;
+        a_ob[q] = (uint32_t)(m * g.lda + chunk * 8) * 2u;
+    }
+    const uint32_t b_ob = (uint32_t)((n0 + wave * 8 + lrow) * g.ldw + chunk * 8) * 2u;
+    const size_t w_stride = (size_t)64 * g.ldw;           // 32 rows, in bytes
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
+    // K-step walker over the three segments (scalars only)
+    const int spk = g.Kc / 64;                            // steps per segment
+    const int t0 = blockIdx.y * g.steps_per_split;
+    const int t1 = min(3 * spk, t0 + g.steps_per_split);
+    const int nk = t1 - t0;
+    int seg = t0 / spk, kin = t0 - seg * spk;
+#define AZ_G3DMA(buf_)                                                                                  \
+    {                                                                                                   \
+        const char* abase = (const char*)((seg == 2 ? g.a_lo : g.a_hi) + kin * 64);                     \
+        const char* wbase = (const char*)((seg == 1 ? g.w_lo : g.w_hi) + kin * 64);                     \
+        const uint32_t la = lds0 + (buf_) * G3_STAGE;                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < MT; ++q_) train_dma16(abase, a_ob[q_], la + q_ * 4096); \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) train_dma16(wbase + q_ * w_stride, b_ob, la + G3_BM * 128 + q_ * 4096); \
+        if (++kin == spk) { kin = 0; ++seg; }                                                           \
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    if (nk > 0) AZ_G3DMA(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stage kt has landed (the only one in flight)
+        __builtin_amdgcn_s_barrier();                        // ... for every wave, and every wave is done with stage kt-1's buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) AZ_G3DMA((kt + 1) & 1);
+        const unsigned char* sA = smem + (kt & 1) * G3_STAGE;
+        const unsigned char* sB = sA + G3_BM * 128;
+        const int coff0 = ((0 + fq) ^ fsw) << 4, coff1 = ((4 + fq) ^ fsw) << 4;
+        bf16x8_t fa0[MT], fb0[4], fa1[MT], fb1[4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa0[mt] = *(const bf16x8_t*)(sA + (wr * (G3_BM / 2) + mt * 16 + frow) * 128 + coff0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) fb0[nt] = *(const bf16x8_t*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa1[mt] = *(const bf16x8_t*)(sA + (wr * (G3_BM / 2) + mt * 16 + frow) * 128 + coff1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) fb1[nt] = *(const bf16x8_t*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nt], fa0[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt], fa1[mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + 4, 0);
+#pragma unroll
+        for (int gi = 0; gi < MT + 4; ++gi) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MT - (MT + 4), 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef AZ_G3DMA
+    (void)NDMA;
+    // f32 epilogue: a lane holds 4 consecutive columns of one row
+    float* obase = g.splits > 1 ? g.out + (size_t)blockIdx.y * g.M * g.N : g.out;
+    const int ldo = g.splits > 1 ? g.N : g.ldo;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias && g.splits == 1) bv = *(const float4*)(g.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wr * (G3_BM / 2) + mt * 16 + frow;
+            if (m >= g.M) continue;
+            *(float4*)(obase + (size_t)m * ldo + n) =
+                make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+        }
+    }
+}
+
+// every weight matrix W [K][N] f32 -> hi / lo bf16 as stored (the dgrad operand), at the matrix's own offset of flat buffers the size of
+// the parameter vector.  blockIdx.y = matrix.
+struct SplitWeights {
+    int64_t off[5], count[5];
+};
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ P, const SplitWeights sw, uint16_t* __restrict__ w_hi,
+                                                       uint16_t* __restrict__ w_lo) {
+    const int mi = blockIdx.y;
+    const int64_t n4 = sw.count[mi] / 4, base = sw.off[mi];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        uint2 hi, lo;
+        split4(*(const float4*)(P + base + i * 4), hi, lo);
+        *(uint2*)(w_hi + base + i * 4) = hi;
+        *(uint2*)(w_lo + base + i * 4) = lo;
+    }
+}
+
+// in [R][C] f32 (row stride ld) -> out hi / lo [C][Rp] bf16, rows R .. Rp-1 of the source taken as zero; 64 x 64 tiles
+__global__ __launch_bounds__(256) void k_transpose_split(const float* __restrict__ in, int R, int C, int64_t ld, uint16_t* __restrict__ out_hi,
+                                                         uint16_t* __restrict__ out_lo, int Rp) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty + 4 * i;
+        tile[r][tx] = (r0 + r < R && c0 + tx < C) ? in[(size_t)(r0 + r) * ld + c0 + tx] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = ty + 4 * i;
+        if (c0 + c < C && r0 + tx < Rp) {
+            uint16_t hi, lo;
+            split_bf16(tile[tx][c], hi, lo);
+            out_hi[(size_t)(c0 + c) * Rp + r0 + tx] = hi;
+            out_lo[(size_t)(c0 + c) * Rp + r0 + tx] = lo;
+        }
+    }
+}
+
 // what changes from step to step lives in device memory, so the launch sequence of a step is the same every time
 struct StepState {
     uint64_t mask_seed;     // keys the dropout masks of this step
@@ -266,6 +460,7 @@ struct BnLayer {
     uint32_t drop_layer;    // dropout stream id; keep_thresh = 0 -> no dropout
     uint32_t keep_thresh;
     float drop_scale;
+    uint16_t *out_hi, *out_lo;   // k_bn_bwd_apply, not nullptr: dz also as hi / lo bf16 (the dgrad operand), same [M][N] layout
 };
 
 
@@ -369,7 +564,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnLayer L, const dou
     for (int r = r0 + ty; r < r1; r += 4) {
         float xh;
         const float g = bn_grad_in(L, mask_seed, r, c, mean, invstd, gamma, beta, xh);
-        L.out[(size_t)r * L.N + c] = gamma * invstd * (g - (db + xh * dg) * inv_m);
+        const float dzv = gamma * invstd * (g - (db + xh * dg) * inv_m);
+        L.out[(size_t)r * L.N + c] = dzv;
+        if (L.out_hi) { uint16_t hi, lo; split_bf16(dzv, hi, lo); L.out_hi[(size_t)r * L.N + c] = hi; L.out_lo[(size_t)r * L.N + c] = lo; }
     }
 }
 
@@ -476,6 +673,10 @@ struct Trainer {
     float *sums = nullptr, *dhead = nullptr, *sample_loss = nullptr, *logits = nullptr;
     double *partial = nullptr, *loss_totals = nullptr;
     float* splitk = nullptr;           // partial sums of the split-K GEMMs
+    // bf16 x 3 operands of the backward GEMMs (gemm_mode 1): the weights as stored, dz, and the transposed wgrad operands
+    int gemm_mode = 1;
+    uint16_t *w_hi = nullptr, *w_lo = nullptr;                                         // [L.total] each, a matrix at its own offset
+    uint16_t *dz_hi = nullptr, *dz_lo = nullptr, *dzt_hi = nullptr, *dzt_lo = nullptr, *at_hi = nullptr, *at_lo = nullptr;
     StepState* step_state = nullptr;
     StepState* host_state = nullptr;   // pinned ring: source of the asynchronous per-step uploads of trainer_step
     uint32_t host_state_next = 0;
@@ -531,7 +732,14 @@ Trainer* trainer_create(int channels, const char** err) {
     ok &= (t->step_state = t->dalloc<StepState>(1)) != nullptr;
     ok &= hipHostMalloc((void**)&t->host_state, HOST_STATE_RING * sizeof(StepState), hipHostMallocDefault) == hipSuccess;
     ok &= (t->counters = t->dalloc<EpochCounters>(1)) != nullptr;
-    t->splitk_floats = (size_t)32 << 20;      // 128 MiB
+    {
+        const size_t NM = std::max<size_t>(C, 1024), Mp = (B * 42 + 63) / 64 * 64;
+        for (uint16_t** q : {&t->w_hi, &t->w_lo}) ok &= (*q = t->dalloc<uint16_t>(T)) != nullptr;
+        for (uint16_t** q : {&t->dz_hi, &t->dz_lo}) ok &= (*q = t->dalloc<uint16_t>(B * 42 * NM)) != nullptr;
+        for (uint16_t** q : {&t->dzt_hi, &t->dzt_lo}) ok &= (*q = t->dalloc<uint16_t>(NM * Mp)) != nullptr;
+        for (uint16_t** q : {&t->at_hi, &t->at_lo}) ok &= (*q = t->dalloc<uint16_t>(9 * C * Mp)) != nullptr;
+    }
+    t->splitk_floats = (size_t)96 << 20;      // 384 MiB (a conv2-sized dgrad at the largest batch has 49.5 M outputs; it is never split)
     ok &= (t->splitk = t->dalloc<float>(t->splitk_floats)) != nullptr;
     if (!ok) { if (err) *err = "hipMalloc failed for the trainer workspace"; trainer_destroy(t); return nullptr; }
     (void)hipMemset(t->loss_totals, 0, 2 * sizeof(double));
@@ -629,6 +837,25 @@ void gemm_tn(const float* A, int64_t lda, const float* dZ, float* dW, int M, int
 
 int red_parts(int M) { return std::max(1, std::min(RED_PARTS, (M + 63) / 64)); }
 
+// out[M][N] (row stride ldo) = A W^T (+ bias) as bf16 x 3: A hi / lo [M][lda], W hi / lo [N][ldw], both contiguous along the contraction
+// Kc.  Split-K so that about two workgroups per CU exist (a workgroup walks at least 8 K-steps); the slices are summed in slice order.
+void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* out, int ldo,
+                  const float* bias, int M, int N, int Kc, float* ws, size_t ws_floats, hipStream_t s) {
+    const int mt = (M + G3_BM - 1) / G3_BM, NT = N / 128, tiles = mt * NT;
+    const int steps = 3 * (Kc / 64);
+    int splits = std::max(1, std::min((512 + tiles / 2) / tiles, steps / 8));
+    while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
+    const int sps = (steps + splits - 1) / splits;
+    splits = (steps + sps - 1) / sps;
+    Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits};
+    hipLaunchKernelGGL(k_gemm3, dim3((unsigned)((mt + 7) / 8 * 8 * NT), (unsigned)splits), dim3(256), 0, s, g);
+    if (splits > 1)
+        hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
+}
+void launch_transpose_split(const float* in, int R, int C, int64_t ld, uint16_t* out_hi, uint16_t* out_lo, int Rp, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_split, dim3((unsigned)((C + 63) / 64), (unsigned)(Rp / 64)), dim3(256), 0, s, in, R, C, ld, out_hi, out_lo, Rp);
+}
+
 }  // namespace
 
 namespace {
@@ -667,6 +894,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     };
     constexpr int APPLY_ROWS = 64;      // rows per block of the apply kernels
     // ---- forward ----
+    const bool x3 = t->gemm_mode == 1;
     hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
@@ -685,10 +913,18 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     // ---- backward ----
     hipLaunchKernelGGL(k_heads_bwd, grid1(std::max<int64_t>(512 * 8 + 8, (int64_t)b * 512)), dim3(256), 0, s, t->a[5], t->dhead,
                        P + L.pi_w, P + L.v_w, b, G + L.pi_w, G + L.pi_b, G + L.v_w, G + L.v_b, t->dact, t->sample_loss, t->loss_totals);
+    if (x3) {
+        SplitWeights sw{};
+        const int64_t offs[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
+        for (int i = 0; i < 5; ++i) { sw.off[i] = offs[i]; sw.count[i] = (int64_t)ld[i + 1].K * ld[i + 1].N; }
+        hipLaunchKernelGGL(k_split_weights, dim3(256, 5), dim3(256), 0, s, (const float*)P, sw, t->w_hi, t->w_lo);
+    }
     for (int l = 5; l >= 0; --l) {
         const LayerDef& d = ld[l];
         // t->dact holds d loss / d a[l]  ->  dz (through dropout, ReLU and BatchNorm)
         BnLayer bn = bn_desc(l, t->dz, t->dact);
+        const bool g3 = x3 && l >= 1;
+        if (g3) { bn.out_hi = t->dz_hi; bn.out_lo = t->dz_lo; }
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
         hipLaunchKernelGGL((k_colreduce<1>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
         hipLaunchKernelGGL(k_bn_bwd_apply, dim3((d.N + 63) / 64, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial,
@@ -696,12 +932,22 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         // The gradient of a bias in front of a BatchNorm is identically zero (the batch mean absorbs it); the kernels
         // leave those slots at 0 instead of the rounding residue a column sum of dz would give, which Adam would
         // turn into a random walk of size lr.
-        gemm_tn(d.A, d.lda, t->dz, G + d.w, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
-        if (l == 0) break;
-        if (l >= 4) {
-            gemm_nt(t->dz, P + d.w, t->dact, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);      // FC: d a[l-1] directly
+        if (g3) {
+            // wgrad: dW [K][N] = A^T dz, both operands transposed so that the contraction (the rows) is contiguous
+            const int Mp = (d.M + 63) / 64 * 64;
+            launch_transpose_split(t->dz, d.M, d.N, d.N, t->dzt_hi, t->dzt_lo, Mp, s);
+            launch_transpose_split(d.A, d.M, d.K, d.lda, t->at_hi, t->at_lo, Mp, s);
+            launch_gemm3(t->at_hi, t->at_lo, Mp, t->dzt_hi, t->dzt_lo, Mp, G + d.w, d.N, nullptr, d.K, d.N, Mp, t->splitk, t->splitk_floats, s);
+            // dgrad: d input [M][K] = dz W^T, W [K][N] as stored
+            float* din = l >= 4 ? t->dact : t->dcol;
+            launch_gemm3(t->dz_hi, t->dz_lo, d.N, t->w_hi + d.w, t->w_lo + d.w, d.N, din, d.K, nullptr, d.M, d.K, d.N, t->splitk, t->splitk_floats, s);
         } else {
-            gemm_nt(t->dz, P + d.w, t->dcol, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
+            gemm_tn(d.A, d.lda, t->dz, G + d.w, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
+            if (l == 0) break;
+            if (l >= 4) gemm_nt(t->dz, P + d.w, t->dact, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);      // FC: d a[l-1] directly
+            else gemm_nt(t->dz, P + d.w, t->dcol, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
+        }
+        if (l >= 1 && l <= 3) {
             const int H = l == 3 ? 4 : 6, W = l == 3 ? 5 : 7, pad = l == 1 ? 1 : 0;
             hipLaunchKernelGGL(k_col2im, grid1((int64_t)b * H * W * C / 4), dim3(256), 0, s, t->dcol, t->dact, b, H, W, C, pad);
         }
@@ -763,5 +1009,6 @@ bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards,
 }
 
 void trainer_set_graph(Trainer* t, bool on) { if (t) t->use_graph = on; }
+void trainer_set_gemm(Trainer* t, int mode) { if (t) t->gemm_mode = mode; }
 
 }  // namespace az

@@ -13,6 +13,8 @@ b = int(sys.argv[2]) if len(sys.argv) > 2 else 37
 T.C = C
 e = E.Engine(device=0, max_batch=1024, net_channels=C)
 e.set_option("train_dropout_e6", 0)
+if os.environ.get("TRAIN_GEMM"):
+    e.set_option("train_gemm", int(os.environ["TRAIN_GEMM"]))
 p = T.perturbed_params(e, 1, seed=b)
 boards, pis, vs = T.make_batch(b, seed=100 + b)
 e.train_begin(1)
