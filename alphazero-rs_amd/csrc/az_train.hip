@@ -211,6 +211,7 @@ struct Gemm3 {
     int lda, ldw, ldo;
     int steps_per_split;            // 64-deep K-steps of the 3 * Kc / 64 per blockIdx.y
     int splits;
+    int xcd_rows;                   // workgroup id -> tile mapping (k_gemm3)
 };
 
 constexpr int G3_BM = 128, G3_STAGE = G3_BM * 128 + 16384;
@@ -220,8 +221,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
     constexpr int MT = G3_BM / 32, NDMA = MT + 4;
     const int NT = g.N / 128;
     const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    int ntile, mtile;
+    if (g.xcd_rows) {            // row tile = XCD + 8 i: the column tiles of a row tile share an XCD's L2 (workgroup ids go round the 8 XCDs)
+        const int xcd = id & 7, j = id >> 3;
+        ntile = j % NT; mtile = (j / NT) * 8 + xcd;
+    } else {                     // fewer than 8 row tiles: that mapping would leave whole XCDs without work
+        ntile = id % NT; mtile = id / NT;
+    }
     const int m0 = mtile * G3_BM, n0 = ntile * 128;
     if (m0 >= g.M) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -464,62 +470,90 @@ struct BnLayer {
 };
 
 
-AZ_D float bn_grad_in(const BnLayer& L, uint64_t mask_seed, int r, int c, float mean, float invstd, float gamma, float beta, float& xh) {
-    const size_t i = (size_t)r * L.N + c;
-    xh = (L.z[i] - mean) * invstd;
+// d loss / d (BatchNorm output) of element (r, c) behind ReLU and dropout, and xhat
+AZ_D float bn_grad_in(const BnLayer& L, uint64_t mask_seed, size_t i, float z, float go, float mean, float invstd, float gamma, float beta, float& xh) {
+    xh = (z - mean) * invstd;
     const float y = gamma * xh + beta;
-    float g = y > 0.0f ? L.grad_out[i] : 0.0f;
+    float g = y > 0.0f ? go : 0.0f;
     if (L.keep_thresh) g = dropout_keep(mask_seed, L.drop_layer, i, L.keep_thresh) ? g * L.drop_scale : 0.0f;
     return g;
 }
 
-// stage 1 of a column reduction: block (64 columns x 4 row lanes) reduces rows [blockIdx.y*rpb, +rpb) and writes
-// partial[blockIdx.y][column][2] (f64); KIND 0: (sum z, sum z^2); 1: BN backward (sum g, sum g*xhat)
+// Geometry of the four BatchNorm kernels: a block is 32 column quads (128 columns, one float4 per thread and row) x 8 row lanes; a
+// thread walks its rows 8 apart with four rows' loads in flight.  (Round 2's blocks were 64 single columns x 4 row lanes with one
+// 4-byte load in flight per thread: 12.5 us for the 11 MB a conv2-sized backward reduction reads, 0.9 TB/s; N % 128 == 0 for every layer.)
+constexpr int BN_COLS = 128, BN_LANES = 8;
+
+// stage 1 of a column reduction: the block reduces rows [blockIdx.y*rpb, +rpb) of its 128 columns and writes
+// partial[blockIdx.y][column][2] (f64); KIND 0: (sum z, sum z^2); 1: BN backward (sum g, sum g*xhat).  The eight row lanes are
+// combined in lane order, the slices by the consumers in slice order: no atomics, one result whatever the scheduling.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_colreduce(const BnLayer L, int rpb, double* __restrict__ partial,
                                                    const StepState* __restrict__ st) {
-    __shared__ double red[4][64][2];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    __shared__ double red[BN_LANES][32][8];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * BN_COLS + tx * 4;
     const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
-    double s0 = 0.0, s1 = 0.0;
-    if (c < L.N) {
-        float mean = 0.f, invstd = 0.f, gamma = 0.f, beta = 0.f;
-        uint64_t mask_seed = 0;
-        if (KIND == 1) { mean = L.mean[c]; invstd = L.invstd[c]; gamma = L.gamma[c]; beta = L.beta[c]; if (L.keep_thresh) mask_seed = st->mask_seed; }
-        for (int r = r0 + ty; r < r1; r += 4) {
-            if (KIND == 0) { const float v = L.z[(size_t)r * L.N + c]; s0 += v; s1 += (double)v * v; }
-            else { float xh; const float g = bn_grad_in(L, mask_seed, r, c, mean, invstd, gamma, beta, xh); s0 += g; s1 += (double)g * xh; }
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    float4 mean = make_float4(0, 0, 0, 0), invstd = mean, gamma = mean, beta = mean;
+    uint64_t mask_seed = 0;
+    if (KIND == 1) {
+        mean = *(const float4*)(L.mean + c); invstd = *(const float4*)(L.invstd + c);
+        gamma = *(const float4*)(L.gamma + c); beta = *(const float4*)(L.beta + c);
+        if (L.keep_thresh) mask_seed = st->mask_seed;
+    }
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += BN_LANES) {
+        const size_t i = (size_t)r * L.N + c;
+        const float4 z = *(const float4*)(L.z + i);
+        if (KIND == 0) {
+            s0[0] += z.x; s1[0] += (double)z.x * z.x; s0[1] += z.y; s1[1] += (double)z.y * z.y;
+            s0[2] += z.z; s1[2] += (double)z.z * z.z; s0[3] += z.w; s1[3] += (double)z.w * z.w;
+        } else {
+            const float4 go = *(const float4*)(L.grad_out + i);
+            float xh;
+            float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); s0[0] += g; s1[0] += (double)g * xh;
+            g = bn_grad_in(L, mask_seed, i + 1, z.y, go.y, mean.y, invstd.y, gamma.y, beta.y, xh); s0[1] += g; s1[1] += (double)g * xh;
+            g = bn_grad_in(L, mask_seed, i + 2, z.z, go.z, mean.z, invstd.z, gamma.z, beta.z, xh); s0[2] += g; s1[2] += (double)g * xh;
+            g = bn_grad_in(L, mask_seed, i + 3, z.w, go.w, mean.w, invstd.w, gamma.w, beta.w, xh); s0[3] += g; s1[3] += (double)g * xh;
         }
     }
-    red[ty][threadIdx.x & 63][0] = s0;
-    red[ty][threadIdx.x & 63][1] = s1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[ty][tx][2 * q] = s0[q]; red[ty][tx][2 * q + 1] = s1[q]; }
     __syncthreads();
-    if (ty == 0 && c < L.N) {
-        const int t = threadIdx.x;
-        s0 = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
-        s1 = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
-        partial[((size_t)blockIdx.y * L.N + c) * 2 + 0] = s0;
-        partial[((size_t)blockIdx.y * L.N + c) * 2 + 1] = s1;
-    }
+    // 256 threads = 128 columns x 2 values: sum the eight row lanes in lane order
+    const int cl = threadIdx.x >> 1, v = threadIdx.x & 1;
+    double t = 0.0;
+#pragma unroll
+    for (int l = 0; l < BN_LANES; ++l) t += red[l][cl >> 2][2 * (cl & 3) + v];
+    partial[((size_t)blockIdx.y * L.N + blockIdx.x * BN_COLS + cl) * 2 + v] = t;
 }
 
-// Stage 2 is folded into the consumers: every block of the apply kernels first sums the partials of its 64 columns
-// in slice order (<= 32 slices: cheap, and the same result in every block), so there is no separate finish launch.
+// Stage 2 is folded into the consumers: every block of the apply kernels first sums the partials of its 128 columns in slice
+// order (<= 32 slices: cheap, and the same result in every block), so there is no separate finish launch.
+AZ_D void bn_sum_partials(const double* __restrict__ partial, int nparts, int N, int col0, double (*sums)[2]) {
+    const int cl = threadIdx.x >> 1, v = threadIdx.x & 1;
+    double t = 0.0;
+    for (int p = 0; p < nparts; ++p) t += partial[((size_t)p * N + col0 + cl) * 2 + v];
+    sums[cl][v] = t;
+}
 
-// a = dropout(relu(gamma * xhat + beta)).  grid (N/64, row blocks of `rpb` rows); block = 64 columns x 4 row lanes.
+// a = dropout(relu(gamma * xhat + beta)).  grid (N/128, row blocks of `rpb` rows).
 // Batch mean / biased variance -> mean, invstd (kept for the backward pass); the blockIdx.y == 0 blocks also update
 // the moving averages in place (moving = momentum*moving + (1-momentum)*batch, the variance with Bessel's
 // correction, as F.batch_norm does).
 __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double* __restrict__ partial, int nparts, int rpb, float eps,
                                                   float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
                                                   const StepState* __restrict__ st) {
-    __shared__ float s_mean[64], s_inv[64];
-    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, ty = threadIdx.x >> 6;
-    if (ty == 0 && c < L.N) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int p = 0; p < nparts; ++p) { s0 += partial[((size_t)p * L.N + c) * 2]; s1 += partial[((size_t)p * L.N + c) * 2 + 1]; }
-        const double mu = s0 / L.M;
-        double var = s1 / L.M - mu * mu;
+    __shared__ double sums[BN_COLS][2];
+    __shared__ __attribute__((aligned(16))) float s_mean[BN_COLS], s_inv[BN_COLS];
+    const int col0 = blockIdx.x * BN_COLS;
+    bn_sum_partials(partial, nparts, L.N, col0, sums);
+    __syncthreads();
+    if (threadIdx.x < BN_COLS) {
+        const int cl = threadIdx.x, c = col0 + cl;
+        const double mu = sums[cl][0] / L.M;
+        double var = sums[cl][1] / L.M - mu * mu;
         if (var < 0.0) var = 0.0;
         const float mean = (float)mu, inv = (float)(1.0 / sqrt(var + (double)eps));
         s_mean[cl] = mean; s_inv[cl] = inv;
@@ -531,15 +565,24 @@ __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double*
         }
     }
     __syncthreads();
-    if (c >= L.N) return;
-    const float mean = s_mean[cl], inv = s_inv[cl], gamma = L.gamma[c], beta = L.beta[c];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
+    const float4 mean = *(const float4*)(s_mean + tx * 4), inv = *(const float4*)(s_inv + tx * 4);
+    const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
     const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
     const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
-    for (int r = r0 + ty; r < r1; r += 4) {
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += BN_LANES) {
         const size_t i = (size_t)r * L.N + c;
-        float y = fmaxf(gamma * ((L.z[i] - mean) * inv) + beta, 0.0f);
-        if (L.keep_thresh) y = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i, L.keep_thresh) ? y * L.drop_scale : 0.0f;
-        L.out[i] = y;
+        const float4 z = *(const float4*)(L.z + i);
+        float4 y = make_float4(fmaxf(gamma.x * ((z.x - mean.x) * inv.x) + beta.x, 0.0f), fmaxf(gamma.y * ((z.y - mean.y) * inv.y) + beta.y, 0.0f),
+                               fmaxf(gamma.z * ((z.z - mean.z) * inv.z) + beta.z, 0.0f), fmaxf(gamma.w * ((z.w - mean.w) * inv.w) + beta.w, 0.0f));
+        if (L.keep_thresh) {
+            y.x = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 0, L.keep_thresh) ? y.x * L.drop_scale : 0.0f;
+            y.y = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 1, L.keep_thresh) ? y.y * L.drop_scale : 0.0f;
+            y.z = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 2, L.keep_thresh) ? y.z * L.drop_scale : 0.0f;
+            y.w = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 3, L.keep_thresh) ? y.w * L.drop_scale : 0.0f;
+        }
+        *(float4*)(L.out + i) = y;
     }
 }
 
@@ -547,26 +590,41 @@ __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double*
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnLayer L, const double* __restrict__ partial, int nparts, int rpb,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       const StepState* __restrict__ st) {
-    __shared__ float s_db[64], s_dg[64];
-    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, ty = threadIdx.x >> 6;
-    if (ty == 0 && c < L.N) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int p = 0; p < nparts; ++p) { s0 += partial[((size_t)p * L.N + c) * 2]; s1 += partial[((size_t)p * L.N + c) * 2 + 1]; }
-        s_db[cl] = (float)s0; s_dg[cl] = (float)s1;
-        if (blockIdx.y == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+    __shared__ double sums[BN_COLS][2];
+    __shared__ __attribute__((aligned(16))) float s_db[BN_COLS], s_dg[BN_COLS];
+    const int col0 = blockIdx.x * BN_COLS;
+    bn_sum_partials(partial, nparts, L.N, col0, sums);
+    __syncthreads();
+    if (threadIdx.x < BN_COLS) {
+        const int cl = threadIdx.x, c = col0 + cl;
+        s_db[cl] = (float)sums[cl][0]; s_dg[cl] = (float)sums[cl][1];
+        if (blockIdx.y == 0) { dbeta[c] = (float)sums[cl][0]; dgamma[c] = (float)sums[cl][1]; }
     }
     __syncthreads();
-    if (c >= L.N) return;
-    const float mean = L.mean[c], invstd = L.invstd[c], gamma = L.gamma[c], beta = L.beta[c], db = s_db[cl], dg = s_dg[cl];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
+    const float4 mean = *(const float4*)(L.mean + c), invstd = *(const float4*)(L.invstd + c);
+    const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
+    const float4 db = *(const float4*)(s_db + tx * 4), dg = *(const float4*)(s_dg + tx * 4);
     const float inv_m = 1.0f / (float)L.M;
     const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
     const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
-    for (int r = r0 + ty; r < r1; r += 4) {
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += BN_LANES) {
+        const size_t i = (size_t)r * L.N + c;
+        const float4 z = *(const float4*)(L.z + i), go = *(const float4*)(L.grad_out + i);
         float xh;
-        const float g = bn_grad_in(L, mask_seed, r, c, mean, invstd, gamma, beta, xh);
-        const float dzv = gamma * invstd * (g - (db + xh * dg) * inv_m);
-        L.out[(size_t)r * L.N + c] = dzv;
-        if (L.out_hi) { uint16_t hi, lo; split_bf16(dzv, hi, lo); L.out_hi[(size_t)r * L.N + c] = hi; L.out_lo[(size_t)r * L.N + c] = lo; }
+        float4 dz;
+        float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); dz.x = gamma.x * invstd.x * (g - (db.x + xh * dg.x) * inv_m);
+        g = bn_grad_in(L, mask_seed, i + 1, z.y, go.y, mean.y, invstd.y, gamma.y, beta.y, xh); dz.y = gamma.y * invstd.y * (g - (db.y + xh * dg.y) * inv_m);
+        g = bn_grad_in(L, mask_seed, i + 2, z.z, go.z, mean.z, invstd.z, gamma.z, beta.z, xh); dz.z = gamma.z * invstd.z * (g - (db.z + xh * dg.z) * inv_m);
+        g = bn_grad_in(L, mask_seed, i + 3, z.w, go.w, mean.w, invstd.w, gamma.w, beta.w, xh); dz.w = gamma.w * invstd.w * (g - (db.w + xh * dg.w) * inv_m);
+        *(float4*)(L.out + i) = dz;
+        if (L.out_hi) {
+            uint2 hi, lo;
+            split4(dz, hi, lo);
+            *(uint2*)(L.out_hi + i) = hi;
+            *(uint2*)(L.out_lo + i) = lo;
+        }
     }
 }
 
@@ -847,8 +905,9 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
     while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
     const int sps = (steps + splits - 1) / splits;
     splits = (steps + sps - 1) / sps;
-    Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits};
-    hipLaunchKernelGGL(k_gemm3, dim3((unsigned)((mt + 7) / 8 * 8 * NT), (unsigned)splits), dim3(256), 0, s, g);
+    const int xcd_rows = mt >= 8 ? 1 : 0;
+    Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, xcd_rows};
+    hipLaunchKernelGGL(k_gemm3, dim3((unsigned)((xcd_rows ? (mt + 7) / 8 * 8 : mt) * NT), (unsigned)splits), dim3(256), 0, s, g);
     if (splits > 1)
         hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
 }
@@ -892,7 +951,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         d.drop_scale = drop_scale;
         return d;
     };
-    constexpr int APPLY_ROWS = 64;      // rows per block of the apply kernels
+    constexpr int APPLY_ROWS = 32;      // rows per block of the apply kernels
     // ---- forward ----
     const bool x3 = t->gemm_mode == 1;
     hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
@@ -901,8 +960,8 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
         BnLayer bn = bn_desc(l, t->a[l], nullptr);
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
-        hipLaunchKernelGGL((k_colreduce<0>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
-        hipLaunchKernelGGL(k_bn_apply, dim3((d.N + 63) / 64, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
+        hipLaunchKernelGGL((k_colreduce<0>), dim3(d.N / BN_COLS, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
+        hipLaunchKernelGGL(k_bn_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
                            APPLY_ROWS, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
         if (l == 0) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 42 * 9 * C / 4), dim3(256), 0, s, t->a[0], t->col[1], b, 6, 7, C, 1);
         if (l == 1) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 20 * 9 * C / 4), dim3(256), 0, s, t->a[1], t->col[2], b, 6, 7, C, 0);
@@ -926,8 +985,8 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         const bool g3 = x3 && l >= 1;
         if (g3) { bn.out_hi = t->dz_hi; bn.out_lo = t->dz_lo; }
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
-        hipLaunchKernelGGL((k_colreduce<1>), dim3((d.N + 63) / 64, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
-        hipLaunchKernelGGL(k_bn_bwd_apply, dim3((d.N + 63) / 64, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial,
+        hipLaunchKernelGGL((k_colreduce<1>), dim3(d.N / BN_COLS, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
+        hipLaunchKernelGGL(k_bn_bwd_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial,
                            parts, APPLY_ROWS, G + d.bn, G + d.bn + d.N, st);
         // The gradient of a bias in front of a BatchNorm is identically zero (the batch mean absorbs it); the kernels
         // leave those slots at 0 instead of the rounding residue a column sum of dz would give, which Adam would

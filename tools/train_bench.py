@@ -16,6 +16,8 @@ vs = rng.choice([-1.0, 1.0], n).astype(np.float32)
 e = E.Engine(device=0, max_batch=1024, net_channels=C)
 e.net_init_random(0, seed=1)
 e.set_option("train_epochs", 1); e.set_option("train_batch", batch)
+if os.environ.get("TRAIN_GRAPH"):
+    e.set_option("train_graph", int(os.environ["TRAIN_GRAPH"]))
 if os.environ.get("TRAIN_GEMM"):
     e.set_option("train_gemm", int(os.environ["TRAIN_GEMM"]))
 e.train(0, 1, boards[: 4 * batch], pis[: 4 * batch], vs[: 4 * batch])     # warm-up (allocations, code load)
