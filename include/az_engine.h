@@ -120,33 +120,41 @@ az_status az_create(const az_config* cfg, az_engine** out);
 /* Destroy every az_tree of the engine first: a tree borrows the engine's stream. */
 void az_destroy(az_engine* e);
 const char* az_last_error(const az_engine* e);
-/* Tuning / A-B switches (no reference counterpart). Keys: "gemm_variant" = which implicit-GEMM kernels the conv
- * net uses (0 = 128x128 register-staged tiles for every layer, 1 / 2 = 256x256 LDS-DMA tiles, 3 = conv2 image-resident
- * in one 8-wave workgroup per CU, 5 = default, conv2 image-resident in two 4-wave workgroups per CU; 11-17 = timing
- * ablations with WRONG results; list in csrc/az_net.hip). Variants 0, 1, 2, 3, 5 are bit-identical. "conv4_big" = 0 (default: conv4 on the ring kernel) / 1 (256x256 kernel) / 2 (256x256 from
- * 4096 rows). "conv3_pipe" = 1 (default: conv3 with the LDS-DMA issued from inline asm and a software-pipelined K-step) / 2 (the same
- * without interleaving the fragment reads into the MFMA clusters) / 0 (round 1's kernel) / 3 (1 + clock stamps), all bit-identical;
- * 9-15 = its timing ladder (WRONG results). "conv3_small" = 1 (default): conv3 of a small expected batch (at most 356 rows) runs on the
- * 4-stage LDS-DMA ring (half the latency of the image-resident kernel there), 0 = never; "conv3_ring" = 1 / 2 / 3 forces conv3 onto the
- * ring (128-row tiles with 2 / 4 stages, device-picked tile); bit-identical. "conv2_pipe" = 1 (default) / 0: the conv2 GEMM kernel
- * ("conv2_table" = 0) with / without this round's pipeline; bit-identical. "ring_tile" = layer * 10000 + rows * 10 + stages forces one ring tile for layer 3 (conv4) /
- * 4 (fc1) / 5 (fc2), layer * 10000 = automatic again; bit-identical. "profile_every" = n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and tree_ms
- * sums then cover that sample of launches; every bracket costs a little GPU idle time between dependent kernels). "fused_search" = 1
- * (default): the stub / hash nets run a whole search in one launch, 0 = one launch per simulation like the conv net. "fc_ring" = 1
- * (default): LDS-DMA ring kernel for conv4 / fc1 / fc2 with 64..192-row tiles picked on the device from the batch's row count, 2 = the
- * tile picked on the host from its estimate, 3 = always 128-row tiles, 0 = register-staged tiles. "conv2_table" = 1 (default; 2 = the
- * same gather as whole rows per wave instead of one 64-channel slice per XCD, bit-identical): conv2 of the
- * default kernel set is nine gathered rows of a per-model table (conv2 is linear in conv1's output, which is one of 3^9 table rows
- * per position: csrc/az_net.hip) -- 198 of the net's 329 MFLOP per leaf are never executed; 0 = conv2 as the MFMA implicit GEMM
- * (same function, different rounding: each is batch-independent and within the stated tolerance of the fp32 reference).
- * "conv1_table" = 1 (default): conv2 of the default kernel set gathers its input image from the
- * per-model conv1 table (3^9 neighbourhood patterns x C channels) instead of running conv1 as a kernel, 0 = conv1 kernel; bit-identical.
- * Leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
- * src/node.rs:282-289): "eval_dedup" = 0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is
- * evaluated once; "eval_cache_log2" = log2 entries of the engine's evaluation cache shared by all trees (default 27, 0 = none,
- * 40 bytes per entry); "eval_cache_max_stones" = only states with at most that many stones are cached (default 42);
- * "eval_cache_persist" = 0 (default): every az_selfplay / az_arena / az_tree_get_action_prob call starts from an empty cache,
- * 1: entries live until the model's weights change.  Unknown keys or values return AZ_ERR_BAD_ARGUMENT. */
+/* Tuning switches (no reference counterpart).  EVERY option is state of the engine it is set on: two engines in one process never
+ * see each other's settings.  Unknown keys or values return AZ_ERR_BAD_ARGUMENT.  Keys of libaz_engine.so (each choice of a
+ * bit-identical group computes the same bits; tests/test_net_gpu.py):
+ *   the net  "conv2_table"  1 (default): conv1 + conv2 as nine gathered rows of a per-model table (conv2 is linear in conv1's output,
+ *                           which is one of 3^9 table rows per position; 198 of the net's 329 MFLOP per leaf are never executed);
+ *                           0: conv2 as the MFMA implicit GEMM -- the same function with its own rounding (each batch-independent and
+ *                           within the stated tolerance of the fp32 reference)
+ *            "conv3_small"  1 (default): conv3 of a small expected batch runs on the 4-stage LDS-DMA ring; 0: never.  Bit-identical
+ *            "conv3_tail"   1 (default): a short last round of conv3 workgroups is cut into half tiles; 0: full tiles.  Bit-identical
+ *            "conv3_planes" 1 (default): conv3's LDS image in the bank-conflict-free layout; 0: image rows in order.  Bit-identical
+ *            "narrow_rows"  n (default 32, 0 = off): batches of at most n boards (conv3; 2n for conv4, 4n for the FCs) run the
+ *                           register-fed skinny GEMM; the hand-over is decided on the device from the exact row count.  Bit-identical
+ *   search   "search_graph" n (default 20, even, 0 = off): n simulation steps per captured hipGraph replay (conv nets)
+ *            "fused_search" 1 (default): the stub / hash nets run a whole search in one launch; 0: one launch per simulation
+ *            "tree_block4"  1 (default): four waves per workgroup in the select / backup kernel; 0: one
+ *   leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
+ *   src/node.rs:282-289)
+ *            "eval_dedup"   0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is evaluated once
+ *            "eval_cache_log2"  upper bound of log2 entries of the engine's evaluation cache (default 27, 0 = none, 10..28; 40 bytes per
+ *                           entry).  A call allocates and clears only what ITS games can fill (4 x its bound on inserted rows,
+ *                           at least 2^10): a 1-tree, 25-simulation call touches 40 KB, not the 5.4 GB of the full table
+ *            "eval_cache_max_stones"  only states with at most that many stones are cached (default 42)
+ *            "eval_cache_persist"  0 (default): every az_selfplay / az_arena / az_tree_get_action_prob call starts from an empty cache;
+ *                           1: entries live until the model's weights change (the full "eval_cache_log2" table)
+ *            "dedup_stats"  1 (default) / 0: maintain the five leaf-row counters of az_stats
+ *   profile  "profile_every" n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and
+ *                           tree_ms sums then cover that sample of launches; a bracket costs a little idle time between kernels)
+ *   NNet::train  "train_epochs" (10), "train_batch" (64, <= 256), "train_seed" (0), "train_lr_e9" (1000000 = 1e-3),
+ *            "train_dropout_e6" (300000 = 0.3), "train_graph" 1 (default) / 0: replay a step's launches as a captured hipGraph,
+ *            "train_gemm" 1 (default): dgrad / wgrad as bf16 x 3 on the bf16 matrix cores (gradients within 1e-5 of float64
+ *                           autograd), 0: every GEMM on v_mfma_f32_16x16x4_f32 (1e-6)
+ * libaz_engine_diag.so (the same sources built with -DAZ_DIAG; alphazero-rs_amd/build.py) additionally takes the keys of the
+ * SUPERSEDED kernel generations and the TIMING ABLATIONS WITH WRONG RESULTS -- "gemm_variant", "fc_ring", "ring_tile", "conv3_ring",
+ * "conv2_pipe", "conv3_pipe", "conv1_table", "conv4_big", "conv2_table" = 2, "tree_stamps", "print_*" -- which the shipped library
+ * refuses (it accepts their default values, so a host may set them unconditionally); csrc/az_net.hip, csrc/az_net_diag.inc. */
 az_status az_set_option(az_engine* e, const char* key, int64_t value);
 az_status az_get_stats(az_engine* e, az_stats* out);
 az_status az_reset_stats(az_engine* e);
@@ -175,7 +183,8 @@ az_status az_net_predict_states(az_engine* e, int32_t model_id, const uint64_t* 
  * reference's recipe on the device (connect_four_net.py:13-21, :102-151: loss = softmax cross-entropy(pi) + mean
  * squared error(v), Adam, BatchNorm in training mode, dropout on the two FC layers; epochs x (n / batch) steps on
  * batches drawn with replacement), store the result under id. boards [n,2,6,7], pis [n,7], vs [n] f32, host or
- * device. f32 throughout, GEMMs on the f32 matrix cores (csrc/az_train.hip). Hyper-parameters through
+ * device. f32 parameters, activations, gradients and optimiser state; the forward GEMMs on the f32 matrix cores, dgrad / wgrad as
+ * bf16 x 3 with f32 accumulation ("train_gemm"; csrc/az_train.hip). Hyper-parameters through
  * az_set_option: "train_epochs" (10), "train_batch" (64, <= 256), "train_seed" (0), "train_lr_e9" (1000000 = 1e-3),
  * "train_dropout_e6" (300000 = 0.3). Batches and dropout masks come from the build's counter RNG (B7). */
 az_status az_net_train(az_engine* e, int32_t prev_id, int32_t id, const float* boards, const float* pis,

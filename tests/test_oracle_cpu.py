@@ -161,3 +161,33 @@ def test_rng_stream(oracle):
     picks = [L.azo_rng_choose_weighted(L.azo_rng_draw(3, i, 0, 2), w.ctypes.data, 7) for i in range(4000)]
     assert set(picks) == {1, 3} and 0.70 < picks.count(3) / 4000 < 0.80
     assert all(L.azo_rng_choose(L.azo_rng_draw(5, i, 0, 1), 3) in (0, 1, 2) for i in range(100))
+
+
+def test_lockstep_schedule_with_one_thread_is_the_plain_search(oracle):
+    """The oracle's lock-step schedule (num_threads > 1, az_oracle.hpp search_lockstep) run with ONE thread must be the reference's
+    search_iteration loop itself: same counts / pi / Q at every move of a whole game, same counters, nothing abandoned.  And with
+    several threads it is a different (and deterministic) search that still spends exactly num_sims simulations per move."""
+    sims = 60
+    a = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=11)
+    b = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=11, force_lockstep=True)
+    c = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=11, threads=4)
+    c2 = oracle.Tree(sims, net_kind=oracle.NET_HASH, salt=11, threads=4)
+    s = (0, 0)
+    differs = False
+    for move in range(42):
+        temp = 1.0 if move < 8 else 0.0
+        ra = a.get_action_prob(s[0], s[1], temp, seed=3, game_id=1)
+        rb = b.get_action_prob(s[0], s[1], temp, seed=3, game_id=1)
+        rc = c.get_action_prob(s[0], s[1], temp, seed=3, game_id=1)
+        rc2 = c2.get_action_prob(s[0], s[1], temp, seed=3, game_id=1)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y), move
+        for x, y in zip(rc, rc2):
+            assert np.array_equal(x, y), move
+        differs |= not np.array_equal(ra[1], rc[1])
+        s = oracle.c4_play(s[0], s[1], int(np.argmax(ra[1])))
+        if oracle.c4_ended(*s) != 0.0:
+            break
+    sa, sb, sc = a.stats(), b.stats(), c.stats()
+    assert sa == sb and sb["abandoned"] == 0
+    assert sc["sims"] == sa["sims"] and differs
