@@ -2,7 +2,7 @@
 alone (a one-game shard): where do the recorded rows differ?   python tools/arena_replay_probe.py [game] [num] [sims]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from alphazero_rs_amd import engine as azeng
 from oracle import oracle_py as orc
 g, num, sims = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 446), (2, 4096), (3, 400)))

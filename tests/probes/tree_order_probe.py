@@ -2,7 +2,7 @@
 into the engine's own NNet::predict.  Prints the first differing request of the first differing call."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from alphazero_rs_amd import engine as azeng
 from oracle import oracle_py as orc
 g, total, sims = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 446), (2, 4096), (3, 400)))

@@ -3,7 +3,7 @@ replayed on an oracle tree from the rows that call recorded; prints the first ca
 python tools/tree_replay_probe.py [game] [total] [sims]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from alphazero_rs_amd import engine as azeng
 from oracle import oracle_py as orc
 g, total, sims = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 446), (2, 4096), (3, 400)))

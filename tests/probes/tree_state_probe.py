@@ -1,7 +1,7 @@
 """Diagnostic (libaz_engine_diag.so): tree state of engine vs oracle right before the first simulation whose leaf differs."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from alphazero_rs_amd import engine as azeng
 from oracle import oracle_py as orc
 g, total, sims, bad_ply, bad_sim = 446, 4096, 400, int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 306
