@@ -469,6 +469,35 @@ def test_replay_parity_selfplay_with_refill_and_the_conv_net(engine, oracle):
         assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
 
 
+def test_replay_parity_lockstep_threads_with_the_conv_net(engine, oracle):
+    """Several simulations in flight per tree (num_sim_threads = 4: the lock-step schedule of DESIGN.md 4.1a) with the real bf16 net,
+    tables, de-duplication and the evaluation cache on, 2,048 slots x 4 threads = up to 8,192 rows per step, with slot refill: the
+    eval log holds every tree's rows in the order its threads consumed them, and the oracle's lock-step search re-plays 16 episodes
+    from them -- moves, pi and z bit for bit, no simulation spent differently."""
+    engine.net_init_random(27, seed=12)
+    n, conc, sims, T, seed = 4096, 2048, 100, 4, 21
+    cap = 42 * (sims + 1) + 8
+    engine.reset_stats()
+    got = engine.selfplay(n_games=n, concurrent=conc, num_sims=sims, model_id=27, seed=seed, want_boards=False, record_evals=cap,
+                          num_sim_threads=T)
+    st = engine.stats()
+    assert st["games"] == n and st["simulations"] == sims * int(got["game_len"].sum())
+    cnt, states, pis, vs = engine.selfplay_get_evals(n, cap)
+    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([rng.choice(conc, size=8, replace=False), conc + rng.choice(n - conc, size=8, replace=False)])
+    for g in ids:
+        c = int(cnt[g])
+        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_REPLAY, seed=seed, first_game_id=int(g), sim_threads=T,
+                              replay=(np.array([0, c], np.int64), np.ascontiguousarray(states[g, :c]), np.ascontiguousarray(pis[g, :c]),
+                                      np.ascontiguousarray(vs[g, :c])))
+        assert not ref["replay_bad"].any(), g
+        L = int(ref["game_len"][0])
+        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
+        lo, hi = offs[g], offs[g + 1]
+        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+
+
 def test_set_option_is_per_engine(engine_mod, oracle):
     """az_set_option changes the handle it is given and nothing else: two engines in one process, one with conv2 as the MFMA
     GEMM ("conv2_table" = 0: a different rounding of the same function) and the older kernel families, interleaved
