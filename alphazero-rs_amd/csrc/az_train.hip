@@ -1,4 +1,5 @@
-// az_train.hip -- NNet::train (src/nnet.rs:38) as f32 HIP kernels for gfx950.
+// az_train.hip -- NNet::train (src/nnet.rs:38) as HIP kernels for gfx950: f32 state, forward GEMMs on the f32 matrix cores, backward
+// GEMMs as bf16 x 3 on the bf16 matrix cores (second half of this file).
 //
 // Recipe (the reference's Python net, connect_four_net.py; only its hyper-parameters and layer list are taken,
 // the TF1 code itself is broken -- SURVEY.md B11): loss = softmax cross-entropy(pi) + mean squared error(v)
@@ -10,10 +11,9 @@
 //   and back: heads -> BN/ReLU/dropout backward (two-stage column sums) -> wgrad GEMM (A^T dz), dgrad GEMM
 //   (dz W^T) -> col2im -> previous layer ...; then one Adam kernel over the flat vector.
 //
-// Everything is f32 (activations row-major [rows][channels], rows = (sample, y, x)); the GEMMs use
-// v_mfma_f32_16x16x4_f32 with 64x64 block tiles.  At the reference's batch of 64 a step is ~63 GFLOP over ~45
-// small launches: it is launch- and fill-bound, not roofline-bound, and is sized for correctness first
-// (DESIGN.md section 8).
+// Parameters, activations (row-major [rows][channels], rows = (sample, y, x)), gradients and the optimiser state are f32; k_gemm_f32
+// (v_mfma_f32_16x16x4_f32, 64 x 64 or 128 x 128 block tiles, deterministic split-K) runs the forward GEMMs and, with "train_gemm" = 0,
+// every GEMM.  At the reference's batch of 64 a step is ~63 GFLOP over ~75 launches of 5 - 150 us.
 #include "az_train.h"
 
 #include <algorithm>
@@ -145,6 +145,115 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmF32 g) {
                 for (int q = 0; q < 4; ++q)
                     if (n + q < g.N) c[q] = acc[i][j][q] + (g.bias ? g.bias[n + q] : 0.0f);
             }
+        }
+    }
+}
+
+// ---- the forward GEMMs' kernel: C = A W (+ bias), A [M][K] and W [K][N] row-major, fed by LDS-DMA -----------------------------------
+// k_gemm_f32 stages its tiles through registers (global load -> VGPR -> ds_write), a path a CU takes in at ~10 B/clk: conv2's forward GEMM
+// reaches 83 of the 157 TFLOP/s of v_mfma_f32_16x16x4_f32 on it.  Here both tiles of a 16-deep K-step go global -> LDS by asm-issued
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write) into a ring of four 16 KiB stages, three in flight, retired by a counted
+// s_waitcnt and ONE barrier per K-step; two workgroups per CU.  The LDS image is the global layout, 16-byte cells permuted on the source
+// side so that the fragment reads are conflict-free:
+//   A tile [128 m][16 k]: 64-byte rows of four k quads; lane (row fr, k group fk) reads quad fk of its row as ONE ds_read_b128 and uses
+//     component j in the step's j-th MFMA -- so an MFMA sums k = j, 4 + j, 8 + j, 12 + j, and B follows the same assignment; quad q of
+//     row r sits at position q ^ F(r), F = {0, 2, 3, 1}[(r >> 2) & 3] (the four non-contiguous 16-lane groups of a ds_read_b128 then
+//     cover 16 distinct 16-byte slots);
+//   B tile [16 k][128 n]: 512-byte rows; lane (n = fr, fk) reads B[4 fk + j][n] with ds_read_b32; 16-byte cell c of row k sits at
+//     c ^ 4 ((k >> 2) & 1), which puts the two k groups of a 32-lane half on opposite halves of the banks.
+// Requires K % 16 == 0, N % 128 == 0, 16-byte-aligned rows (every forward layer but conv1, whose K is 18).  The per-element summation
+// order differs from k_gemm_f32's, so the last bits of z do too; tests/test_train_gpu.py holds both to float64 autograd.
+constexpr int GD_BK = 16, GD_STAGE = 16384, GD_NS = 4;
+AZ_D void gd_dma16(const void* sbase /*uniform*/, uint32_t voff, uint32_t lds_addr /*uniform*/) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void k_gemm_f32_dma(const GemmF32 g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[GD_NS * GD_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int kbeg = blockIdx.z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg) / GD_BK;
+    // DMA maps.  A: piece p (16 rows) of wave w = w, w + 4; lane -> row p*16 + (lane >> 2), position lane & 3 holding quad (lane & 3) ^ F(row)
+    const uint32_t fA = (0x78u >> ((((uint32_t)lane >> 4) & 3u) * 2u)) & 3u;
+    uint32_t a_ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + (wave + 4 * i) * 16 + (lane >> 2);
+        m = m < g.M ? m : g.M - 1;
+        a_ob[i] = (uint32_t)((int64_t)m * g.sAm * 4 + (((lane & 3) ^ fA) << 4));
+    }
+    // B: piece p (2 rows) of wave w = w, w + 4 (+ 8 rows: a uniform offset); lane -> row 2p + (lane >> 5), position lane & 31 holding cell
+    // (lane & 31) ^ 4 ((row >> 2) & 1), and (row >> 2) & 1 == wave >> 1 for both pieces
+    const uint32_t b_ob = (uint32_t)((int64_t)(2 * wave + (lane >> 5)) * g.sBk * 4 + (n0 + (((lane & 31) ^ ((wave >> 1) << 2)) << 2)) * 4);
+    const size_t b_piece = (size_t)8 * g.sBk * 4;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
+    int kd = kbeg;
+#define AZ_GDDMA(buf_)                                                                                  \
+    {                                                                                                   \
+        const char* ab = (const char*)(g.A + kd);                                                       \
+        const char* bb = (const char*)(g.B + (int64_t)kd * g.sBk);                                      \
+        const uint32_t la = lds0 + (buf_) * GD_STAGE;                                                   \
+        gd_dma16(ab, a_ob[0], la);                                                                      \
+        gd_dma16(ab, a_ob[1], la + 4096);                                                               \
+        gd_dma16(bb, b_ob, la + 8192);                                                                  \
+        gd_dma16(bb + b_piece, b_ob, la + 8192 + 4096);                                                 \
+        kd += GD_BK;                                                                                    \
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+    const int a_off = (wr * 64 + fr) * 64 + ((fk ^ (int)((0x78u >> ((((uint32_t)fr >> 2) & 3u) * 2u)) & 3u)) << 4);
+    int b_off[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b_off[nt] = 8192 + fk * 4 * 512 + (((wc * 16 + nt * 4 + (fr >> 2)) ^ ((fk & 1) << 2)) << 4) + (fr & 3) * 4;
+#pragma unroll
+    for (int st = 0; st < GD_NS - 1; ++st)
+        if (st < nk) AZ_GDDMA(st);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = nk - 1 - kt < GD_NS - 2 ? nk - 1 - kt : GD_NS - 2;      // stages issued after stage kt and still in flight
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // stage kt is complete for every wave; every wave is done with stage kt-1's buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + GD_NS - 1 < nk) AZ_GDDMA((kt + GD_NS - 1) % GD_NS);
+        const unsigned char* sb = smem + (kt % GD_NS) * GD_STAGE;
+        float4 a4[4];
+        float bv[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a4[mt] = *(const float4*)(sb + a_off + mt * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bv[nt][j] = *(const float*)(sb + b_off[nt] + j * 512);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float av = j == 0 ? a4[mt].x : j == 1 ? a4[mt].y : j == 2 ? a4[mt].z : a4[mt].w;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][j], av, acc[mt][nt], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef AZ_GDDMA
+    float* cbase = g.splits > 1 ? g.C + (int64_t)blockIdx.z * g.M * g.N : g.C;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wr * 64 + mt * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wc * 64 + nt * 16 + fk * 4;
+            float4 o = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            if (g.bias) { const float4 bb = *(const float4*)(g.bias + n); o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
+            *(float4*)(cbase + (int64_t)m * g.ldc + n) = o;
         }
     }
 }
@@ -733,6 +842,7 @@ struct Trainer {
     float* splitk = nullptr;           // partial sums of the split-K GEMMs
     // bf16 x 3 operands of the backward GEMMs (gemm_mode 1): the weights as stored, dz, and the transposed wgrad operands
     int gemm_mode = 1;
+    bool fwd_dma = true;               // forward GEMMs on k_gemm_f32_dma where its shape constraints hold
     uint16_t *w_hi = nullptr, *w_lo = nullptr;                                         // [L.total] each, a matrix at its own offset
     uint16_t *dz_hi = nullptr, *dz_lo = nullptr, *dzt_hi = nullptr, *dzt_lo = nullptr, *at_hi = nullptr, *at_lo = nullptr;
     StepState* step_state = nullptr;
@@ -878,8 +988,22 @@ void launch_gemm_f32(GemmF32 g, float* ws, size_t ws_floats, hipStream_t s) {
 
 // C[M][N] = A[M][K] W[K][N] + bias
 void gemm_nn(const float* A, int64_t lda, const float* W, float* Cm, const float* bias, int M, int N, int K, float* ws, size_t wsn,
-             hipStream_t s) {
+             hipStream_t s, bool dma = false) {
     GemmF32 g{A, lda, 1, W, N, 1, Cm, N, bias, M, N, K, 0, 1};
+    if (dma && M >= 128 && K % GD_BK == 0 && K >= 8 * GD_BK && N % 128 == 0 && lda % 4 == 0) {
+        // k_gemm_f32_dma: 128 x 128 tiles, two workgroups per CU (512 slots a round), at least 8 K-steps per slice
+        const int tiles = ((M + 127) / 128) * (N / 128), ksteps = K / GD_BK;
+        int splits = std::max(1, std::min((512 + tiles / 2) / tiles, ksteps / 8));
+        while (splits > 1 && (size_t)splits * M * N > wsn) --splits;
+        const int k_per = ((ksteps + splits - 1) / splits) * GD_BK;
+        splits = (K + k_per - 1) / k_per;
+        g.k_per_split = k_per;
+        g.splits = splits;
+        if (splits > 1) { g.C = ws; g.bias = nullptr; }
+        hipLaunchKernelGGL(k_gemm_f32_dma, dim3(N / 128, (M + 127) / 128, splits), dim3(256), 0, s, g);
+        if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, Cm, (int64_t)N, bias);
+        return;
+    }
     launch_gemm_f32<1, 1>(g, ws, wsn, s);
 }
 // dA[M][K] = dZ[M][N] W[K][N]^T   (contraction over n; "B"(n, k) = W[k*N + n])
@@ -957,7 +1081,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
-        gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
+        gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s, t->fwd_dma);
         BnLayer bn = bn_desc(l, t->a[l], nullptr);
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
         hipLaunchKernelGGL((k_colreduce<0>), dim3(d.N / BN_COLS, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
@@ -1069,5 +1193,6 @@ bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards,
 
 void trainer_set_graph(Trainer* t, bool on) { if (t) t->use_graph = on; }
 void trainer_set_gemm(Trainer* t, int mode) { if (t) t->gemm_mode = mode; }
+void trainer_set_fwd_dma(Trainer* t, bool on) { if (t) t->fwd_dma = on; }
 
 }  // namespace az

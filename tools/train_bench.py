@@ -18,6 +18,8 @@ e.net_init_random(0, seed=1)
 e.set_option("train_epochs", 1); e.set_option("train_batch", batch)
 if os.environ.get("TRAIN_GRAPH"):
     e.set_option("train_graph", int(os.environ["TRAIN_GRAPH"]))
+if os.environ.get("TRAIN_FWD_DMA"):
+    e.set_option("train_fwd_dma", int(os.environ["TRAIN_FWD_DMA"]))
 if os.environ.get("TRAIN_GEMM"):
     e.set_option("train_gemm", int(os.environ["TRAIN_GEMM"]))
 e.train(0, 1, boards[: 4 * batch], pis[: 4 * batch], vs[: 4 * batch])     # warm-up (allocations, code load)
