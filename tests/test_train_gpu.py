@@ -50,12 +50,14 @@ def perturbed_params(engine, model_id, seed):
     return p
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["bf16x3_backward", "f32_gemms"])
+@pytest.fixture(scope="module", params=[(1, 1), (0, 1), (0, 0)], ids=["bf16x3_backward", "f32_gemms", "f32_register_staged"])
 def tengine(engine_mod, request):
-    """Both GEMM sets of the trainer: the default (backward GEMMs as bf16 x 3 on the bf16 matrix cores, forward on
-    v_mfma_f32_16x16x4_f32) and every GEMM on the f32 matrix cores ("train_gemm" = 0).  Same bars for both."""
+    """The GEMM sets of the trainer: the default (backward GEMMs as bf16 x 3 on the bf16 matrix cores, forward on
+    v_mfma_f32_16x16x4_f32 fed by LDS-DMA), every GEMM on the f32 matrix cores ("train_gemm" = 0), and that with round 2's
+    register-staged forward kernel ("train_fwd_dma" = 0).  Same bars for all."""
     e = engine_mod.Engine(device=0, max_batch=1024, net_channels=C)
-    e.set_option("train_gemm", request.param)
+    e.set_option("train_gemm", request.param[0])
+    e.set_option("train_fwd_dma", request.param[1])
     yield e
     e.close()
 
