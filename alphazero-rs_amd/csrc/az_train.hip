@@ -447,26 +447,34 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
     }
 }
 
-// in [R][C] f32 (row stride ld) -> out hi / lo [C][Rp] bf16, rows R .. Rp-1 of the source taken as zero; 64 x 64 tiles
-__global__ __launch_bounds__(256) void k_transpose_split(const float* __restrict__ in, int R, int C, int64_t ld, uint16_t* __restrict__ out_hi,
-                                                         uint16_t* __restrict__ out_lo, int Rp) {
+// in [R][C] f32 (row stride ld) -> out hi / lo [C][Rp] bf16, rows R .. Rp-1 of the source taken as zero; 64 x 64 tiles.  One launch
+// transposes BOTH wgrad operands of a layer (dz and the layer's input): the tiles of the second follow the first's in blockIdx.x.
+struct TransposeJob {
+    const float* in;
+    uint16_t *out_hi, *out_lo;
+    int C, tiles_c;
+    int64_t ld;
+};
+__global__ __launch_bounds__(256) void k_transpose_split(const TransposeJob j0, const TransposeJob j1, int R, int Rp) {
     __shared__ float tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const bool second = (int)blockIdx.x >= j0.tiles_c;
+    const TransposeJob& j = second ? j1 : j0;
+    const int r0 = blockIdx.y * 64, c0 = ((int)blockIdx.x - (second ? j0.tiles_c : 0)) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = ty + 4 * i;
-        tile[r][tx] = (r0 + r < R && c0 + tx < C) ? in[(size_t)(r0 + r) * ld + c0 + tx] : 0.0f;
+        tile[r][tx] = (r0 + r < R && c0 + tx < j.C) ? j.in[(size_t)(r0 + r) * j.ld + c0 + tx] : 0.0f;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = ty + 4 * i;
-        if (c0 + c < C && r0 + tx < Rp) {
+        if (c0 + c < j.C && r0 + tx < Rp) {
             uint16_t hi, lo;
             split_bf16(tile[tx][c], hi, lo);
-            out_hi[(size_t)(c0 + c) * Rp + r0 + tx] = hi;
-            out_lo[(size_t)(c0 + c) * Rp + r0 + tx] = lo;
+            j.out_hi[(size_t)(c0 + c) * Rp + r0 + tx] = hi;
+            j.out_lo[(size_t)(c0 + c) * Rp + r0 + tx] = lo;
         }
     }
 }
@@ -549,17 +557,30 @@ __global__ void k_col2im(const float* __restrict__ dcol, float* __restrict__ din
     }
 }
 
-__global__ void k_gather_batch(const float* __restrict__ all_boards, const float* __restrict__ all_pis,
-                               const float* __restrict__ all_vs, const int64_t* __restrict__ idx, int b,
-                               float* __restrict__ boards, float* __restrict__ pis, float* __restrict__ vs,
-                               const StepState* __restrict__ st) {
+// The step's batch gathered from the epoch's samples (boards, pis, vs: rows idx[idx_offset ..]) and conv1's im2col matrix (k_boards_col1's)
+// straight from those rows, one launch (the epoch loop)
+__global__ void k_gather_col1(const float* __restrict__ all_boards, const float* __restrict__ all_pis, const float* __restrict__ all_vs,
+                              const int64_t* __restrict__ idx, int b, float* __restrict__ boards, float* __restrict__ pis, float* __restrict__ vs,
+                              float* __restrict__ col, const StepState* __restrict__ st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b * 92) return;
-    const int j = i / 92, f = i % 92;
-    const int64_t src = idx[st->idx_offset + j];
-    if (f < 84) boards[(size_t)j * 84 + f] = all_boards[(size_t)src * 84 + f];
-    else if (f < 91) pis[(size_t)j * 7 + (f - 84)] = all_pis[(size_t)src * 7 + (f - 84)];
-    else vs[j] = all_vs[src];
+    const int64_t off = st->idx_offset;
+    if (i < b * 92) {
+        const int j = i / 92, f = i % 92;
+        const int64_t src = idx[off + j];
+        if (f < 84) boards[(size_t)j * 84 + f] = all_boards[(size_t)src * 84 + f];
+        else if (f < 91) pis[(size_t)j * 7 + (f - 84)] = all_pis[(size_t)src * 7 + (f - 84)];
+        else vs[j] = all_vs[src];
+    }
+    if (i < b * 42 * 20) {
+        const int k = i % 20, row = i / 20;
+        const int s = row / 42, p = row % 42, y = p / 7, x = p % 7;
+        float v = 0.0f;
+        if (k < 18) {
+            const int tap = k >> 1, ci = k & 1, iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            if (iy >= 0 && iy < 6 && ix >= 0 && ix < 7) v = all_boards[(size_t)idx[off + s] * 84 + ci * 42 + iy * 7 + ix];
+        }
+        col[i] = v;
+    }
 }
 
 // ---- BatchNorm (training mode) + ReLU + dropout ----------------------------------------------------------------
@@ -719,6 +740,117 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnLayer L, const dou
     const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
 #pragma unroll 4
     for (int r = r0 + ty; r < r1; r += BN_LANES) {
+        const size_t i = (size_t)r * L.N + c;
+        const float4 z = *(const float4*)(L.z + i), go = *(const float4*)(L.grad_out + i);
+        float xh;
+        float4 dz;
+        float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); dz.x = gamma.x * invstd.x * (g - (db.x + xh * dg.x) * inv_m);
+        g = bn_grad_in(L, mask_seed, i + 1, z.y, go.y, mean.y, invstd.y, gamma.y, beta.y, xh); dz.y = gamma.y * invstd.y * (g - (db.y + xh * dg.y) * inv_m);
+        g = bn_grad_in(L, mask_seed, i + 2, z.z, go.z, mean.z, invstd.z, gamma.z, beta.z, xh); dz.z = gamma.z * invstd.z * (g - (db.z + xh * dg.z) * inv_m);
+        g = bn_grad_in(L, mask_seed, i + 3, z.w, go.w, mean.w, invstd.w, gamma.w, beta.w, xh); dz.w = gamma.w * invstd.w * (g - (db.w + xh * dg.w) * inv_m);
+        *(float4*)(L.out + i) = dz;
+        if (L.out_hi) {
+            uint2 hi, lo;
+            split4(dz, hi, lo);
+            *(uint2*)(L.out_hi + i) = hi;
+            *(uint2*)(L.out_lo + i) = lo;
+        }
+    }
+}
+
+// The FC layers' BatchNorm (at most BN_SMALL_ROWS rows: one slice): both stages in ONE launch -- a block owns 128 columns of EVERY row, so
+// it has the complete column sums itself (same lane-order summation as k_colreduce with one slice: identical results).
+constexpr int BN_SMALL_ROWS = 64;
+template <int KIND>
+AZ_D void bn_small_sums(const BnLayer& L, uint64_t mask_seed, float4 mean, float4 invstd, float4 gamma, float4 beta, double (*red)[32][8],
+                        double (*sums)[2]) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * BN_COLS + tx * 4;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int r = ty; r < L.M; r += BN_LANES) {
+        const size_t i = (size_t)r * L.N + c;
+        const float4 z = *(const float4*)(L.z + i);
+        if (KIND == 0) {
+            s0[0] += z.x; s1[0] += (double)z.x * z.x; s0[1] += z.y; s1[1] += (double)z.y * z.y;
+            s0[2] += z.z; s1[2] += (double)z.z * z.z; s0[3] += z.w; s1[3] += (double)z.w * z.w;
+        } else {
+            const float4 go = *(const float4*)(L.grad_out + i);
+            float xh;
+            float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); s0[0] += g; s1[0] += (double)g * xh;
+            g = bn_grad_in(L, mask_seed, i + 1, z.y, go.y, mean.y, invstd.y, gamma.y, beta.y, xh); s0[1] += g; s1[1] += (double)g * xh;
+            g = bn_grad_in(L, mask_seed, i + 2, z.z, go.z, mean.z, invstd.z, gamma.z, beta.z, xh); s0[2] += g; s1[2] += (double)g * xh;
+            g = bn_grad_in(L, mask_seed, i + 3, z.w, go.w, mean.w, invstd.w, gamma.w, beta.w, xh); s0[3] += g; s1[3] += (double)g * xh;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[ty][tx][2 * q] = s0[q]; red[ty][tx][2 * q + 1] = s1[q]; }
+    __syncthreads();
+    const int cl = threadIdx.x >> 1, v = threadIdx.x & 1;
+    double t = 0.0;
+#pragma unroll
+    for (int l = 0; l < BN_LANES; ++l) t += red[l][cl >> 2][2 * (cl & 3) + v];
+    sums[cl][v] = t;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_bn_fwd_small(const BnLayer L, float eps, float momentum, float* __restrict__ run_mean,
+                                                      float* __restrict__ run_var, const StepState* __restrict__ st) {
+    __shared__ double red[BN_LANES][32][8];
+    __shared__ double sums[BN_COLS][2];
+    __shared__ __attribute__((aligned(16))) float s_mean[BN_COLS], s_inv[BN_COLS];
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    bn_small_sums<0>(L, 0, z4, z4, z4, z4, red, sums);
+    const int col0 = blockIdx.x * BN_COLS;
+    if (threadIdx.x < BN_COLS) {
+        const int cl = threadIdx.x, c = col0 + cl;
+        const double mu = sums[cl][0] / L.M;
+        double var = sums[cl][1] / L.M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)mu, inv = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[cl] = mean; s_inv[cl] = inv;
+        L.mean[c] = mean; L.invstd[c] = inv;
+        const double unbiased = L.M > 1 ? var * L.M / (L.M - 1) : var;
+        run_mean[c] = momentum * run_mean[c] + (1.0f - momentum) * (float)mu;
+        run_var[c] = momentum * run_var[c] + (1.0f - momentum) * (float)unbiased;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
+    const float4 mean = *(const float4*)(s_mean + tx * 4), inv = *(const float4*)(s_inv + tx * 4);
+    const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
+    const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
+#pragma unroll 4
+    for (int r = ty; r < L.M; r += BN_LANES) {
+        const size_t i = (size_t)r * L.N + c;
+        const float4 z = *(const float4*)(L.z + i);
+        float4 y = make_float4(fmaxf(gamma.x * ((z.x - mean.x) * inv.x) + beta.x, 0.0f), fmaxf(gamma.y * ((z.y - mean.y) * inv.y) + beta.y, 0.0f),
+                               fmaxf(gamma.z * ((z.z - mean.z) * inv.z) + beta.z, 0.0f), fmaxf(gamma.w * ((z.w - mean.w) * inv.w) + beta.w, 0.0f));
+        if (L.keep_thresh) {
+            y.x = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 0, L.keep_thresh) ? y.x * L.drop_scale : 0.0f;
+            y.y = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 1, L.keep_thresh) ? y.y * L.drop_scale : 0.0f;
+            y.z = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 2, L.keep_thresh) ? y.z * L.drop_scale : 0.0f;
+            y.w = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 3, L.keep_thresh) ? y.w * L.drop_scale : 0.0f;
+        }
+        *(float4*)(L.out + i) = y;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_small(const BnLayer L, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      const StepState* __restrict__ st) {
+    __shared__ double red[BN_LANES][32][8];
+    __shared__ double sums[BN_COLS][2];
+    const int col0 = blockIdx.x * BN_COLS;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
+    const float4 mean = *(const float4*)(L.mean + c), invstd = *(const float4*)(L.invstd + c);
+    const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
+    const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
+    bn_small_sums<1>(L, mask_seed, mean, invstd, gamma, beta, red, sums);
+    if (threadIdx.x < BN_COLS) { dbeta[col0 + threadIdx.x] = (float)sums[threadIdx.x][0]; dgamma[col0 + threadIdx.x] = (float)sums[threadIdx.x][1]; }
+    const float4 db = make_float4((float)sums[tx * 4][0], (float)sums[tx * 4 + 1][0], (float)sums[tx * 4 + 2][0], (float)sums[tx * 4 + 3][0]);
+    const float4 dg = make_float4((float)sums[tx * 4][1], (float)sums[tx * 4 + 1][1], (float)sums[tx * 4 + 2][1], (float)sums[tx * 4 + 3][1]);
+    const float inv_m = 1.0f / (float)L.M;
+#pragma unroll 4
+    for (int r = ty; r < L.M; r += BN_LANES) {
         const size_t i = (size_t)r * L.N + c;
         const float4 z = *(const float4*)(L.z + i), go = *(const float4*)(L.grad_out + i);
         float xh;
@@ -1035,8 +1167,8 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
     if (splits > 1)
         hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
 }
-void launch_transpose_split(const float* in, int R, int C, int64_t ld, uint16_t* out_hi, uint16_t* out_lo, int Rp, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_split, dim3((unsigned)((C + 63) / 64), (unsigned)(Rp / 64)), dim3(256), 0, s, in, R, C, ld, out_hi, out_lo, Rp);
+void launch_transpose_split2(const TransposeJob& j0, const TransposeJob& j1, int R, int Rp, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_split, dim3((unsigned)(j0.tiles_c + j1.tiles_c), (unsigned)(Rp / 64)), dim3(256), 0, s, j0, j1, R, Rp);
 }
 
 }  // namespace
@@ -1045,7 +1177,7 @@ namespace {
 
 // every kernel of one optimisation step, in order, on stream s (no host synchronisation: capturable in a hipGraph)
 void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const float* d_pis, const float* d_vs, int b, bool apply,
-                  hipStream_t s) {
+                  hipStream_t s, bool col1_done = false) {
     const int C = t->C;
     const Layout& L = t->L;
     float* P = t->params;
@@ -1078,15 +1210,19 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     constexpr int APPLY_ROWS = 32;      // rows per block of the apply kernels
     // ---- forward ----
     const bool x3 = t->gemm_mode == 1;
-    hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
+    if (!col1_done) hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
         gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s, t->fwd_dma);
         BnLayer bn = bn_desc(l, t->a[l], nullptr);
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
-        hipLaunchKernelGGL((k_colreduce<0>), dim3(d.N / BN_COLS, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
-        hipLaunchKernelGGL(k_bn_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
-                           APPLY_ROWS, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
+        if (d.M <= BN_SMALL_ROWS) {
+            hipLaunchKernelGGL(k_bn_fwd_small, dim3(d.N / BN_COLS), dim3(256), 0, s, bn, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
+        } else {
+            hipLaunchKernelGGL((k_colreduce<0>), dim3(d.N / BN_COLS, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
+            hipLaunchKernelGGL(k_bn_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
+                               APPLY_ROWS, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
+        }
         if (l == 0) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 42 * 9 * C / 4), dim3(256), 0, s, t->a[0], t->col[1], b, 6, 7, C, 1);
         if (l == 1) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 20 * 9 * C / 4), dim3(256), 0, s, t->a[1], t->col[2], b, 6, 7, C, 0);
         if (l == 2) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 6 * 9 * C / 4), dim3(256), 0, s, t->a[2], t->col[3], b, 4, 5, C, 0);
@@ -1109,17 +1245,21 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         const bool g3 = x3 && l >= 1;
         if (g3) { bn.out_hi = t->dz_hi; bn.out_lo = t->dz_lo; }
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
-        hipLaunchKernelGGL((k_colreduce<1>), dim3(d.N / BN_COLS, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
-        hipLaunchKernelGGL(k_bn_bwd_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial,
-                           parts, APPLY_ROWS, G + d.bn, G + d.bn + d.N, st);
+        if (d.M <= BN_SMALL_ROWS) {
+            hipLaunchKernelGGL(k_bn_bwd_small, dim3(d.N / BN_COLS), dim3(256), 0, s, bn, G + d.bn, G + d.bn + d.N, st);
+        } else {
+            hipLaunchKernelGGL((k_colreduce<1>), dim3(d.N / BN_COLS, parts), dim3(256), 0, s, bn, rpb, t->partial, st);
+            hipLaunchKernelGGL(k_bn_bwd_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial,
+                               parts, APPLY_ROWS, G + d.bn, G + d.bn + d.N, st);
+        }
         // The gradient of a bias in front of a BatchNorm is identically zero (the batch mean absorbs it); the kernels
         // leave those slots at 0 instead of the rounding residue a column sum of dz would give, which Adam would
         // turn into a random walk of size lr.
         if (g3) {
             // wgrad: dW [K][N] = A^T dz, both operands transposed so that the contraction (the rows) is contiguous
             const int Mp = (d.M + 63) / 64 * 64;
-            launch_transpose_split(t->dz, d.M, d.N, d.N, t->dzt_hi, t->dzt_lo, Mp, s);
-            launch_transpose_split(d.A, d.M, d.K, d.lda, t->at_hi, t->at_lo, Mp, s);
+            const TransposeJob jz{t->dz, t->dzt_hi, t->dzt_lo, d.N, (d.N + 63) / 64, d.N}, ja{d.A, t->at_hi, t->at_lo, d.K, (d.K + 63) / 64, d.lda};
+            launch_transpose_split2(ja, jz, d.M, Mp, s);          // the big one first
             launch_gemm3(t->at_hi, t->at_lo, Mp, t->dzt_hi, t->dzt_lo, Mp, G + d.w, d.N, nullptr, d.K, d.N, Mp, t->splitk, t->splitk_floats, s);
             // dgrad: d input [M][K] = dz W^T, W [K][N] as stored
             float* din = l >= 4 ? t->dact : t->dcol;
@@ -1164,9 +1304,9 @@ bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards,
     if (hipStreamSynchronize(s) != hipSuccess) return false;      // `c` is a stack object
     auto one_step = [&]() {
         hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, t->step_state, t->counters, b);
-        hipLaunchKernelGGL(k_gather_batch, dim3((b * 92 + 255) / 256), dim3(256), 0, s, all_boards, all_pis, all_vs, d_idx, b, t->bboards,
-                           t->bpis, t->bvs, (const StepState*)t->step_state);
-        enqueue_step(t, h, t->bboards, t->bpis, t->bvs, b, true, s);
+        hipLaunchKernelGGL(k_gather_col1, dim3((b * 42 * 20 + 255) / 256), dim3(256), 0, s, all_boards, all_pis, all_vs, d_idx, b, t->bboards,
+                           t->bpis, t->bvs, t->col[0], (const StepState*)t->step_state);
+        enqueue_step(t, h, t->bboards, t->bpis, t->bvs, b, true, s, true);
     };
     // the step's ~60 launches are captured once and replayed: the epoch is launch-bound otherwise
     hipGraph_t graph = nullptr;
