@@ -15,7 +15,7 @@ import weakref
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libaz_engine.so")
+LIB_PATH = os.environ.get("AZ_ENGINE_LIB") or os.path.join(_PKG, "libaz_engine.so")      # AZ_ENGINE_LIB: A/B of two builds (tools/)
 # The diagnostic twin (built with -DAZ_DIAG): the same ABI plus the superseded kernel generations, forced tiles, clock-stamp builds and
 # timing ablations behind az_set_option.  tools/ and the kernel-family bit-identity tests use it (Engine(diag=True)); nothing else.
 DIAG_LIB_PATH = os.path.join(_PKG, "libaz_engine_diag.so")
