@@ -279,11 +279,10 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, i
 // the ~10 B/clk/CU register-load path): 0.85 of the 1.58 ms step.  The bf16 matrix cores are 16 times faster per product, so every f32
 // operand x is split into two bf16 numbers, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo up to 2^-17 |x|), and
 //     A W  ~=  A_hi W_hi + A_hi W_lo + A_lo W_hi            (the dropped A_lo W_lo term is 2^-16 of a product)
-// is ONE bf16 GEMM over a contraction three times as long -- segments (A_hi, W_hi), (A_hi, W_lo), (A_lo, W_hi) -- accumulated in f32 by
-// the MFMA.  k_gemm3 is the inference side's LDS-DMA ring (az_net.hip gemm_ring_body: asm-issued global_load_lds_dwordx4 into an XOR-
-// swizzled image, two stages, one raw barrier per 64-deep K-step, both 32-deep halves' fragments requested up front) with a plain
-// row-major A, the segment walker, split-K over blockIdx.y and an f32 epilogue; k_splitk_reduce sums the slices in slice order, so a
-// step stays deterministic.  Both operands must be contiguous along the contraction:
+// is three bf16 products per K-step accumulated in f32 by the MFMA.  k_gemm3 is built like the inference side's LDS-DMA kernels (asm-issued
+// global_load_lds_dwordx4 into a swizzled image, two stages, one raw barrier per K-step) with all four operand tiles of a K-step in one
+// stage, split-K over blockIdx.y and an f32 epilogue; k_splitk_reduce sums the slices in slice order, so a step stays deterministic.
+// Both operands must be contiguous along the contraction:
 //     dgrad     dA = dz W^T    dz [M][N] (written split by k_bn_bwd_apply), W [K][N] as stored (k_split_weights)
 //     wgrad     dW = A^T dz    A^T [K][M'] and dz^T [N][M'] (k_transpose_split: f32 in, hi / lo out; M' = M rounded up to 64, zero-filled)
 // THE FORWARD GEMMS STAY ON THE f32 KERNEL: a 2^-17 error in a pre-activation flips the ReLU (and the dropout-free BatchNorm sign) of the
@@ -318,16 +317,21 @@ struct Gemm3 {
     const float* bias;
     int M, N, Kc;                   // Kc % 64 == 0, N % 128 == 0
     int lda, ldw, ldo;
-    int steps_per_split;            // 64-deep K-steps of the 3 * Kc / 64 per blockIdx.y
+    int steps_per_split;            // 32-deep K-steps (of Kc / 32) per blockIdx.y
     int splits;
     int xcd_rows;                   // workgroup id -> tile mapping (k_gemm3)
 };
 
-constexpr int G3_BM = 128, G3_STAGE = G3_BM * 128 + 16384;
+// One stage = the four operand tiles of one 32-deep K-step -- A_hi, A_lo, W_hi, W_lo, 128 rows x 64 B each = 32 KiB -- shared by the step's
+// three products (48 MFMAs per wave); two stages, two workgroups per CU.  (Walking the products as three K segments re-loaded A_hi and
+// W_hi: 48 KiB for the same MFMAs, and the kernel is bound by that L2 -> LDS traffic.)  Rows of 64 bytes are four 16-byte k chunks; chunk q
+// of row r sits at position q ^ F(r), F = {0, 2, 3, 1}[(r >> 2) & 3], which makes the ds_read_b128 fragment reads conflict-free
+// (k_gemm_f32_dma's A tile has the same geometry).
+constexpr int G3_BM = 128, G3_TILE = 128 * 64, G3_STAGE = 4 * G3_TILE;
 
 __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G3_STAGE];
-    constexpr int MT = G3_BM / 32, NDMA = MT + 4;
+    constexpr int MT = G3_BM / 32;
     const int NT = g.N / 128;
     const int id = blockIdx.x;
     int ntile, mtile;
@@ -342,76 +346,80 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
-    uint32_t a_ob[MT];
+    // DMA map: a tile is 8 pieces of 16 rows; wave w loads pieces w and w + 4; lane -> row lane >> 2, position lane & 3 holding chunk
+    // (lane & 3) ^ F(row)
+    const uint32_t fD = (0x78u >> ((((uint32_t)lane >> 4) & 3u) * 2u)) & 3u;
+    const uint32_t chunk = ((uint32_t)lane & 3u) ^ fD;
+    uint32_t a_ob[2], b_ob[2];
 #pragma unroll
-    for (int q = 0; q < MT; ++q) {
-        int m = m0 + (q * 4 + wave) * 8 + lrow;
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + (wave + 4 * i) * 16 + (lane >> 2);
         m = m < g.M ? m : g.M - 1;
-        a_ob[q] = (uint32_t)(m * g.lda + chunk * 8) * 2u;
+        a_ob[i] = (uint32_t)(m * g.lda + (int)chunk * 8) * 2u;
+        b_ob[i] = (uint32_t)((n0 + (wave + 4 * i) * 16 + (lane >> 2)) * g.ldw + (int)chunk * 8) * 2u;
     }
-    const uint32_t b_ob = (uint32_t)((n0 + wave * 8 + lrow) * g.ldw + chunk * 8) * 2u;
-    const size_t w_stride = (size_t)64 * g.ldw;           // 32 rows, in bytes
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
-    // K-step walker over the three segments (scalars only)
-    const int spk = g.Kc / 64;                            // steps per segment
     const int t0 = blockIdx.y * g.steps_per_split;
-    const int t1 = min(3 * spk, t0 + g.steps_per_split);
-    const int nk = t1 - t0;
-    int seg = t0 / spk, kin = t0 - seg * spk;
+    const int nk = min(g.Kc / 32, t0 + g.steps_per_split) - t0;
+    int kin = t0;
 #define AZ_G3DMA(buf_)                                                                                  \
     {                                                                                                   \
-        const char* abase = (const char*)((seg == 2 ? g.a_lo : g.a_hi) + kin * 64);                     \
-        const char* wbase = (const char*)((seg == 1 ? g.w_lo : g.w_hi) + kin * 64);                     \
+        const char* ah = (const char*)(g.a_hi + kin * 32);                                              \
+        const char* al = (const char*)(g.a_lo + kin * 32);                                              \
+        const char* wh = (const char*)(g.w_hi + kin * 32);                                              \
+        const char* wl = (const char*)(g.w_lo + kin * 32);                                              \
         const uint32_t la = lds0 + (buf_) * G3_STAGE;                                                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < MT; ++q_) train_dma16(abase, a_ob[q_], la + q_ * 4096); \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) train_dma16(wbase + q_ * w_stride, b_ob, la + G3_BM * 128 + q_ * 4096); \
-        if (++kin == spk) { kin = 0; ++seg; }                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
+            train_dma16(ah, a_ob[i_], la + i_ * 4096);                                                  \
+            train_dma16(al, a_ob[i_], la + G3_TILE + i_ * 4096);                                        \
+            train_dma16(wh, b_ob[i_], la + 2 * G3_TILE + i_ * 4096);                                    \
+            train_dma16(wl, b_ob[i_], la + 3 * G3_TILE + i_ * 4096);                                    \
+        }                                                                                               \
+        ++kin;                                                                                          \
     }
     f32x4 acc[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int coff = (fq ^ (int)((0x78u >> ((((uint32_t)frow >> 2) & 3u) * 2u)) & 3u)) << 4;
+    const int a_row = (wr * (G3_BM / 2) + frow) * 64 + coff, b_row = (wc * 64 + frow) * 64 + coff;
     if (nk > 0) AZ_G3DMA(0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stage kt has landed (the only one in flight)
         __builtin_amdgcn_s_barrier();                        // ... for every wave, and every wave is done with stage kt-1's buffer
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) AZ_G3DMA((kt + 1) & 1);
-        const unsigned char* sA = smem + (kt & 1) * G3_STAGE;
-        const unsigned char* sB = sA + G3_BM * 128;
-        const int coff0 = ((0 + fq) ^ fsw) << 4, coff1 = ((4 + fq) ^ fsw) << 4;
-        bf16x8_t fa0[MT], fb0[4], fa1[MT], fb1[4];
+        const unsigned char* sAh = smem + (kt & 1) * G3_STAGE;
+        const unsigned char* sAl = sAh + G3_TILE;
+        const unsigned char* sWh = sAh + 2 * G3_TILE;
+        const unsigned char* sWl = sAh + 3 * G3_TILE;
+        bf16x8_t ah[MT], al[MT], wh[4], wl[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa0[mt] = *(const bf16x8_t*)(sA + (wr * (G3_BM / 2) + mt * 16 + frow) * 128 + coff0);
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const bf16x8_t*)(sAh + a_row + mt * 1024);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) fb0[nt] = *(const bf16x8_t*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff0);
+        for (int nt = 0; nt < 4; ++nt) wh[nt] = *(const bf16x8_t*)(sWh + b_row + nt * 1024);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa1[mt] = *(const bf16x8_t*)(sA + (wr * (G3_BM / 2) + mt * 16 + frow) * 128 + coff1);
+        for (int nt = 0; nt < 4; ++nt) wl[nt] = *(const bf16x8_t*)(sWl + b_row + nt * 1024);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) fb1[nt] = *(const bf16x8_t*)(sB + (wc * 64 + nt * 16 + frow) * 128 + coff1);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nt], fa0[mt], acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const bf16x8_t*)(sAl + a_row + mt * 1024);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt], fa1[mt], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MT + 4, 0);
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-        for (int gi = 0; gi < MT + 4; ++gi) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MT - (MT + 4), 0);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], al[mt], acc[mt][nt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef AZ_G3DMA
-    (void)NDMA;
     // f32 epilogue: a lane holds 4 consecutive columns of one row
     float* obase = g.splits > 1 ? g.out + (size_t)blockIdx.y * g.M * g.N : g.out;
     const int ldo = g.splits > 1 ? g.N : g.ldo;
@@ -1156,7 +1164,7 @@ int red_parts(int M) { return std::max(1, std::min(RED_PARTS, (M + 63) / 64)); }
 void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* out, int ldo,
                   const float* bias, int M, int N, int Kc, float* ws, size_t ws_floats, hipStream_t s) {
     const int mt = (M + G3_BM - 1) / G3_BM, NT = N / 128, tiles = mt * NT;
-    const int steps = 3 * (Kc / 64);
+    const int steps = Kc / 32;
     int splits = std::max(1, std::min((512 + tiles / 2) / tiles, steps / 8));
     while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
     const int sps = (steps + splits - 1) / splits;
