@@ -638,6 +638,11 @@ def test_second_game_through_the_seam(engine_mod, oracle):
             _compare_selfplay(e.selfplay(n_games=n, num_sims=sims, model_id=10, seed=5, concurrent=40), ref)
             wld, res = e.arena(num_games=16, num_sims=25, new_model_id=10, old_model_id=11, seed=9)
             assert np.array_equal(wld, owld) and np.array_equal(res, ores)
+        # the second game with several simulations in flight per tree (the lock-step schedule is a template over the Game policy too)
+        e.set_option("eval_dedup", 1)
+        e.set_option("fused_search", 1)
+        ref_t = oracle.selfplay(n, 24, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=6, threads=8, game_kind=oracle.GAME_CONNECT3, sim_threads=4)
+        _compare_selfplay(e.selfplay(n_games=n, num_sims=24, model_id=10, seed=6, concurrent=40, num_sim_threads=4), ref_t)
         # fine-grained entry: one search from a position where three in a row is one move away for the side to move
         s = (0, 0)
         for a in (0, 6, 0, 5):
