@@ -1,6 +1,6 @@
 // examples/connect_four.rs (src lines 45-80) on the C++ host: the same Coach::setup parameters, the engine behind it.
-// Build:  g++ -std=c++17 -O2 -I include examples/connect_four.cpp -o connect_four -L alphazero-rs_amd -laz_engine \
-//             -Wl,-rpath,$PWD/alphazero-rs_amd
+// Build:  g++ -std=c++17 -O2 -I include examples/connect_four.cpp -o connect_four -L alphazero-rs_amd -laz_engine
+//         (and -Wl,-rpath,$PWD/alphazero-rs_amd)
 // Run:    ./connect_four ./checkpoint [num_iters] [num_eps] [num_sims] [num_arena_games]
 #include <cstdio>
 #include <cstdlib>
