@@ -825,12 +825,22 @@ az_status az_get_stats(az_engine* e, az_stats* out) {
     out->net_fc_flops = e->netprof.fc_flops;
     out->net_rows_timed = e->netprof.rows;
     out->tree_arena_allocs = e->tree_pool_allocs;
+    {
+        unsigned long long acct[2] = {0, 0};
+        (void)hipSetDevice(e->device);
+        for (NetWorkspace* w : e->ws) if (w && !netws_conv3_accounting(w, acct, false)) return fail(e, AZ_ERR_HIP, "az_get_stats: reading the conv3 accounting");
+        out->net_conv3_image_rows = acct[0];
+        out->net_conv3_image_launches = acct[1];
+    }
     return AZ_OK;
 }
 az_status az_reset_stats(az_engine* e) {
     if (!e) return AZ_ERR_BAD_ARGUMENT;
     e->stats = az_stats{};
     e->netprof = NetProfile{};
+    unsigned long long sink[2] = {0, 0};
+    (void)hipSetDevice(e->device);
+    for (NetWorkspace* w : e->ws) if (w && !netws_conv3_accounting(w, sink, true)) return fail(e, AZ_ERR_HIP, "az_reset_stats: clearing the conv3 accounting");
     return AZ_OK;
 }
 

@@ -63,6 +63,8 @@ bool convnet_get_params(const ConvNet* n, float* host_params, int64_t count);
 void convnet_init_random(ConvNet* n, uint64_t seed);
 // fold finished profile records into *prof (call after the workspace's stream has been synchronised)
 void netws_resolve_profile(NetWorkspace* ws, NetProfile* prof);
+// k_conv3_auto's device-side accounting: adds (rows, working launches) since the last reset to out[2]; reset clears it
+bool netws_conv3_accounting(NetWorkspace* ws, unsigned long long out[2], bool reset);
 // Kernel-set switches of the conv net (az_set_option).  They live in the az_engine that was handed to az_set_option and are passed
 // down with every forward: one engine's option never changes another engine's results.  The shipped library (built without
 // -DAZ_DIAG) only honours conv2_table 0 / 1 and conv3_small 0 / 1; everything else selects superseded kernel generations, forced tiles,

@@ -274,6 +274,7 @@ struct GemmDesc {
     // estimate cannot tell; exactly one of them finds the batch's row count on its side of the line and runs):
     int m_min;                 // tiled kernels: do nothing when the batch has at most this many output rows (0 = always run)
     int m_max;                 // k_gemm_skinny: do nothing when the batch has more than this many output rows
+    unsigned long long* acct;  // k_conv3_auto: {rows, working launches} it has processed (device counters of the workspace)
     const uint16_t* c3tab;     // conv_valid_tile<.., PLANES>: the LDS image's cell maps (Conv3Tables, built by convnet_prepare's workspace)
 };
 
@@ -1275,6 +1276,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const i
     __shared__ __attribute__((aligned(16))) unsigned char smem[TF::LDS_BYTES];
     const int n_boards = (int)(*d.n_dev);
     if (n_boards * d.rows_per_sample <= d.m_min) return;      // the small-batch kernel launched beside this one takes the batch
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.acct && n_boards > 0) { atomicAdd(&d.acct[0], (unsigned long long)n_boards); atomicAdd(&d.acct[1], 1ull); }
     const int NT = d.N / 128;
     const int tiles8 = ((n_boards + C3_NB - 1) / C3_NB + 7) / 8 * 8;
     const int wid = tiles8 * NT;                       // workgroup ids that map to a tile of this batch (the last group of 8 row tiles may be partly empty)
@@ -1540,6 +1542,7 @@ struct NetWorkspace {
     int pinned_cap = 0, pinned_next = 0;
     unsigned long long* dbg = nullptr;     // [2048] clock stamps of the diagnostic variant
     uint16_t* c3tab = nullptr;             // Conv3Tables (the PLANES layout of conv3's LDS image)
+    unsigned long long* acct = nullptr;    // [2] k_conv3_auto's rows and working launches
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr;
         if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
@@ -1600,6 +1603,8 @@ NetWorkspace* netws_create(int channels, int max_batch, const char** err) {
     ok &= (n->fc2o = n->dalloc<uint16_t>(B * 512)) != nullptr;
     ok &= (n->dbg = n->dalloc<unsigned long long>(2048)) != nullptr;
     if (ok) ok = hipMemset(n->dbg, 0, 2048 * 8) == hipSuccess;
+    ok &= (n->acct = n->dalloc<unsigned long long>(2)) != nullptr;
+    if (ok) ok = hipMemset(n->acct, 0, 16) == hipSuccess;
     ok &= (n->c3tab = n->dalloc<uint16_t>(C3_TAB_INV + C3_TAB_RD)) != nullptr;
     if (ok) {
         const std::vector<uint16_t> tab = conv3_tables();
@@ -1945,6 +1950,14 @@ static hipEvent_t net_event(NetWorkspace* n) {
     return e;
 }
 
+bool netws_conv3_accounting(NetWorkspace* n, unsigned long long out[2], bool reset) {
+    if (!n || !n->acct) return true;
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, n->acct, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    out[0] += h[0]; out[1] += h[1];
+    return !reset || hipMemset(n->acct, 0, sizeof h) == hipSuccess;
+}
+
 // Resolve finished profile records (call after the workspace's stream is synchronised).
 void netws_resolve_profile(NetWorkspace* n, NetProfile* prof) {
     if (!n) return;
@@ -2021,6 +2034,7 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     d.relu = 1;
     d.dbg = ws->dbg;
     d.c3tab = ws->c3tab;
+    d.acct = ws->acct;
     // conv2: 3x3 same over the haloed [8][9][C] image (or the conv1 table) -> [6][7][C]
     d.A = table ? n->t1 : ws->act1; d.states = table ? eb.state : nullptr;
     d.W = n->wg[0]; d.bias = n->bg[0]; d.out = ws->act2;

@@ -54,7 +54,7 @@ class az_stats(C.Structure):
                [(n, C.c_double) for n in ("net_conv3_ms", "net_conv3_flops", "net_conv2_bytes")] + \
                [(n, C.c_uint64) for n in ("tree_launches", "tree_launches_timed", "tree_arena_allocs")] + \
                [(n, C.c_double) for n in ("net_conv4_ms", "net_conv4_flops", "net_fc_ms", "net_fc_flops", "net_rows_timed")] + \
-               [("abandoned_sims", C.c_uint64)]
+               [("abandoned_sims", C.c_uint64), ("net_conv3_image_rows", C.c_uint64), ("net_conv3_image_launches", C.c_uint64)]
 
 
 class az_selfplay_params(C.Structure):

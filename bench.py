@@ -383,6 +383,12 @@ def main():
                         "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{src}: bytes per executed row x "
                                         "this run's mean rows per launch)",
                         "avg_launch_ms": st["net_conv3_ms"] / st["net_launches"], "avg_flop_per_launch": st["net_conv3_flops"] / st["net_launches"],
+                        # exact, counted on the device over EVERY forward of the timed region (not the sampled ones): what a profiler's
+                        # total k_conv3_auto time has to be divided by (the smallest batches run conv3 on the ring / skinny kernels, and the
+                        # idle half of a dual launch does no work)
+                        "k_conv3_auto_accounting": {"rows": st["net_conv3_image_rows"], "working_launches": st["net_conv3_image_launches"],
+                                                    "rows_per_working_launch": st["net_conv3_image_rows"] / max(1, st["net_conv3_image_launches"]),
+                                                    "flop_per_row": 2.0 * 20 * 512 * 4608},
                         **common}
                 gb = st["net_conv2_bytes"] / (st["net_conv2_ms"] * 1e-3) / 1e9
                 line["conv2_table"] = {"bound": "hbm", "kernel": "k_conv2_table_x (conv1 + conv2 as nine gathered rows of the per-model U table per output "

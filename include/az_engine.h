@@ -113,6 +113,10 @@ typedef struct az_stats {
     double net_rows_timed;         /* executed rows of the timed forwards (profile mode) */
     uint64_t abandoned_sims;     /* num_threads > 1 only: simulations abandoned where the reference has no legal continuation
                                   * (every child Locked, src/node.rs:366-367; a link into a Locked node, :354); counted in `simulations` */
+    uint64_t net_conv3_image_rows;      /* rows (boards) conv3 processed on the image-resident kernel k_conv3_auto, counted on the device ... */
+    uint64_t net_conv3_image_launches;  /* ... and the launches of it that did that work (a launch that finds the batch on the small-batch
+                                         * kernel's side of the hand-over exits at once and is not counted): what a profiler's average
+                                         * duration of k_conv3_auto has to be divided into.  Always on (two atomics per launch). */
 } az_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */

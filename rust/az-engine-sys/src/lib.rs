@@ -26,7 +26,7 @@ pub struct az_stats {
     pub eval_cache_inserts: u64, pub net_conv3_ms: f64, pub net_conv3_flops: f64, pub net_conv2_bytes: f64,
     pub tree_launches: u64, pub tree_launches_timed: u64, pub tree_arena_allocs: u64,
     pub net_conv4_ms: f64, pub net_conv4_flops: f64, pub net_fc_ms: f64, pub net_fc_flops: f64, pub net_rows_timed: f64,
-    pub abandoned_sims: u64,
+    pub abandoned_sims: u64, pub net_conv3_image_rows: u64, pub net_conv3_image_launches: u64,
 }
 
 #[repr(C)] #[derive(Clone, Copy)]

@@ -27,7 +27,7 @@ def test_struct_layouts_match_header(engine_mod):
     assert ctypes.sizeof(engine_mod.az_selfplay_params) == 64
     assert ctypes.sizeof(engine_mod.az_samples) == 64
     assert ctypes.sizeof(engine_mod.az_arena_params) == 80
-    assert ctypes.sizeof(engine_mod.az_stats) == 34 * 8
+    assert ctypes.sizeof(engine_mod.az_stats) == 36 * 8
 
 
 def test_no_gpu_fails_loudly(engine_mod):

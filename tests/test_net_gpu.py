@@ -498,6 +498,23 @@ def test_replay_parity_lockstep_threads_with_the_conv_net(engine, oracle):
         assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
 
 
+def test_conv3_image_kernel_accounting(engine, oracle):
+    """az_stats.net_conv3_image_rows / _launches: what the image-resident conv3 kernel really processed, counted on the device -- a big
+    batch is one working launch with all its rows, a small batch (the skinny / ring kernels take it) none."""
+    engine.net_init_random(28, seed=3)
+    states = random_states(oracle, 4000, seed=77)
+    engine.reset_stats()
+    engine.predict_states(states, 28)
+    st = engine.stats()
+    assert (st["net_conv3_image_rows"], st["net_conv3_image_launches"]) == (4000, 1)
+    engine.predict_states(states[:13], 28)
+    engine.predict_states(states[:3000], 28)
+    st = engine.stats()
+    assert (st["net_conv3_image_rows"], st["net_conv3_image_launches"]) == (7000, 2)
+    engine.reset_stats()
+    assert engine.stats()["net_conv3_image_rows"] == 0
+
+
 def test_set_option_is_per_engine(engine_mod, oracle):
     """az_set_option changes the handle it is given and nothing else: two engines in one process, one with conv2 as the MFMA
     GEMM ("conv2_table" = 0: a different rounding of the same function) and the older kernel families, interleaved
