@@ -530,7 +530,9 @@ def main():
                 ea = azeng.Engine(device=local_rank, max_batch=4096, net_channels=args.channels, profile=False)
                 ea.net_set_params(0, e.net_get_params(0))
                 ea.net_init_random(2, seed=args.seed + 1)
-                ea.arena(num_games=64, num_sims=50, new_model_id=2, old_model_id=0, seed=args.seed)       # warm-up: arenas, graphs
+                # warm-up with the SAME shape (like the warm-up steps of the self-play measurement): the tree arenas of 2 x 4096 trees are
+                # allocated and the search graphs captured once per shape and kept (Coach::learn plays an arena of this shape every iteration)
+                ea.arena(num_games=4096, num_sims=400, new_model_id=2, old_model_id=0, seed=args.seed + 7)
                 ea.reset_stats()
                 t1 = time.perf_counter()
                 wld, _res = ea.arena(num_games=4096, num_sims=400, new_model_id=2, old_model_id=0, seed=args.seed)
@@ -540,8 +542,9 @@ def main():
                 line["arena"] = {"games_per_sec": 4096 / dta, "seconds": dta, "games": 4096, "sims_per_move": 400, "wld_new_model": [int(x) for x in wld],
                                  "simulations_per_sec": sa["simulations"] / dta,
                                  "leaf_rows_executed_over_requested": sa["leaf_rows_executed"] / max(1, sa["leaf_rows_requested"]),
-                                 "note": "temp 0 from the first move (src/coach.rs:356-372): games of one seating differ only where the "
-                                         "tie-break RNG does, so most leaf rows are duplicates the evaluation cache answers"}
+                                 "note": "after one warm-up arena of the same shape (arena allocation, graph capture); temp 0 from the first move "
+                                         "(src/coach.rs:356-372): games of one seating differ only where the tie-break RNG does, so most leaf "
+                                         "rows are duplicates the evaluation cache answers"}
             except Exception as ex:
                 line["arena"] = {"error": repr(ex)}
             # (c) BASELINE config 1 as the fine-grained drop-in: one az_tree of ONE game behind az_host::AsyncMcts::get_action_prob,
