@@ -300,6 +300,21 @@ struct az_engine {
     // communicator of the sharded Coach loop (az_comm_init): RCCL on the engine's stream
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    // staging of the collectives (az_gather_samples, az_allreduce_u64): one device allocation that only grows
+    struct Scratch {
+        void* p = nullptr;
+        size_t cap = 0;
+        void* ensure(size_t bytes, hipStream_t s) {
+            if (bytes <= cap) return p;
+            HIPCHK(hipStreamSynchronize(s));
+            if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+            const size_t want = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 16);
+            HIPCHK(hipMalloc(&p, want));
+            cap = want;
+            return p;
+        }
+        ~Scratch() { if (p) (void)hipFree(p); }
+    } comm_scratch;
 };
 
 struct az_tree {
@@ -650,6 +665,15 @@ az_status check_batch(az_engine* e, const NetModel& net, int trees) {
     return AZ_OK;
 }
 
+// Is a caller-supplied pointer device (or managed) memory?  Plain host memory is unknown to the runtime: the query fails and the
+// sticky error is cleared.
+bool on_device(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
 struct ScopedTimer {
     az_engine* e;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -741,6 +765,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("conv3_ring") && value >= 0 && value <= 3) { o.conv3_ring = (int)value; return AZ_OK; }
     if (is("conv2_pipe") && (value == 0 || value == 1)) { o.conv2_pipe = (int)value; return AZ_OK; }
     if (is("conv3_pipe") && ((value >= 0 && value <= 3) || (value >= 9 && value <= 15))) { o.conv3_pipe = (int)value; return AZ_OK; }
+    if (is("conv3_pp") && (value == 0 || value == 1 || (value >= 16 && value <= 40))) { o.conv3_pp = (int)value; return AZ_OK; }
     if (is("conv1_table") && (value == 0 || value == 1)) { o.conv1_table = (int)value; return AZ_OK; }
     if (is("conv4_big") && value >= 0 && value <= 2) { o.conv4_big = (int)value; return AZ_OK; }
     if (is("tree_stamps") && (value == 0 || value == 1)) { return tree_set_stamps((int)value) ? AZ_OK : fail(e, AZ_ERR_HIP, "tree_set_stamps"); }
@@ -776,6 +801,23 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
         e->err = out;
         return AZ_OK;
     }
+    if (is("print_pp_stamps")) {
+        // conv3_pp 36 / 37: per-segment cycle sums of waves 0 (group 0) and 4 (group 1) of the first 128 workgroups, median over blocks
+        std::vector<unsigned long long> st(2048);
+        if (!e->ws[0] || !netws_read_clock_stamps(e->ws[0], st.data())) return fail(e, AZ_ERR_BAD_ARGUMENT, "no workspace");
+        std::string out;
+        for (int i = 0; i < 16; ++i) {
+            std::vector<unsigned long long> v;
+            for (int b = 0; b < 128; ++b) if (st[16 * b + 7]) v.push_back(st[16 * b + i]);
+            if (v.empty()) return fail(e, AZ_ERR_BAD_ARGUMENT, "no stamps (run a forward with conv3_pp 36 first)");
+            std::sort(v.begin(), v.end());
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "%s%llu", i ? " " : "", v[v.size() / 2]);
+            out += buf;
+        }
+        e->err = out;
+        return AZ_OK;
+    }
     if (is("print_tree_stamps")) {
         // "tree_stamps" = 1: cycles per phase of the last k_backup_select launch, median over its waves:
         // load head+path | backup | wait for its stores | select | leaf request | store head+path | whole kernel
@@ -797,8 +839,8 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
 #else
     // the diagnostic keys exist in libaz_engine_diag.so only; their DEFAULT value is accepted here so that a caller resetting them is not an error
     static const struct { const char* k; int64_t dflt; } diag_keys[] = {{"gemm_variant", 5}, {"fc_ring", 1}, {"conv3_ring", 0}, {"conv2_pipe", 1},
-                                                                         {"conv3_pipe", 1}, {"conv1_table", 1}, {"conv4_big", 0}, {"tree_stamps", 0}};
-    bool diag_key = is("print_clock_stamps") || is("print_seg_stamps") || is("print_tree_stamps") || (is("conv2_table") && value == 2);
+                                                                         {"conv3_pipe", 1}, {"conv1_table", 1}, {"conv4_big", 0}, {"tree_stamps", 0}, {"conv3_pp", 0}};
+    bool diag_key = is("print_clock_stamps") || is("print_seg_stamps") || is("print_pp_stamps") || is("print_tree_stamps") || (is("conv2_table") && value == 2);
     if (is("ring_tile")) { if (value >= 30000 && value < 60000 && value % 10000 == 0) return AZ_OK; diag_key = true; }
     for (const auto& dk : diag_keys)
         if (is(dk.k)) { if (value == dk.dflt) return AZ_OK; diag_key = true; }
@@ -1241,8 +1283,14 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
         HIPCHK(hipSetDevice(e->device));
         TreeDev& d = t->th.d;
         const int G = d.G;
-        std::memcpy(t->h_states, states, (size_t)G * 16);
-        HIPCHK(hipMemcpyAsync(t->d_root_states, t->h_states, (size_t)G * 16, hipMemcpyHostToDevice, e->stream));
+        // include/az_engine.h: caller pointers may be host or device memory.  Host memory takes the pinned fast path (one stream
+        // synchronisation per call); device memory is copied by the runtime.
+        if (on_device(states)) {
+            HIPCHK(hipMemcpyAsync(t->d_root_states, states, (size_t)G * 16, hipMemcpyDeviceToDevice, e->stream));
+        } else {
+            std::memcpy(t->h_states, states, (size_t)G * 16);
+            HIPCHK(hipMemcpyAsync(t->d_root_states, t->h_states, (size_t)G * 16, hipMemcpyHostToDevice, e->stream));
+        }
         launch_set_active(d, 1u, e->stream);
         SearchParams sp{(uint32_t)t->max_depth, (float)t->cpuct};
         prepare_cache(e, dedup_applies(e, *net), (uint64_t)G * ((uint64_t)t->num_sims + 1), e->stream);
@@ -1257,9 +1305,13 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
         e->stats.moves += (uint64_t)G;
         st = report_tree_errors(e, t->th, t->h_rb->err);
         if (st) return st;
-        std::memcpy(pi, t->h_pi, (size_t)G * 7 * sizeof(float));
-        if (counts) std::memcpy(counts, t->h_counts, (size_t)G * 7 * sizeof(uint16_t));
-        if (q) std::memcpy(q, t->h_q, (size_t)G * 7 * sizeof(float));
+        auto copy_out = [&](void* dst, const void* src, size_t bytes) {
+            if (on_device(dst)) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+            else std::memcpy(dst, src, bytes);
+        };
+        copy_out(pi, t->h_pi, (size_t)G * 7 * sizeof(float));
+        if (counts) copy_out(counts, t->h_counts, (size_t)G * 7 * sizeof(uint16_t));
+        if (q) copy_out(q, t->h_q, (size_t)G * 7 * sizeof(float));
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
@@ -1430,8 +1482,11 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
     const int G = sharded ? p->num_games : 2 * half;
     const int first = sharded ? p->first_game : 0;
     out_wld[0] = out_wld[1] = out_wld[2] = 0;
+    // a host that asks for the whole arena's tally but never bound a communicator would gate the model on its own shard's count
+    if (p->allreduce_wld && (!sharded || !e->comm))
+        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: allreduce_wld needs a sharded call (total_games > 0) on an engine with a communicator (az_comm_init)");
     if (G == 0) {      // an empty shard still takes part in the tally's all-reduce
-        if (sharded && p->allreduce_wld && e->comm) return az_allreduce_u64(e, out_wld, 3);
+        if (p->allreduce_wld) return az_allreduce_u64(e, out_wld, 3);
         return AZ_OK;
     }
     if (G > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_arena: at most 65536 games");
@@ -1452,6 +1507,7 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
             if (results && hipMemcpy(results, res.data(), (size_t)G, hipMemcpyDefault) != hipSuccess) return fail(e, AZ_ERR_HIP, "az_arena: results copy");
             e->stats.games += (uint64_t)G;
             e->ar_log_cap = 0;
+            if (p->allreduce_wld) return az_allreduce_u64(e, out_wld, 3);     // the shards' tallies, as on the played path
             return AZ_OK;
         }
     }
@@ -1565,7 +1621,7 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         }
         if (results) HIPCHK(hipMemcpy(results, res.data(), G, hipMemcpyDefault));
         e->stats.games += (uint64_t)G;
-        if (sharded && p->allreduce_wld && e->comm) {       // every rank returns the whole arena's tally (one 3-counter all-reduce)
+        if (p->allreduce_wld) {       // every rank returns the whole arena's tally (one 3-counter all-reduce)
             az_status rs = az_allreduce_u64(e, out_wld, 3);
             if (rs) return rs;
         }
@@ -1643,8 +1699,7 @@ az_status az_allreduce_u64(az_engine* e, uint64_t* values, int32_t n) {
     if (n == 0) return AZ_OK;
     try {
         HIPCHK(hipSetDevice(e->device));
-        DeviceMem mem;
-        unsigned long long* d = mem.alloc<unsigned long long>((size_t)n);
+        unsigned long long* d = (unsigned long long*)e->comm_scratch.ensure((size_t)n * 8, e->stream);
         HIPCHK(hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
         NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, ncclUint64, ncclSum, e->comm, e->stream));
         HIPCHK(hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
@@ -1653,36 +1708,65 @@ az_status az_allreduce_u64(az_engine* e, uint64_t* values, int32_t n) {
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
 
+// The episode-batch exchange.  EVERY decision that could make one rank leave early is taken from data every rank holds: the first
+// collective carries, per rank, its tuple count (or -1: its local buffers are unusable), the capacity it can receive into (-1: not a
+// receiver, -2: receive buffers unusable) and its dst_rank -- so either every rank posts its part of the grouped exchange or every rank
+// returns the same error without posting anything.  (Round 3's version returned on the receiving rank alone and left its peers
+// waiting in ncclGroupEnd.)
 az_status az_gather_samples(az_engine* e, const az_samples* local, int32_t dst_rank, az_samples* gathered, int64_t* counts_out) {
     if (!e || !local) return AZ_ERR_BAD_ARGUMENT;
     if (!e->comm) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: no communicator (az_comm_init)");
     const int world = e->comm_world, rank = e->comm_rank;
-    if (dst_rank < -1 || dst_rank >= world) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: dst_rank outside the communicator");
-    const bool receiver = dst_rank < 0 || rank == dst_rank;         // dst_rank = -1: every rank receives (all-gather)
-    const long long n = local->count;
-    if (n < 0 || (n > 0 && (!local->states || !local->pis || !local->zs)))
-        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: local needs states, pis and zs");
-    if (receiver && (!gathered || !gathered->states || !gathered->pis || !gathered->zs))
-        return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: a receiving rank needs states, pis and zs to receive into");
+    long long n = local->count;
+    const bool dst_ok = dst_rank >= -1 && dst_rank < world;
+    const bool receiver = dst_ok && (dst_rank < 0 || rank == dst_rank);         // dst_rank = -1: every rank receives (all-gather)
+    const bool local_ok = dst_ok && n >= 0 && (n == 0 || (local->states && local->pis && local->zs));
+    const bool recv_ok = !receiver || (gathered && gathered->states && gathered->pis && gathered->zs && gathered->capacity >= 0);
+    struct Hello { long long n, cap, dst, pad; };
+    const Hello mine{local_ok ? n : -1, !receiver ? -1 : (recv_ok ? gathered->capacity : -2), dst_rank, 0};
+    if (!local_ok) n = 0;
+    struct GroupGuard {          // an error between GroupStart and GroupEnd must not leave the group open
+        bool open = false;
+        ~GroupGuard() { if (open) (void)g_rccl.GroupEnd(); }
+    } group;
     try {
         HIPCHK(hipSetDevice(e->device));
         hipStream_t s = e->stream;
-        DeviceMem mem;
-        // 1. all-gather of the per-rank tuple counts
-        long long* d_counts = mem.alloc<long long>((size_t)world + 1);
-        HIPCHK(hipMemcpyAsync(d_counts + world, &n, sizeof n, hipMemcpyHostToDevice, s));
-        NCCLCHK(g_rccl.AllGather(d_counts + world, d_counts, 1, ncclInt64, e->comm, s));
-        std::vector<long long> counts((size_t)world);
-        HIPCHK(hipMemcpyAsync(counts.data(), d_counts, (size_t)world * sizeof(long long), hipMemcpyDeviceToHost, s));
+        // one allocation, kept by the engine and grown on demand (it was five to nine hipMalloc / hipFree pairs per call):
+        // [hello x (world + 1)] [st | pi | z | packed] of the local tuples; the receive side is carved once the total is known
+        const size_t hello_b = ((size_t)world + 1) * sizeof(Hello);
+        const size_t local_b = (size_t)n * (16 + 28 + 4 + sizeof(PackedSample));
+        char* base = (char*)e->comm_scratch.ensure(hello_b + local_b + 256, s);
+        Hello* d_hello = (Hello*)base;
+        // 1. all-gather of the per-rank hello records (count, receive capacity, dst_rank)
+        HIPCHK(hipMemcpyAsync(d_hello + world, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+        NCCLCHK(g_rccl.AllGather(d_hello + world, d_hello, sizeof(Hello), ncclUint8, e->comm, s));
+        std::vector<Hello> hello((size_t)world);
+        HIPCHK(hipMemcpyAsync(hello.data(), d_hello, (size_t)world * sizeof(Hello), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         long long total = 0;
-        for (int r = 0; r < world; ++r) { if (counts_out) counts_out[r] = counts[r]; total += counts[r]; }
-        if (receiver && gathered->capacity < total) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: gathered buffers too small");
+        int bad_local = -1, bad_recv = -1, bad_dst = -1;
+        for (int r = 0; r < world; ++r) {
+            if (hello[r].n < 0) { if (bad_local < 0) bad_local = r; } else total += hello[r].n;
+            if (hello[r].dst != hello[0].dst || hello[r].dst < -1 || hello[r].dst >= world) { if (bad_dst < 0) bad_dst = r; }
+        }
+        for (int r = 0; r < world; ++r) {
+            if (counts_out) counts_out[r] = hello[r].n < 0 ? 0 : hello[r].n;
+            if (hello[r].cap == -2 || (hello[r].cap >= 0 && hello[r].cap < total)) { if (bad_recv < 0) bad_recv = r; }
+        }
+        // the same verdict on every rank, before anything is posted
+        if (bad_dst >= 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: dst_rank outside the communicator or not the same on every rank (rank " + std::to_string(bad_dst) + ")");
+        if (bad_local >= 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: rank " + std::to_string(bad_local) + "'s local tuples need states, pis and zs");
+        if (bad_recv >= 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_gather_samples: rank " + std::to_string(bad_recv) + "'s gathered buffers are missing or too small for " + std::to_string(total) + " tuples");
         // 2. pack this rank's tuples (inputs may be host or device memory)
-        ulonglong2* d_st = mem.alloc<ulonglong2>((size_t)n);
-        float* d_pi = mem.alloc<float>((size_t)n * 7);
-        float* d_z = mem.alloc<float>((size_t)n);
-        PackedSample* d_mine = mem.alloc<PackedSample>((size_t)n);
+        const size_t recv_b = receiver ? (size_t)total * (sizeof(PackedSample) + 16 + 28 + 4) : 0;
+        base = (char*)e->comm_scratch.ensure(hello_b + local_b + recv_b + 512, s);      // may move: nothing of step 1 is needed any more
+        char* cur = base + hello_b;
+        auto carve = [&](size_t bytes) { char* q = cur; cur += (bytes + 63) / 64 * 64; return q; };
+        ulonglong2* d_st = (ulonglong2*)carve((size_t)n * 16);
+        float* d_pi = (float*)carve((size_t)n * 28);
+        float* d_z = (float*)carve((size_t)n * 4);
+        PackedSample* d_mine = (PackedSample*)carve((size_t)n * sizeof(PackedSample));
         if (n > 0) {
             HIPCHK(hipMemcpyAsync(d_st, local->states, (size_t)n * 16, hipMemcpyDefault, s));
             HIPCHK(hipMemcpyAsync(d_pi, local->pis, (size_t)n * 28, hipMemcpyDefault, s));
@@ -1690,29 +1774,32 @@ az_status az_gather_samples(az_engine* e, const az_samples* local, int32_t dst_r
             hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_st, d_pi, d_z, d_mine, n);
         }
         // 3. ONE exchange (a grouped gatherv): a receiving rank posts a receive per peer, a sending rank one send per receiver
-        PackedSample* d_all = receiver ? mem.alloc<PackedSample>((size_t)total) : nullptr;
+        PackedSample* d_all = receiver ? (PackedSample*)carve((size_t)total * sizeof(PackedSample)) : nullptr;
         NCCLCHK(g_rccl.GroupStart());
+        group.open = true;
         long long off = 0;
         for (int r = 0; r < world; ++r) {
+            const long long cr = hello[r].n;
             if (receiver) {
-                if (r != rank && counts[r] > 0) NCCLCHK(g_rccl.Recv(d_all + off, (size_t)counts[r] * sizeof(PackedSample), ncclUint8, r, e->comm, s));
+                if (r != rank && cr > 0) NCCLCHK(g_rccl.Recv(d_all + off, (size_t)cr * sizeof(PackedSample), ncclUint8, r, e->comm, s));
                 if (r == rank && n > 0) HIPCHK(hipMemcpyAsync(d_all + off, d_mine, (size_t)n * sizeof(PackedSample), hipMemcpyDeviceToDevice, s));
             }
             if (r != rank && n > 0 && (dst_rank < 0 || r == dst_rank)) NCCLCHK(g_rccl.Send(d_mine, (size_t)n * sizeof(PackedSample), ncclUint8, r, e->comm, s));
-            off += counts[r];
+            off += cr;
         }
+        group.open = false;
         NCCLCHK(g_rccl.GroupEnd());
         if (receiver) {
-            ulonglong2* o_st = mem.alloc<ulonglong2>((size_t)total);
-            float* o_pi = mem.alloc<float>((size_t)total * 7);
-            float* o_z = mem.alloc<float>((size_t)total);
+            ulonglong2* o_st = (ulonglong2*)carve((size_t)total * 16);
+            float* o_pi = (float*)carve((size_t)total * 28);
+            float* o_z = (float*)carve((size_t)total * 4);
             if (total > 0) hipLaunchKernelGGL(k_unpack_samples, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_all, o_st, o_pi, o_z, total);
-            HIPCHK(hipStreamSynchronize(s));
             if (total > 0) {
-                HIPCHK(hipMemcpy(gathered->states, o_st, (size_t)total * 16, hipMemcpyDefault));
-                HIPCHK(hipMemcpy(gathered->pis, o_pi, (size_t)total * 28, hipMemcpyDefault));
-                HIPCHK(hipMemcpy(gathered->zs, o_z, (size_t)total * 4, hipMemcpyDefault));
+                HIPCHK(hipMemcpyAsync(gathered->states, o_st, (size_t)total * 16, hipMemcpyDefault, s));
+                HIPCHK(hipMemcpyAsync(gathered->pis, o_pi, (size_t)total * 28, hipMemcpyDefault, s));
+                HIPCHK(hipMemcpyAsync(gathered->zs, o_z, (size_t)total * 4, hipMemcpyDefault, s));
             }
+            HIPCHK(hipStreamSynchronize(s));
             gathered->count = total;
         } else {
             HIPCHK(hipStreamSynchronize(s));

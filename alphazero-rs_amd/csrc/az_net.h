@@ -77,6 +77,9 @@ struct NetOptions {
     int narrow_rows = 32;   // conv3 / conv4 / fc1 / fc2 of a batch of at most this many rows (x 2 for conv4, x 4 for the FCs) run as the register-fed
                             // skinny GEMM (k_gemm_skinny), decided on the device from the exact row count; 0 = never (bit-identical)
     // ---- diagnostic library only ----
+    int conv3_pp = 0;       // 1: conv3 as the ping-pong kernel (k_conv3_pp: ONE 8-wave workgroup per CU, 12 boards x 256 channels, the two waves of a
+                            // SIMD alternating LOAD and COMPUTE slots; bit-identical; measured in round 4, not faster: profiles/README.md); 16..40: its
+                            // timing ablations / schedule variants (WRONG results)
     int gemm_variant = 5;   // 0 128x128 register-staged tiles everywhere; 1 / 2 256x256 LDS-DMA tiles; 3 conv2 image-resident, one 8-wave
                             // workgroup per CU; 5 the shipped set; 11-17 timing ablations of variant 2 (WRONG results)
     int conv1_table = 1;    // conv2 as a GEMM gathers its image from the conv1 table (1) / runs k_conv1 into act1 (0)

@@ -276,6 +276,7 @@ struct GemmDesc {
     int m_max;                 // k_gemm_skinny: do nothing when the batch has more than this many output rows
     unsigned long long* acct;  // k_conv3_auto: {rows, working launches} it has processed (device counters of the workspace)
     const uint16_t* c3tab;     // conv_valid_tile<.., PLANES>: the LDS image's cell maps (Conv3Tables, built by convnet_prepare's workspace)
+    const uint16_t* Wp;        // k_conv3_pp: the layer's weights packed as LDS stage images (ConvNet::wp3), nullptr = not available
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -1298,6 +1299,279 @@ __global__ __launch_bounds__(256, 2) void k_conv3_auto(const GemmDesc d, const i
     else conv_valid_tile<C3_NB, 6, 7, 8, 2, PLANES>(d, smem, b0, n0 + half * 64, n_boards);
 }
 
+#ifdef AZ_DIAG
+// ---- conv3 as a PING-PONG kernel: ONE 8-wave workgroup per CU, the two waves of every SIMD in opposite phases ------------------------
+// k_conv3_auto's two independent 4-wave workgroups per CU interleave fragment reads, DMA issue and MFMAs in every wave's in-order
+// stream: the matrix pipe waits whenever both waves of a SIMD wait (SQ_WAIT_INST_ANY 56 % of wave cycles, profiles/r03f_pmc_sq_*).
+// Here the two waves of a SIMD belong to ONE workgroup and alternate roles, separated by workgroup barriers: in every slot one of them
+// issues nothing but 32 MFMAs on fragments it already holds in registers (the pipe runs back to back), the other one reads the 12
+// fragments of ITS next 32 MFMAs and issues the slot's LDS-DMA.  Group 0 = waves 0-3 (rows 0..127 of the tile), group 1 = waves 4-7 (rows
+// 128..255), group 1 one barrier behind.
+//   tile     12 boards (240 of 256 rows) x 256 channels; wave = 128 rows x 64 channels (8 x 4 accumulators, as in every conv3 kernel)
+//   stage s  = (channel block cb, tap, k half): 32 deep.  Weights: 256 channels x 32 k = 16 KiB per stage, TWO stage buffers, streamed from
+//            the model's packed copy (ConvNet::wp3: the LDS image of every stage, swizzle included, contiguous -- one DMA piece is 1 KiB
+//            of consecutive global bytes).  Image: the boards' 64-channel slice of act2 (63 KiB), TWO buffers: slice cb + 1 streams in
+//            during the 36 slots of slice cb, so there is no image switch to wait for.  2 x 63 + 2 x 16 = 158 KiB.
+//   slot 2s     group 0: LOAD(s): 12 ds_read_b128, DMA weights of stage s + 1 | group 1: MFMAs of stage s - 1
+//   slot 2s + 1 group 0: MFMAs of stage s, then vmcnt(0)                     | group 1: LOAD(s), DMA one piece of image slice cb + 1
+// Same K order per accumulator as every other conv3 kernel (channel block outer, tap inner, k 0..31 then 32..63): bit-identical.
+constexpr int PP_NB = C3_NB;                       // boards per tile (the cell maps are Conv3Tables')
+constexpr int PP_NCOL = 256;                       // channels per tile
+constexpr int PP_WSTAGE = PP_NCOL * 64;            // one weight stage: 64-byte rows, chunk q of row n at slot q ^ pp_wperm(n)
+// LDS: [chunk-parity plane][image buffer][32 KiB of 64-byte cells] | w[2].  The buffer is bit 15 of an image address (an immediate of
+// the ds_read), the plane bit 16 (per lane).
+constexpr int PP_LDS = 4 * C3_PLANE_BYTES + 2 * PP_WSTAGE;
+constexpr int PP_EP_STRIDE = PP_NCOL * 2 + 16;
+static_assert(PP_LDS <= 163840 && PP_NB * 20 * PP_EP_STRIDE <= PP_LDS, "one workgroup per CU: 160 KiB");
+AZ_HD int pp_wperm(int n) { return (0x1320 >> (((n >> 2) & 3) * 4)) & 3; }      // {0, 2, 3, 1}[(n >> 2) & 3]: conflict-free ds_read_b128 of 64-byte rows
+
+template <int LAYER, int ABL = 0, int SCHED = 2, int TAIL = 2>     // TAIL: row tiles (x 4 MFMAs) of a stage issued behind its closing barrier; SCHED: barriers per stage (2: a LOAD and a COMPUTE slot; 1: see AZ_QSTAGE); ABL (diagnostic library, timing only, WRONG results): 1 no weight DMA, 2 no image DMA, 4 no fragment reads, 8 no MFMAs, 16 THREE weight buffers (the first overlaps the image: what a third buffer would buy)
+__global__ __launch_bounds__(512, 2) void k_conv3_pp(const GemmDesc d) {
+    constexpr int OUT_PER = 20, IN_PER = 42, OUT_ROWS = PP_NB * OUT_PER;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PP_LDS];
+    const int n_boards = (int)(*d.n_dev);
+    const int M = n_boards * OUT_PER;
+    if (M <= d.m_min) return;                          // the small-batch kernel launched beside this one takes the batch
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.acct && n_boards > 0) { atomicAdd(&d.acct[0], (unsigned long long)n_boards); atomicAdd(&d.acct[1], 1ull); }
+    const int C = d.cin;
+    const int NT = d.N / PP_NCOL;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int ntile = j % NT, mtile = (j / NT) * 8 + xcd;
+    const int b0 = mtile * PP_NB, n0 = ntile * PP_NCOL;
+    if (b0 >= n_boards) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wr = (wave >> 1) & 1, wc = g * 2 + (wave & 1);   // group (= column half of the tile: each group streams ITS 128 channels' weights), row half, column quarter
+    const int w4 = wave & 3;                           // wave within its group
+    const int frow = lane & 15, fq = lane >> 4;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)smem;
+    const int ncb = C / 64, nst = ncb * 18;
+    const char* wp = (const char*)d.Wp + (size_t)ntile * nst * PP_WSTAGE;
+    const uint32_t w_vo = (uint32_t)(wave * 2048 + lane * 16);             // wave w: pieces 2 w, 2 w + 1 of a stage (its own group's half)
+    constexpr int R3 = (ABL & 16) ? 1 : 0;             // weight ring of 3 (ablation) or 2 stages
+    constexpr int W_BASE = 4 * C3_PLANE_BYTES - R3 * PP_WSTAGE;
+    const uint32_t lds_w = lds_base + W_BASE + wave * 2048;
+    // image DMA (Conv3Tables' inverse map): piece q of a group's wave w4 fills cells (q & 7) * 64 + w4 * 16 + (lane >> 2) of plane q >> 3;
+    // group 0 brings plane 0 (pieces 0..7), group 1 plane 1 (pieces 8..15)
+    // (kept packed, two per register: image row | chunk position << 10; the byte offset is rebuilt where a piece is issued)
+    uint32_t i_pk[4];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const uint32_t e = d.c3tab[jj * 64 + w4 * 16 + (lane >> 2)];
+        const uint32_t pk = (e & 1023u) | ((((uint32_t)lane & 3u) ^ ((e >> 10) & 3u)) << 10);
+        if (jj & 1) i_pk[jj >> 1] |= pk << 16; else i_pk[jj >> 1] = pk;
+    }
+    const uint32_t i_b0 = (uint32_t)(b0 * IN_PER * C) * 2u, i_rs = (uint32_t)C * 2u;
+    const uint32_t lds_i = lds_base + w4 * 1024;
+#define AZ_QDMA_IMG(q_, cb_)                                                                                                  \
+    {                                                                                                                          \
+        uint32_t pkr_ = i_pk[((q_) & 7) >> 1];                                                                                 \
+        asm volatile("" : "+v"(pkr_));                 /* opaque: the eight offsets are loop-invariant and must not be hoisted (spills) */ \
+        const uint32_t pk_ = (((q_) & 1) ? pkr_ >> 16 : pkr_) & 0xFFFFu;                                                       \
+        lds_dma16((const char*)(d.A + (cb_) * 64) + ((q_) >> 3) * 16, i_b0 + (pk_ & 1023u) * i_rs + ((pk_ >> 10) << 5),        \
+                  lds_i + ((q_) >> 3) * (2 * C3_PLANE_BYTES) + ((cb_) & 1) * C3_PLANE_BYTES + ((q_) & 7) * 4096);              \
+    }
+    // prologue: the first image slice (plane 0 by waves 0-3, plane 1 by waves 4-7) and weight stage 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) AZ_QDMA_IMG(g * 8 + i, 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lds_dma16(wp + i * 1024, w_vo, lds_w + i * 1024);
+    if ((SCHED == 1 && g == 1) || R3) {                 // SCHED 1: group 1 issues one stage further ahead (see AZ_QSTAGE)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(wp + PP_WSTAGE + i * 1024, w_vo, lds_w + PP_WSTAGE + i * 1024);
+    }
+    if (SCHED == 1 && g == 1 && R3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(wp + 2 * PP_WSTAGE + i * 1024, w_vo, lds_w + 2 * PP_WSTAGE + i * 1024);
+    }
+    // fragment cells of all nine taps: 8 row tiles x 16 bit per tap and lane (Conv3Tables' read map), the lane's chunk position folded in
+    uint32_t tq[9][4];
+    {
+        const uint4* rdtab = (const uint4*)(d.c3tab + C3_TAB_INV) + (wr * 16 + frow);
+        const uint32_t px = ((uint32_t)fq >> 1) << 4, pxx = px | (px << 16);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { const uint4 v = rdtab[t * 32]; tq[t][0] = v.x ^ pxx; tq[t][1] = v.y ^ pxx; tq[t][2] = v.z ^ pxx; tq[t][3] = v.w ^ pxx; }
+    }
+    const uint32_t lx = ((uint32_t)fq & 1u) << 16;     // the lane's plane
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* wb = smem + W_BASE + (wc * 64 + frow) * 64 + ((fq ^ pp_wperm(frow)) << 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 fb[4], fa[8];
+    if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[i] = *(const bf16x8*)(smem + 4 * C3_PLANE_BYTES + lane * 16 + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8*)(smem + lane * 16 + i * 1024);
+    }
+    if (SCHED == 2 && g == 1) __builtin_amdgcn_s_barrier();       // SCHED 2: group 1 runs one slot behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+    int s = 0;
+    // ABL 128 (diagnostic): per-segment s_memtime sums of waves 0 and 4 -- LOAD until its reads are back | barrier 1 | MFMA issue |
+    // wait for the DMA | barrier 2 -- every stamp sits where lgkmcnt is 0 anyway
+    unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = 0, t_begin = 0;
+    if constexpr ((ABL & 128) != 0) { t_begin = tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+#define AZ_QSTAMP(i_)                                                                                                          \
+    if constexpr ((ABL & 128) != 0) {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        unsigned long long t_;                                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                          \
+        seg[i_] += t_ - tprev; tprev = t_;                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    }
+    // SCHED 1: both groups run the same sequence LOAD(0) COMPUTE(0) LOAD(1) COMPUTE(1) ...; group 0's barrier stands behind every COMPUTE, group 1's
+    // behind every LOAD, so between two barriers group 0 does LOAD(i), COMPUTE(i) while group 1 does COMPUTE(i - 1), LOAD(i): ONE barrier
+    // per stage keeps the two waves of a SIMD in opposite phases.  Each group opens its interval with its DMA (its half of a weight stage,
+    // then at most one image piece) and waits for the weight pieces just before its barrier: a LOAD and a COMPUTE later.
+    // weight stage st_ -> buffer st_ & 1 (given as a literal); IMG_: this interval also brings one piece of image slice cb + 1
+#define AZ_QDMA(st_, wbuf_, IMG_, TAP_)                                                                                        \
+    {                                                                                                                          \
+        if (!(ABL & 1) && (st_) < nst) {                                                                                       \
+            const char* src_ = wp + (size_t)(st_) * PP_WSTAGE;                                                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) lds_dma16(src_ + i_ * 1024, w_vo, lds_w + (wbuf_) * PP_WSTAGE + i_ * 1024); \
+        }                                                                                                                      \
+        if (!(ABL & 2) && (IMG_) && cb + 1 < ncb) AZ_QDMA_IMG(g * 8 + (TAP_), cb + 1)                                           \
+    }
+    // wait for the weight pieces of the interval; an image piece issued behind them may stay in flight
+#define AZ_QWAITV(IMG_)                                                                                                        \
+    {                                                                                                                          \
+        if constexpr (R3) {                            /* the stage issued in THIS interval may stay in flight */               \
+            if ((IMG_) && !(ABL & 2) && cb + 1 < ncb) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                          \
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                              \
+        } else {                                                                                                               \
+            if ((IMG_) && !(ABL & 2) && cb + 1 < ncb) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                          \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+        }                                                                                                                      \
+    }
+    // one stage: BUF_ (image buffer), TAP_, HALF_ are literals, so every LDS address is a register + an immediate
+#define AZ_QLOAD(BUF_, TAP_, HALF_)                                                                                            \
+        if constexpr (!(ABL & 4)) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) fb[nt] = *(const bf16x8*)(wb + (R3 ? ((TAP_) * 2 + (HALF_)) % 3 : (HALF_)) * PP_WSTAGE + nt * 1024); \
+        if constexpr (!(ABL & 4)) _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) {                                           \
+            uint32_t a_;   /* asm volatile: the 144 addresses of a slice are loop-invariant and must NOT be hoisted (spills) */ \
+            if (HALF_) asm volatile("v_perm_b32 %0, %1, %2, %3\n\tv_xor_b32 %0, 32, %0" : "=&v"(a_) : "v"(lx), "v"(tq[TAP_][mt >> 1]), "s"((mt & 1) ? 0x0C060302u : 0x0C060100u)); \
+            else asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a_) : "v"(lx), "v"(tq[TAP_][mt >> 1]), "s"((mt & 1) ? 0x0C060302u : 0x0C060100u)); \
+            fa[mt] = *(const bf16x8*)(smem + (BUF_) * C3_PLANE_BYTES + a_);                                                    \
+        }
+    // row tiles [mt0_, mt1_) of the stage's 8 x 4 MFMAs
+#define AZ_QCOMPUTE(mt0_, mt1_)                                                                                                \
+        if constexpr (!(ABL & 96)) __builtin_amdgcn_s_setprio(1);                                                              \
+        if constexpr (!(ABL & 8)) _Pragma("unroll") for (int mt = (mt0_); mt < (mt1_); ++mt)                                   \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                   \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);                   \
+        else { _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) asm volatile("" :: "v"(fa[mt])); _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) asm volatile("" :: "v"(fb[nt])); } \
+        if constexpr (!(ABL & 96)) __builtin_amdgcn_s_setprio(0);
+    // one stage: BUF_ (image buffer), TAP_, HALF_ are literals, so every LDS address is a register + an immediate
+#define AZ_QSTAGE(BUF_, TAP_, HALF_)                                                                                           \
+    if constexpr (SCHED == 2) {                                                                                                \
+        /* two barriers per stage: a LOAD slot and a COMPUTE slot per wave, group 1 one slot behind group 0 */                  \
+        AZ_QDMA(s + 1 + R3, R3 ? ((TAP_) * 2 + (HALF_) + 2) % 3 : 1 - (HALF_), (HALF_) == 0 && (TAP_) < 8, TAP_)               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        AZ_QLOAD(BUF_, TAP_, HALF_)                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        __builtin_amdgcn_s_waitcnt(0xC07F);            /* lgkmcnt(0): my reads are done before anybody may overwrite them */   \
+        AZ_QSTAMP(0)                                                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                          \
+        AZ_QSTAMP(1)                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        AZ_QCOMPUTE(0, 8 - TAIL)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        AZ_QSTAMP(2)                                                                                                           \
+        AZ_QWAITV((HALF_) == 0 && (TAP_) < 8)                                                                                  \
+        AZ_QSTAMP(3)                                                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                          \
+        AZ_QSTAMP(4)                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        /* the last TAIL row tiles' MFMAs issue BEHIND the barrier: they keep the matrix pipe busy while the other group starts */ \
+        if constexpr (TAIL > 0) { AZ_QCOMPUTE(8 - TAIL, 8) __builtin_amdgcn_sched_barrier(0); }                                \
+        ++s;                                                                                                                   \
+    } else {                                                                                                                   \
+        if (g == 0) AZ_QDMA(s + 1 + R3, R3 ? ((TAP_) * 2 + (HALF_) + 2) % 3 : 1 - (HALF_), (HALF_) == 0 && (TAP_) < 8, TAP_)   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        AZ_QLOAD(BUF_, TAP_, HALF_)                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        if (g == 1) {                                                                                                          \
+            __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): my reads are done before anybody may overwrite them */   \
+            AZ_QWAITV((HALF_) == 1 && (TAP_) < 8)      /* what I issued behind the previous stage's barrier */                 \
+            __builtin_amdgcn_s_barrier();                                                                                      \
+            AZ_QDMA(s + 2 + R3, R3 ? ((TAP_) * 2 + (HALF_)) % 3 : (HALF_), (HALF_) == 0 && (TAP_) < 8, TAP_)                   \
+        }                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        AZ_QCOMPUTE(0, 8)                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        if (g == 0) {                                                                                                          \
+            AZ_QWAITV((HALF_) == 0 && (TAP_) < 8)                                                                              \
+            __builtin_amdgcn_s_barrier();                                                                                      \
+        }                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        ++s;                                                                                                                   \
+    }
+#define AZ_QSLICE(BUF_)                                                                                                        \
+    AZ_QSTAGE(BUF_, 0, 0) AZ_QSTAGE(BUF_, 0, 1) AZ_QSTAGE(BUF_, 1, 0) AZ_QSTAGE(BUF_, 1, 1) AZ_QSTAGE(BUF_, 2, 0) AZ_QSTAGE(BUF_, 2, 1) \
+    AZ_QSTAGE(BUF_, 3, 0) AZ_QSTAGE(BUF_, 3, 1) AZ_QSTAGE(BUF_, 4, 0) AZ_QSTAGE(BUF_, 4, 1) AZ_QSTAGE(BUF_, 5, 0) AZ_QSTAGE(BUF_, 5, 1) \
+    AZ_QSTAGE(BUF_, 6, 0) AZ_QSTAGE(BUF_, 6, 1) AZ_QSTAGE(BUF_, 7, 0) AZ_QSTAGE(BUF_, 7, 1) AZ_QSTAGE(BUF_, 8, 0) AZ_QSTAGE(BUF_, 8, 1)
+    for (int cb = 0; cb < ncb; ++cb) {                 // ncb is even (C % 256 == 0): two slices per trip, the image buffer a literal
+        AZ_QSLICE(0)
+        ++cb;
+        AZ_QSLICE(1)
+    }
+#undef AZ_QDMA
+#undef AZ_QWAITV
+#undef AZ_QLOAD
+#undef AZ_QCOMPUTE
+#undef AZ_QSTAMP
+    if constexpr ((ABL & 128) != 0) {
+        if ((wave & 3) == 0 && lane == 0 && d.dbg && blockIdx.x < 128) {
+            for (int i = 0; i < 5; ++i) d.dbg[16 * blockIdx.x + g * 8 + i] = seg[i];
+            d.dbg[16 * blockIdx.x + g * 8 + 7] = __builtin_amdgcn_s_memtime() - t_begin;
+        }
+    }
+    if (SCHED == 2 && g == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last COMPUTE barrier
+#undef AZ_QSLICE
+#undef AZ_QSTAGE
+#undef AZ_QDMA_IMG
+    __builtin_amdgcn_sched_barrier(0);
+    // epilogue through LDS (every buffer is dead): [240][256] bf16 with a 528-byte row stride, out as whole 512-byte row segments
+    // (the lane constants are rebuilt from an opaque thread id: computed before the K loop they would be spilled across it)
+    __syncthreads();
+    int etid = (int)threadIdx.x;
+    asm volatile("" : "+v"(etid));
+    const int efrow = etid & 15, efq = (etid >> 4) & 3;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int nl = wc * 64 + nt * 16 + efq * 4;
+        const float4 bv = *(const float4*)(d.bias + n0 + nl);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ml = wr * 128 + mt * 16 + efrow;
+            if (ml >= OUT_ROWS) continue;
+            float r0 = acc[mt][nt][0] + bv.x, r1 = acc[mt][nt][1] + bv.y, r2 = acc[mt][nt][2] + bv.z, r3 = acc[mt][nt][3] + bv.w;
+            if (d.relu) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); r2 = fmaxf(r2, 0.f); r3 = fmaxf(r3, 0.f); }
+            uint2 o;
+            o.x = pack_bf16x2(r0, r1);
+            o.y = pack_bf16x2(r2, r3);
+            *(uint2*)(smem + ml * PP_EP_STRIDE + nl * 2) = o;
+        }
+    }
+    __syncthreads();
+    constexpr int EP_CHUNKS = OUT_ROWS * (PP_NCOL / 8);
+#pragma unroll
+    for (int it = 0; it < (EP_CHUNKS + 511) / 512; ++it) {
+        const int idx = it * 512 + etid;
+        const int ml = idx / (PP_NCOL / 8), c = idx - ml * (PP_NCOL / 8);
+        const int m = b0 * OUT_PER + ml;
+        if (idx >= EP_CHUNKS || m >= M) continue;
+        *(uint4*)(d.out + (size_t)m * d.N + n0 + c * 8) = *(const uint4*)(smem + ml * PP_EP_STRIDE + c * 16);
+    }
+}
+
+#endif   // AZ_DIAG (k_conv3_pp)
+
 // ---- SKINNY GEMM for small batches: operands straight into registers, no LDS, no barrier ---------------------------------------------
 // The arena (temp 0: ~20 executed rows per step and model), the drain of a self-play call and single-tree calls run the forward on a
 // few dozen rows.  The tiled kernels are then a chain of K / 64 dependent steps of { DMA, wait, barrier, fragment reads, MFMAs } run by
@@ -1472,6 +1746,7 @@ struct ConvNet {                      // the WEIGHTS of one model id (21 MB bf16
     uint16_t* w2r = nullptr;                           // conv2's folded weights rearranged [tap*C + co][ci] bf16 (the table GEMM's W)
     uint32_t* npat = nullptr;                          // device constant 19683 (the table GEMM's row count)
     uint16_t* wg[5] = {nullptr};                       // conv2,3,4, fc1, fc2 folded bf16 [N][K]
+    uint16_t* wp3 = nullptr;                           // conv3's weights as k_conv3_pp's LDS stage images [N / 256][C / 64 * 18][256][32] (C % 256 == 0)
     float* bg[5] = {nullptr};                          // folded bias f32 [N]
     float *wh = nullptr, *bh = nullptr;              // heads f32 [8][512], [8]
     template <class T> T* dalloc(size_t n) {
@@ -1575,6 +1850,9 @@ ConvNet* convnet_create(int channels, const char** err) {
     }
     ok &= (n->wh = n->dalloc<float>(8 * 512)) != nullptr;
     ok &= (n->bh = n->dalloc<float>(8)) != nullptr;
+#ifdef AZ_DIAG
+    if (C % PP_NCOL == 0) ok &= (n->wp3 = n->dalloc<uint16_t>(9 * (size_t)C * C)) != nullptr;
+#endif
     if (!ok) {
         if (err) *err = "convnet_create: device allocation failed";
         convnet_destroy(n);
@@ -1688,6 +1966,22 @@ bool convnet_set_params(ConvNet* net, const float* p, int64_t count) {
         }
         ok &= hipMemcpy(net->wg[l], w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
         ok &= hipMemcpy(net->bg[l], b.data(), b.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+#ifdef AZ_DIAG
+        if (l == 1 && net->wp3) {   // conv3: the same bf16 values as k_conv3_pp's stage images (stage = channel block, tap, k half)
+            std::vector<uint16_t> wp((size_t)9 * C * C);
+            const int nst = C / 64 * 18;
+            for (int nt = 0; nt < C / PP_NCOL; ++nt)
+                for (int st = 0; st < nst; ++st) {
+                    const int cb = st / 18, tap = (st % 18) / 2, half = st & 1;
+                    uint16_t* img = &wp[((size_t)nt * nst + st) * (PP_WSTAGE / 2)];
+                    for (int nl = 0; nl < PP_NCOL; ++nl)
+                        for (int q = 0; q < 4; ++q)
+                            std::memcpy(img + nl * 32 + ((q ^ pp_wperm(nl)) << 3),
+                                        &w[(size_t)(nt * PP_NCOL + nl) * K[1] + (size_t)tap * C + cb * 64 + half * 32 + q * 8], 16);
+                }
+            ok &= hipMemcpy(net->wp3, wp.data(), wp.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+        }
+#endif
         if (l == 0) {   // conv2: the same bf16 values as [tap*C + co][ci] for the table GEMM, then U = T x W2r^T
             std::vector<uint16_t> wr((size_t)9 * C * C);
             for (int co = 0; co < C; ++co)
@@ -1773,7 +2067,38 @@ static void launch_conv2_gemm(const GemmDesc& d, int rows_hint, hipStream_t s) {
     const int t8 = (tiles + 7) / 8 * 8;
     hipLaunchKernelGGL((k_conv_same_pipe<1, TABLE>), dim3(t8 * (d.N / HBN2_)), dim3(256), 0, s, d);
 }
-static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s, bool tail, bool planes) {
+static void launch_conv3_image(const GemmDesc& d, int rows_hint, hipStream_t s, bool tail, bool planes, int pp) {
+#ifdef AZ_DIAG
+    if (pp && d.Wp && d.N % PP_NCOL == 0) {
+        const int t8 = ((rows_hint + PP_NB - 1) / PP_NB + 7) / 8 * 8;
+        const dim3 grid(t8 * (d.N / PP_NCOL)), block(512);
+        switch (pp) {           // 16 + mask: the timing ablations (WRONG results)
+            case 17: hipLaunchKernelGGL((k_conv3_pp<2, 1>), grid, block, 0, s, d); return;
+            case 18: hipLaunchKernelGGL((k_conv3_pp<2, 2>), grid, block, 0, s, d); return;
+            case 19: hipLaunchKernelGGL((k_conv3_pp<2, 3>), grid, block, 0, s, d); return;
+            case 20: hipLaunchKernelGGL((k_conv3_pp<2, 4>), grid, block, 0, s, d); return;
+            case 23: hipLaunchKernelGGL((k_conv3_pp<2, 7>), grid, block, 0, s, d); return;
+            case 24: hipLaunchKernelGGL((k_conv3_pp<2, 8>), grid, block, 0, s, d); return;
+            case 27: hipLaunchKernelGGL((k_conv3_pp<2, 11>), grid, block, 0, s, d); return;
+            case 28: hipLaunchKernelGGL((k_conv3_pp<2, 16>), grid, block, 0, s, d); return;
+            case 34: hipLaunchKernelGGL((k_conv3_pp<2, 0, 1>), grid, block, 0, s, d); return;
+            case 36: hipLaunchKernelGGL((k_conv3_pp<2, 128>), grid, block, 0, s, d); return;
+            case 38: hipLaunchKernelGGL((k_conv3_pp<2, 0, 2, 0>), grid, block, 0, s, d); return;
+            case 39: hipLaunchKernelGGL((k_conv3_pp<2, 0, 2, 1>), grid, block, 0, s, d); return;
+            case 40: hipLaunchKernelGGL((k_conv3_pp<2, 0, 2, 3>), grid, block, 0, s, d); return;
+            case 37: hipLaunchKernelGGL((k_conv3_pp<2, 128 + 16>), grid, block, 0, s, d); return;
+            case 35: hipLaunchKernelGGL((k_conv3_pp<2, 16, 1>), grid, block, 0, s, d); return;
+            case 30: hipLaunchKernelGGL((k_conv3_pp<2, 32>), grid, block, 0, s, d); return;
+            case 31: hipLaunchKernelGGL((k_conv3_pp<2, 64>), grid, block, 0, s, d); return;
+            case 32: hipLaunchKernelGGL((k_conv3_pp<2, 48>), grid, block, 0, s, d); return;
+            case 33: hipLaunchKernelGGL((k_conv3_pp<2, 80>), grid, block, 0, s, d); return;
+            case 29: hipLaunchKernelGGL((k_conv3_pp<2, 24>), grid, block, 0, s, d); return;
+            default: break;
+        }
+        hipLaunchKernelGGL((k_conv3_pp<2>), grid, block, 0, s, d);
+        return;
+    }
+#endif
     const int tiles = (rows_hint + C3_NB - 1) / C3_NB;
     const int t8 = (tiles + 7) / 8 * 8;
     const int full_grid = t8 * (d.N / 128);
@@ -1936,7 +2261,7 @@ static void launch_gemm(const GemmDesc& d, int rows_hint, int rows_typ, hipStrea
     }
     if constexpr (LAYER == 2) {
         if (o.conv3_small && conv3_is_small(d2, rows_hint, rows_typ)) launch_ring_auto<LAYER>(d2, rows_hint, rows_typ, s, true);
-        else launch_conv3_image(d2, rows_hint, s, o.conv3_tail != 0, o.conv3_planes != 0);
+        else launch_conv3_image(d2, rows_hint, s, o.conv3_tail != 0, o.conv3_planes != 0, o.conv3_pp);
         return;
     }
 
@@ -2060,7 +2385,9 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     // conv3: 3x3 valid [6][7][C] -> [4][5][C]
     d.A = ws->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = ws->act3;
     d.rows_per_sample = 20; d.out_w = 5; d.in_h = 6; d.in_w = 7;
+    d.Wp = n->wp3;
     launch_gemm<2>(d, rows_hint, rows_typ, s, o);
+    d.Wp = nullptr;
     if (timed) (void)hipEventRecord(rec.e2b, s);
     // conv4: 3x3 valid [4][5][C] -> [2][3][C]
     d.A = ws->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = ws->act4;

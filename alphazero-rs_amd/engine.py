@@ -366,15 +366,17 @@ class Engine:
         buf = np.ascontiguousarray(unique_id, np.uint8)
         assert buf.size == COMM_ID_BYTES
         self._check(self._lib.az_comm_init(self._h, rank, world, _ptr(buf)))
+        self._comm_world = int(world)
 
     def comm_destroy(self):
         self._check(self._lib.az_comm_destroy(self._h))
 
     def gather_samples(self, states, pis, zs, dst=0, is_dst=True, capacity=0):
-        """ONE gather of this rank's (s, pi, z) tuples to rank dst; returns (states, pis, zs, counts) on dst, (None, None, None, counts) elsewhere."""
+        """ONE gather of this rank's (s, pi, z) tuples to rank dst (-1: every rank receives); returns (states, pis, zs, counts) on a
+        receiving rank, (None, None, None, counts) elsewhere.  counts has one entry per rank of the communicator."""
         n = int(len(zs))
         local = az_samples(n, n, _as_ptr(states), None, _as_ptr(pis), _as_ptr(zs), None, None)
-        counts = np.zeros(64, np.int64)
+        counts = np.zeros(max(1, getattr(self, "_comm_world", 1)), np.int64)
         if is_dst:
             gs, gp, gz = np.zeros((capacity, 2), np.uint64), np.zeros((capacity, ACTIONS), np.float32), np.zeros(capacity, np.float32)
             g = az_samples(capacity, 0, _ptr(gs), None, _ptr(gp), _ptr(gz), None, None)

@@ -187,19 +187,22 @@ pub fn self_play(e: *mut az_engine, p: &az_selfplay_params) -> (Vec<f32>, Vec<f3
 }
 
 /// The ONE exchange of a sharded episode batch (each rank played `p.first_game_id ..` of the global episode ids): this rank's
-/// (states [n,2], pis [n,7], zs [n]) go to `dst_rank`, which gets everybody's tuples in rank order (else empty vectors).
-pub fn gather_samples(e: *mut az_engine, states: &mut [u64], pis: &mut [f32], zs: &mut [f32], rank: i32, world: i32, dst_rank: i32)
-                      -> (Vec<u64>, Vec<f32>, Vec<f32>) {
+/// (states [n,2], pis [n,7], zs [n]) go to `dst_rank`, which gets everybody's tuples in rank order (else empty vectors);
+/// `dst_rank = -1`: every rank receives everything.  `global_episodes` = the number of episodes of the WHOLE batch over all ranks:
+/// a receiving rank sizes its buffers from the hard bound 42 plies per episode (uneven shards make any bound derived from the
+/// local count too small; the library checks the capacity on every rank before anything is posted, so a wrong bound is an error
+/// on all ranks, never a hang).
+pub fn gather_samples(e: *mut az_engine, states: &mut [u64], pis: &mut [f32], zs: &mut [f32], rank: i32, world: i32, dst_rank: i32,
+                      global_episodes: usize) -> (Vec<u64>, Vec<f32>, Vec<f32>) {
     let n = zs.len();
     let local = az_samples { capacity: n as i64, count: n as i64, states: states.as_mut_ptr(), boards: std::ptr::null_mut(),
                              pis: pis.as_mut_ptr(), zs: zs.as_mut_ptr(), game_len: std::ptr::null_mut(), moves: std::ptr::null_mut() };
     let mut counts = vec![0i64; world as usize];
-    if rank != dst_rank {
+    if dst_rank >= 0 && rank != dst_rank {
         check(e, unsafe { az_gather_samples(e, &local, dst_rank, std::ptr::null_mut(), counts.as_mut_ptr()) });
         return (vec![], vec![], vec![]);
     }
-    // capacity: the caller's bound on the global batch (42 plies per episode at most); two passes would need the counts first
-    let cap = n * world as usize + 42 * world as usize;
+    let cap = global_episodes * 42;
     let (mut gs, mut gp, mut gz) = (vec![0u64; cap * 2], vec![0f32; cap * 7], vec![0f32; cap]);
     let mut g = az_samples { capacity: cap as i64, count: 0, states: gs.as_mut_ptr(), boards: std::ptr::null_mut(),
                              pis: gp.as_mut_ptr(), zs: gz.as_mut_ptr(), game_len: std::ptr::null_mut(), moves: std::ptr::null_mut() };
