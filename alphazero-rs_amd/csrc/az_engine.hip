@@ -48,7 +48,9 @@ struct NetModel {
     uint64_t salt = 0;
     ConvNet* conv = nullptr;
     uint64_t cache_tag = 0;     // evaluation-cache tag of the current weights (0 = none yet); new tag per upload
+    uint64_t generation = 0;    // bumped by every weight upload / kind change of any model of the process: part of a search graph's key
 };
+uint64_t g_model_generation = 0;
 
 // timed regions (profile mode): event pairs recorded on the engine stream, resolved at sync points
 enum Region { RG_TREE = 0, RG_NET = 1, RG_COUNT };   // RG_NET brackets the whole predict (kept for stub nets)
@@ -266,6 +268,8 @@ struct az_engine {
     struct EvalLog { std::vector<int32_t> count; std::vector<uint64_t> states; std::vector<float> pi, v; };
     EvalLog ar_log[2];
     int ar_log_cap = 0, ar_log_games = 0;
+    std::vector<uint8_t> ar_moves;      // [games][AZ_MAX_PLIES] move record of the last az_arena (az_arena_get_moves)
+    std::vector<int32_t> ar_len;
     // NNet::train
     Trainer* trainer = nullptr;
     bool train_open = false;
@@ -282,6 +286,7 @@ struct az_engine {
     int dedup_stats = 1;            // "dedup_stats": the leaf-row accounting counters (requested / executed / hits / duplicates)
     uint64_t profile_tick = 0;
     int search_graph = 20;          // "search_graph": simulation steps per hipGraph launch (0 = every kernel launched on its own); not in profile mode
+    int search_graph_rows = 1024;   // "search_graph_rows": ... for searches whose expected leaf batch has at most this many rows (the arena, a drain, single trees)
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
     int eval_cache_log2 = 27;       // entries = 2^log2 (40 B each: 5.4 GB); 0 = no cache, in-batch de-duplication only
@@ -550,7 +555,10 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
     // ping-pong with the step's parity), so S steps (S even) are captured once into a hipGraph and replayed; the graph is kept with
     // the tree arena and re-captured only when something that shapes a launch changes.
     const int S = e->search_graph;
-    if (S >= 2 && !e->prof.on && num_sims >= S) {
+    // ... and only there: on big batches the kernels set the pace, and a graph's power-of-two grids and tile estimates cost more than its
+    // launches save (measured in round 4: 9.90 s per 65536-episode step with graphs everywhere, 9.64 s launched one by one)
+    const int expect_rows = rows_typ > 0 ? std::min(rows_typ, rows_hint) : rows_hint;
+    if (S >= 2 && !e->prof.on && num_sims >= S && expect_rows <= e->search_graph_rows) {
         // the grids' bound and the tile estimate in powers of two: the graph survives from move to move (a larger bound only adds
         // workgroups that exit at once; the estimate only picks tile families)
         auto pow2_up = [](int x, int cap) { int p = 1; while (p < x) p <<= 1; return p < cap ? p : cap; };
@@ -560,7 +568,8 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
             const void *th, *conv, *ws, *stream, *root_states, *max_rows, *ec_key, *ec_stat, *log_state, *log_row;
             unsigned long long ec_tag, salt;
             int kind, rows_hint, rows_typ, S, dedup, block4, log_cap;
-            uint32_t ec_bmask, ec_stones, max_depth;
+            uint32_t ec_bmask, ec_stones, max_depth, reserve_nodes;
+            uint64_t model_gen;
             float cpuct;
             NetOptions opt;
         } k;
@@ -570,15 +579,25 @@ void run_search(az_engine* e, TreeHost& th, const ulonglong2* d_root_states, int
         k.ec_tag = ec.tag; k.salt = net.salt; k.kind = net.kind; k.rows_hint = rows_hint; k.rows_typ = rows_typ; k.S = S; k.dedup = dedup ? 1 : 0;
         k.block4 = th.d.block4; k.log_cap = th.d.log_cap; k.ec_bmask = ec.bmask; k.ec_stones = ec.max_stones; k.max_depth = sp.max_depth; k.cpuct = sp.cpuct_f;
         k.opt = e->netopt;
+        k.reserve_nodes = th.d.reserve_nodes;      // TreeDev travels by value into the captured launches: the capacity threshold is baked in
+        k.model_gen = net.generation;              // a freed and re-created model may reuse the ConvNet's address: its weights' identity is the generation
         TreeHost::StepGraph& sg = th.step_graph;
         if (!sg.exec || sg.key.size() != sizeof k || std::memcmp(sg.key.data(), &k, sizeof k) != 0) {
             if (sg.exec) { HIPCHK(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
             if (net.kind == AZ_NET_CONV) convnet_prepare(workspace_for(e, s), e->netopt);      // nothing may allocate while the stream is capturing
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-            for (int j = 0; j < S; ++j) {
-                launch_backup_select(th.d, B[j & 1], B[(j + 1) & 1], ec, sp, s);
-                net_forward(e, net, B[(j + 1) & 1], rows_hint, s, rows_typ, false);
+            try {
+                for (int j = 0; j < S; ++j) {
+                    launch_backup_select(th.d, B[j & 1], B[(j + 1) & 1], ec, sp, s);
+                    net_forward(e, net, B[(j + 1) & 1], rows_hint, s, rows_typ, false);
+                }
+            } catch (...) {                            // never leave the engine's stream capturing: the next call on the handle would fail obscurely
+                hipGraph_t dead = nullptr;
+                (void)hipStreamEndCapture(s, &dead);
+                if (dead) (void)hipGraphDestroy(dead);
+                (void)hipGetLastError();
+                throw;
             }
             HIPCHK(hipStreamEndCapture(s, &g));
             const hipError_t ie = hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0);
@@ -740,7 +759,11 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("tree_block4") && (value == 0 || value == 1)) { e->tree_block4 = (int)value; return AZ_OK; }
     if (is("dedup_stats") && (value == 0 || value == 1)) { e->dedup_stats = (int)value; return AZ_OK; }
     if (is("profile_every") && value >= 1 && value <= 1000000) { e->profile_every = (int)value; return AZ_OK; }
+    // the HIP-event brackets of az_config.profile, switched between calls: a timed region runs un-bracketed (its search loop as
+    // hipGraph launches), a separate pass of the same call with the brackets on gives the per-kernel times
+    if (is("profile") && (value == 0 || value == 1)) { e->prof.on = value != 0; return AZ_OK; }
     if (is("search_graph") && value >= 0 && value <= 1000 && value % 2 == 0) { e->search_graph = (int)value; return AZ_OK; }
+    if (is("search_graph_rows") && value >= 0 && value <= 1000000) { e->search_graph_rows = (int)value; return AZ_OK; }
     if (is("fused_search") && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
     if (is("eval_dedup") && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
     if (is("eval_cache_log2") && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
@@ -894,6 +917,7 @@ az_status az_net_set_kind(az_engine* e, int32_t model_id, az_net_kind kind, uint
     // two hash nets with the same salt but different model ids differ (oracle: HashNet::predict)
     m.salt = salt + (uint64_t)model_id * 0x51ED27ull;
     m.cache_tag = 0;
+    m.generation = ++g_model_generation;
     return AZ_OK;
 }
 
@@ -929,6 +953,7 @@ az_status az_net_init_random(az_engine* e, int32_t model_id, uint64_t seed) {
         convnet_init_random(m->conv, seed);
         m->kind = AZ_NET_CONV;
         m->cache_tag = 0;
+        m->generation = ++g_model_generation;
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
@@ -946,6 +971,7 @@ az_status az_net_set_params(az_engine* e, int32_t model_id, const float* params,
         if (!convnet_set_params(m->conv, params, n)) return fail(e, AZ_ERR_HIP, "convnet_set_params failed");
         m->kind = AZ_NET_CONV;
         m->cache_tag = 0;
+        m->generation = ++g_model_generation;
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
@@ -1507,6 +1533,8 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
             if (results && hipMemcpy(results, res.data(), (size_t)G, hipMemcpyDefault) != hipSuccess) return fail(e, AZ_ERR_HIP, "az_arena: results copy");
             e->stats.games += (uint64_t)G;
             e->ar_log_cap = 0;
+            e->ar_moves.assign((size_t)G * AZ_MAX_PLIES, 0);      // no move is played on a finished board
+            e->ar_len.assign((size_t)G, 0);
             if (p->allreduce_wld) return az_allreduce_u64(e, out_wld, 3);     // the shards' tallies, as on the played path
             return AZ_OK;
         }
@@ -1543,6 +1571,10 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         ad.alive = mem.alloc<uint8_t>(G);
         ad.results = mem.alloc<int8_t>(G);
         ad.counters = mem.alloc<uint32_t>(4);          // [2], [3]: the largest leaf batch of the ply, per model (tile / kernel choice of the next ply)
+        ad.moves = mem.alloc<uint8_t>((size_t)G * AZ_MAX_PLIES);
+        ad.len = mem.alloc<int32_t>(G);
+        HIPCHK(hipMemset(ad.moves, 0, (size_t)G * AZ_MAX_PLIES));
+        HIPCHK(hipMemset(ad.len, 0, (size_t)G * sizeof(int32_t)));
         {
             // play_games' `board` (src/arena.rs:62-67): None = the initial board
             std::vector<uint64_t> st0((size_t)G * 2, 0ull);
@@ -1620,6 +1652,10 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
             else out_wld[2]++;
         }
         if (results) HIPCHK(hipMemcpy(results, res.data(), G, hipMemcpyDefault));
+        e->ar_moves.resize((size_t)G * AZ_MAX_PLIES);
+        e->ar_len.resize((size_t)G);
+        HIPCHK(hipMemcpy(e->ar_moves.data(), ad.moves, e->ar_moves.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(e->ar_len.data(), ad.len, e->ar_len.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         e->stats.games += (uint64_t)G;
         if (p->allreduce_wld) {       // every rank returns the whole arena's tally (one 3-counter all-reduce)
             az_status rs = az_allreduce_u64(e, out_wld, 3);
@@ -1641,6 +1677,13 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         }
         return AZ_OK;
     } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_arena_get_moves(az_engine* e, int32_t* game_len, uint8_t* moves) {
+    if (!e || e->ar_len.empty()) return fail(e, AZ_ERR_BAD_ARGUMENT, "no move record (run az_arena first)");
+    if (game_len) std::memcpy(game_len, e->ar_len.data(), e->ar_len.size() * sizeof(int32_t));
+    if (moves) std::memcpy(moves, e->ar_moves.data(), e->ar_moves.size());
+    return AZ_OK;
 }
 
 az_status az_arena_get_evals(az_engine* e, int32_t which, int32_t* rec_count, uint64_t* states, float* pis, float* vs) {

@@ -166,6 +166,8 @@ struct ArenaDev {
     uint8_t* alive;        // [G]
     int8_t* results;       // [G] play_game's return: +1 first seat won, -1 second seat won, 0 draw (src/arena.rs:51)
     uint32_t* counters;    // [0] games still running, [1] invalid-move flag (src/arena.rs:31-35)
+    uint8_t* moves;        // [G][42] the actions played, in order (what play_game's `verbose` prints, src/arena.rs:20-27)
+    int32_t* len;          // [G] plies played
 };
 
 // ---- launchers (all asynchronous on `s`; dispatch on TreeDev.game to the Game policy's instantiation) ------------------

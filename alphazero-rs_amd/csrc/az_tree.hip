@@ -1030,6 +1030,11 @@ __global__ __launch_bounds__(64) void k_arena_move(TreeDev t, ArenaDev ad, uint6
     const typename G::State s2 = G::play(s, action);
     const uint32_t ec = G::ended_code(s2);
     if (sub == 0) {
+        if (valid && hot) {                           // the game's move record
+            const int32_t k = ad.len[g];
+            if (k < G::MAX_PLIES) ad.moves[(size_t)g * G::MAX_PLIES + k] = (uint8_t)action;
+            ad.len[g] = k + 1;
+        }
         if (!valid || !hot) {
             atomicOr(&ad.counters[1], 1u);
             ad.alive[g] = 0;

@@ -83,7 +83,7 @@ EXPORTS = [
     "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_net_train_history",
     "az_net_train_begin", "az_net_train_step", "az_net_train_end", "az_tree_create",
     "az_tree_destroy", "az_tree_reset", "az_tree_get_action_prob", "az_tree_record_evals", "az_tree_get_evals",
-    "az_tree_node_counts", "az_selfplay", "az_selfplay_get_evals", "az_arena", "az_arena_get_evals",
+    "az_tree_node_counts", "az_selfplay", "az_selfplay_get_evals", "az_arena", "az_arena_get_evals", "az_arena_get_moves",
     "az_comm_unique_id", "az_comm_init", "az_comm_destroy", "az_gather_samples", "az_allreduce_u64",
 ]
 COMM_ID_BYTES = 128
@@ -129,6 +129,7 @@ def load_library(path=LIB_PATH):
         "az_selfplay_get_evals": (i32, [vp, vp, vp, vp, vp]),
         "az_arena": (i32, [vp, C.POINTER(az_arena_params), vp, vp]),
         "az_arena_get_evals": (i32, [vp, i32, vp, vp, vp, vp]),
+        "az_arena_get_moves": (i32, [vp, vp, vp]),
         "az_comm_unique_id": (i32, [vp, vp]),
         "az_comm_init": (i32, [vp, i32, i32, vp]),
         "az_comm_destroy": (i32, [vp]),
@@ -347,6 +348,13 @@ class Engine:
         return wld, results[: (num_games if total_games > 0 else 2 * (num_games // 2))]
 
 
+    def arena_get_moves(self, n_games):
+        """Move record of the last arena(): (game_len [n_games], moves [n_games, 42])."""
+        game_len = np.zeros(n_games, np.int32)
+        moves = np.zeros((n_games, MAX_PLIES), np.uint8)
+        self._check(self._lib.az_arena_get_moves(self._h, _ptr(game_len), _ptr(moves)))
+        return game_len, moves
+
     def arena_get_evals(self, which, n_games, cap):
         """Eval log of the last arena(record_evals=cap): rows the trees of player `which` (0 new, 1 old) consumed, per game."""
         cnt = np.zeros(n_games, np.int32)
@@ -371,15 +379,22 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.az_comm_destroy(self._h))
 
-    def gather_samples(self, states, pis, zs, dst=0, is_dst=True, capacity=0):
+    def gather_samples(self, states, pis, zs, dst=0, is_dst=True, capacity=0, out=None):
         """ONE gather of this rank's (s, pi, z) tuples to rank dst (-1: every rank receives); returns (states, pis, zs, counts) on a
-        receiving rank, (None, None, None, counts) elsewhere.  counts has one entry per rank of the communicator."""
+        receiving rank, (None, None, None, counts) elsewhere.  counts has one entry per rank of the communicator.
+        out = {"states", "pis", "zs"}: receive into these buffers (numpy arrays or torch tensors, host or device; capacity = their
+        rows) instead of fresh host arrays -- the returned tuple then holds views of them."""
         n = int(len(zs))
         local = az_samples(n, n, _as_ptr(states), None, _as_ptr(pis), _as_ptr(zs), None, None)
         counts = np.zeros(max(1, getattr(self, "_comm_world", 1)), np.int64)
         if is_dst:
-            gs, gp, gz = np.zeros((capacity, 2), np.uint64), np.zeros((capacity, ACTIONS), np.float32), np.zeros(capacity, np.float32)
-            g = az_samples(capacity, 0, _ptr(gs), None, _ptr(gp), _ptr(gz), None, None)
+            if out is not None:
+                gs, gp, gz = out["states"], out["pis"], out["zs"]
+                capacity = int(gz.shape[0])
+                g = az_samples(capacity, 0, _as_ptr(gs), None, _as_ptr(gp), _as_ptr(gz), None, None)
+            else:
+                gs, gp, gz = np.zeros((capacity, 2), np.uint64), np.zeros((capacity, ACTIONS), np.float32), np.zeros(capacity, np.float32)
+                g = az_samples(capacity, 0, _ptr(gs), None, _ptr(gp), _ptr(gz), None, None)
             self._check(self._lib.az_gather_samples(self._h, C.byref(local), dst, C.byref(g), _ptr(counts)))
             m = int(g.count)
             return gs[:m], gp[:m], gz[:m], counts

@@ -6,12 +6,15 @@ Metric (BASELINE.json): self-play games/sec (+ MCTS node-expansions/sec) on conn
 positions from the empty board.
 
 A "step" = one episode batch through the hot path: `--episodes` (default 8 x --games) self-play games per GPU played to completion on
-`--games` concurrent slots (finished slots are refilled; the last `--games` episodes of a step drain on shrinking batches, which is part of the measurement), then the RCCL gather of the (s, pi, z) tuples to rank 0
-when N > 1.  Weak scaling: per-GPU work is fixed; `value` = all ranks' games / max-over-ranks time.
+`--games` concurrent slots (finished slots are refilled; the last `--games` episodes of a step drain on shrinking batches, which is part of the measurement), then -- when N > 1 -- the ONE RCCL gather of the (s, pi, z)
+tuples to rank 0 THROUGH THE C ABI (az_comm_init + az_gather_samples on the engine's stream: the product's collective, not a
+torch.distributed stand-in).  Weak scaling: per-GPU work is fixed; `value` = all ranks' games / max-over-ranks time.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel (conv2's implicit-GEMM MFMA kernel, timed
-live with HIP events on the engine's stream) and "cpu_baseline" (the CPU oracle driving the same search with the
-same f32 net on torch-CPU, bounded sample, rank 0 at N=1 only).
+Two passes, both named in `config.passes`: the TIMED region runs with the engine's HIP-event brackets off (its search loop replays
+hipGraphs, as any embedding host's would); a separate profiled pass of the same call afterwards (brackets on every
+`--profile-every`th simulation step) gives the live per-kernel times behind "roofline" (the dominant kernel, conv3 on the matrix
+cores) and "kernels".  "cpu_baseline" = the CPU oracle driving the same search with the same f32 net on torch-CPU, bounded
+sample, rank 0 at N=1 only.
 """
 import argparse
 import json
@@ -265,7 +268,9 @@ def main():
 
     from alphazero_rs_amd import engine as azeng
     from alphazero_rs_amd import dist as azdist
-    e = azeng.Engine(device=local_rank, max_batch=args.games, net_channels=args.channels, profile=not args.no_profile)
+    # the timed region runs WITHOUT the engine's HIP-event brackets (profile mode launches every kernel on its own; un-bracketed the
+    # search loop replays hipGraphs: what matters on the shrinking batches of a step's drain); the brackets come on for a separate pass
+    e = azeng.Engine(device=local_rank, max_batch=args.games, net_channels=args.channels, profile=False)
     e.set_option("eval_dedup", args.dedup)
     e.set_option("profile_every", args.profile_every)
     e.set_option("conv2_table", args.conv2_table)
@@ -285,16 +290,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gathered = None
+    if use_dist:
+        # the product's collective: bind the engine to an RCCL communicator (az_comm_init; the unique id travels from rank 0 over
+        # the process group that also carries the timing protocol) and gather with az_gather_samples on the engine's stream
+        uid = torch.from_numpy(e.comm_unique_id() if rank == 0 else np.zeros(azeng.COMM_ID_BYTES, np.uint8)).to(dev)
+        dist.broadcast(uid, src=0)
+        e.comm_init(rank, world, uid.cpu().numpy())
+        if rank == 0:
+            gcap = cap * world
+            gathered = {"states": torch.empty((gcap, 2), dtype=torch.int64, device=dev),
+                        "pis": torch.empty((gcap, 7), dtype=torch.float32, device=dev),
+                        "zs": torch.empty(gcap, dtype=torch.float32, device=dev)}
+
     def step(i):
         first = (i * world + rank) * episodes          # global game ids: disjoint per (step, rank)
         r = e.selfplay(n_games=episodes, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
                        first_game_id=first, symmetries=False, want_boards=False, out=out)
         n = r["count"]
         if use_dist:
-            packed = azdist.pack_samples(out["states"][:n], out["pis"][:n], out["zs"][:n])
-            gathered, counts = azdist.gather_samples(packed, dst=0)
-            if rank == 0 and int(counts.sum()) != gathered.shape[0]:
-                raise RuntimeError("gather_samples: count mismatch")
+            _gs, _gp, gz, counts = e.gather_samples(out["states"][:n], out["pis"][:n], out["zs"][:n], dst=0, is_dst=rank == 0, out=gathered)
+            if rank == 0 and int(counts.sum()) != gz.shape[0]:
+                raise RuntimeError("az_gather_samples: count mismatch")
         return n, int(r["game_len"].sum())
 
     for i in range(args.warmup):
@@ -309,7 +326,28 @@ def main():
         plies += p
     barrier()
     dt = time.perf_counter() - t0
-    st = e.stats()
+    st_timed = e.stats()
+    # the profiled pass (outside the timed region): the same call with the HIP-event brackets on
+    prof_s = None
+    if not args.no_profile:
+        e.set_option("profile", 1)
+        e.reset_stats()
+        t1 = time.perf_counter()
+        r = e.selfplay(n_games=episodes, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
+                       first_game_id=(args.warmup + args.steps) * world * episodes + rank * episodes, symmetries=False, want_boards=False, out=out)
+        torch.cuda.synchronize()
+        prof_s = time.perf_counter() - t1
+        st_prof = e.stats()
+        e.set_option("profile", 0)
+    # counts and rates come from the timed region; per-kernel times (net_*_ms, tree_ms, their flops / bytes / launch counts) from the profiled pass
+    st = dict(st_timed)
+    if prof_s is not None:
+        for k, v in st_prof.items():
+            if k.startswith("net_") or k in ("tree_ms", "tree_launches_timed", "tree_bytes", "tree_launches", "depth_sum", "simulations_prof"):
+                st[k] = v
+        st["simulations_for_tree"] = st_prof["simulations"]
+    else:
+        st["simulations_for_tree"] = st_timed["simulations"]
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -337,7 +375,12 @@ def main():
                        "sims_per_move": args.sims, "net": args.net, "parallelism": f"games-sharded x{world}",
                        "symmetries": "identity only in the timed region (the mirrored twin of every tuple is regenerated where the tuples are consumed: "
                                      "k_emit_samples' mirror pass is 0.004 % of device time)",
-                       "csrc_sha": csrc_sha()},
+                       "csrc_sha": csrc_sha(),
+                       "passes": {"timed": f"{args.steps} steps after {args.warmup} warm-up steps, the engine's HIP-event brackets OFF (search loop as hipGraph replays): "
+                                           "value, ms_per_step and every */s rate",
+                                  "profiled": (f"one more step of the same call afterwards with the brackets ON (every {args.profile_every}th simulation step; "
+                                               f"{prof_s:.2f} s): roofline, kernels, conv2_table, tree_hbm") if prof_s is not None else None,
+                                  "gather": "az_comm_init + az_gather_samples (RCCL on the engine's stream, through the C ABI) inside the timed step" if use_dist else None}},
             "node_expansions_per_sec": expansions / dt, "simulations_per_sec": simulations / dt,
             "leaf_evals_per_sec": leaf_evals / dt, "mean_plies": plies_all / games,
             # leaf de-duplication (bit-exact, az_engine.h "eval_dedup"): the trees REQUEST leaf_evals rows, the net EXECUTES
@@ -367,7 +410,7 @@ def main():
             common = {"peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": st["net_launches"],
                       "traffic_source": {"file": f"profiles/{pmc_name}", "csrc_sha": pmc.get("csrc_sha"), "git_sha": pmc.get("git_sha")} if pmc else None,
                       "traffic_stale": bool(pmc["_stale"]) if pmc else None,
-                      "launches_are": f"every {args.profile_every}th simulation step of the timed region (HIP events on the engine's stream)",
+                      "launches_are": f"every {args.profile_every}th simulation step of the profiled pass (HIP events on the engine's stream; config.passes)",
                       "net_forward_tflops": st["net_total_flops"] / (st["net_total_ms"] * 1e-3) / 1e12,
                       "net_forward_ms": st["net_total_ms"] / st["net_launches"]}
             if args.conv2_table:
@@ -383,7 +426,7 @@ def main():
                         "traffic_unit": f"HBM bytes per launch (PMC passes of this command committed as profiles/{src}: bytes per executed row x "
                                         "this run's mean rows per launch)",
                         "avg_launch_ms": st["net_conv3_ms"] / st["net_launches"], "avg_flop_per_launch": st["net_conv3_flops"] / st["net_launches"],
-                        # exact, counted on the device over EVERY forward of the timed region (not the sampled ones): what a profiler's
+                        # exact, counted on the device over EVERY forward of the profiled pass (not the sampled ones): what a profiler's
                         # total k_conv3_auto time has to be divided by (the smallest batches run conv3 on the ring / skinny kernels, and the
                         # idle half of a dual launch does no work)
                         "k_conv3_auto_accounting": {"rows": st["net_conv3_image_rows"], "working_launches": st["net_conv3_image_launches"],
@@ -412,7 +455,7 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
         line["roofline"] = roof
         if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:
-            # the step's kernels from the live HIP-event brackets of the timed region (the same sample of launches as `roofline`):
+            # the step's kernels from the live HIP-event brackets of the profiled pass (the same sample of launches as `roofline`):
             # average duration per launch, share of the bracketed step, and the fraction of the roofline that bounds each
             L = st["net_launches"]
             rows = st["net_rows_timed"] / L
@@ -433,7 +476,7 @@ def main():
                                "per_kernel": {k: {"avg_us": v, "share_of_step": v / step_us, "frac_of_roofline": frac.get(k),
                                                   "bound": "hbm (cache-side bytes; > 1 = served from L2 / Infinity Cache)" if "table" in k else ("hbm" if "tree" in k else "mfma")}
                                               for k, v in us.items()},
-                               "note": f"HIP events on the engine's stream around every {args.profile_every}th simulation step of the timed region"}
+                               "note": f"HIP events on the engine's stream around every {args.profile_every}th simulation step of the profiled pass"}
         if not args.no_profile and st["tree_ms"] > 0:
             tree_counter = None
             pmc, pmc_name = committed_pmc()
@@ -452,8 +495,8 @@ def main():
                                 "frac": tree_gbps(st) / HBM_PEAK_GBS,
                                 "frac_of_measured_copy_bw": tree_gbps(st) / 6290.0,
                                 "launches_timed": st["tree_launches_timed"], "launches": st["tree_launches"],
-                                "algorithmic_bytes_per_sim": st["tree_bytes"] / max(1, st["simulations"]),
-                                "mean_depth": st["depth_sum"] / max(1, st["simulations"])}
+                                "algorithmic_bytes_per_sim": st["tree_bytes"] / max(1, st["simulations_for_tree"]),
+                                "mean_depth": st["depth_sum"] / max(1, st["simulations_for_tree"])}
         if world == 1 and not args.no_cpu_baseline and args.net == "conv":
             try:
                 line["cpu_baseline"] = cpu_baseline(e.net_get_params(0), args.channels, args.sims, mean_plies=plies_all / games)
@@ -486,6 +529,8 @@ def main():
         if world == 1 and args.net == "conv" and not args.no_aux:
             # auxiliary, outside the timed region, not part of `value`
             # (a) the same workload with every requested row executed (de-duplication off): what round 1 measured
+            if not args.no_profile:
+                e.set_option("profile", 1)
             try:
                 e.set_option("eval_dedup", 0)
                 e.reset_stats()

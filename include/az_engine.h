@@ -136,7 +136,9 @@ const char* az_last_error(const az_engine* e);
  *            "conv3_planes" 1 (default): conv3's LDS image in the bank-conflict-free layout; 0: image rows in order.  Bit-identical
  *            "narrow_rows"  n (default 32, 0 = off): batches of at most n boards (conv3; 2n for conv4, 4n for the FCs) run the
  *                           register-fed skinny GEMM; the hand-over is decided on the device from the exact row count.  Bit-identical
- *   search   "search_graph" n (default 20, even, 0 = off): n simulation steps per captured hipGraph replay (conv nets)
+ *   search   "search_graph" n (default 20, even, 0 = off): n simulation steps per captured hipGraph replay (conv nets) ...
+ *            "search_graph_rows" n (default 1024): ... for searches whose expected leaf batch has at most n rows (the arena, the drain
+ *                           of a self-play call, single trees: there the host's launch calls set the pace; on big batches the kernels do)
  *            "fused_search" 1 (default): the stub / hash nets run a whole search in one launch; 0: one launch per simulation
  *            "tree_block4"  1 (default): four waves per workgroup in the select / backup kernel; 0: one
  *   leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
@@ -149,8 +151,10 @@ const char* az_last_error(const az_engine* e);
  *            "eval_cache_persist"  0 (default): every az_selfplay / az_arena / az_tree_get_action_prob call starts from an empty cache;
  *                           1: entries live until the model's weights change (the full "eval_cache_log2" table)
  *            "dedup_stats"  1 (default) / 0: maintain the five leaf-row counters of az_stats
- *   profile  "profile_every" n (default 1): with az_config.profile, bracket every n-th simulation step with HIP events (the net_* and
- *                           tree_ms sums then cover that sample of launches; a bracket costs a little idle time between kernels)
+ *   profile  "profile"      0 / 1: the HIP-event brackets of az_config.profile, switched between calls (bracketed searches launch every
+ *                           kernel on its own; a timed region runs with them off, a separate pass with them on gives the kernel times)
+ *            "profile_every" n (default 1): with the brackets on, bracket every n-th simulation step (the net_* and tree_ms sums
+ *                           then cover that sample of launches; a bracket costs a little idle time between kernels)
  *   NNet::train  "train_epochs" (10), "train_batch" (64, <= 256), "train_seed" (0), "train_lr_e9" (1000000 = 1e-3),
  *            "train_dropout_e6" (300000 = 0.3), "train_graph" 1 (default) / 0: replay a step's launches as a captured hipGraph,
  *            "train_gemm" 1 (default): dgrad / wgrad as bf16 x 3 on the bf16 matrix cores (gradients within 1e-5 of float64
@@ -300,6 +304,10 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
 /* Eval log of the last az_arena with record_evals > 0, for the trees of player `which` (0 = new model, 1 = old model):
  * rec_count [num_games], states [num_games,cap,2], pis [num_games,cap,7], vs [num_games,cap] (any may be NULL). */
 az_status az_arena_get_evals(az_engine* e, int32_t which, int32_t* rec_count, uint64_t* states, float* pis, float* vs);
+/* Move record of the last az_arena: game_len [num_games] plies played, moves [num_games][AZ_MAX_PLIES] the actions in order (the
+ * board sequence play_game's `verbose` prints, src/arena.rs:20-27; what one reaches for when an arena game diverges).  Either
+ * may be NULL. */
+az_status az_arena_get_moves(az_engine* e, int32_t* game_len, uint8_t* moves);
 
 /* ---- the collective of the sharded Coach loop (no reference counterpart: the reference is one process,
  * src/coach.rs:241-272 fans episodes out over a rayon pool; here one process per GPU plays a shard of the global

@@ -88,6 +88,7 @@ extern "C" {
     pub fn az_selfplay_get_evals(e: *mut az_engine, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;
     pub fn az_arena(e: *mut az_engine, p: *const az_arena_params, out_wld: *mut u64, results: *mut i8) -> c_int;
     pub fn az_arena_get_evals(e: *mut az_engine, which: i32, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;
+    pub fn az_arena_get_moves(e: *mut az_engine, game_len: *mut i32, moves: *mut u8) -> c_int;
     // ---- the collective of the sharded Coach loop (one process per GPU; RCCL on the engine's stream)
     pub fn az_comm_unique_id(e: *mut az_engine, id: *mut u8) -> c_int;
     pub fn az_comm_init(e: *mut az_engine, rank: i32, world: i32, id: *const u8) -> c_int;

@@ -117,3 +117,27 @@ def test_bench_parent_does_not_touch_the_gpu():
     assert main.index("self_launch(args.gpus)") < main.index("import torch")
     launch = src[src.index("def self_launch("):src.index("def dry_dist(")]
     assert "import torch" not in launch and "engine" not in launch and "subprocess.call" in launch and "os.exec" not in launch
+
+
+def test_bench_gathers_through_the_c_abi():
+    """bench.py's N-rank step calls the product's collective (az_comm_init + az_gather_samples through the C ABI), not the
+    torch.distributed stand-in of alphazero-rs_amd/dist.py -- that one stays for the gloo rehearsal only."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    step = src[src.index("    def step(i):", src.index("def main():")):src.index("    for i in range(args.warmup):", src.index("def main():"))]
+    assert "e.gather_samples(" in step and "azdist." not in step
+    main = src[src.index("def main():"):]
+    assert "e.comm_init(rank, world" in main and "e.comm_unique_id()" in main
+    dry = src[src.index("def dry_dist("):src.index("def main():")]
+    assert "azdist.gather_samples" in dry
+
+
+def test_sharded_cpp_example_builds_and_rejects_bad_wiring(tmp_path):
+    """examples/connect_four_sharded.cpp (rank, world, id-file: the launcher a host without Python starts once per GPU) compiles
+    against the header, and wiring errors end with exit code 2 before any GPU call (the run itself is a GPU test)."""
+    import subprocess
+    libdir = os.path.join(ROOT, "alphazero-rs_amd")
+    exe = os.path.join(tmp_path, "connect_four_sharded")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "connect_four_sharded.cpp"),
+                           "-o", exe, "-L", libdir, "-laz_engine", f"-Wl,-rpath,{libdir}"])
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "3", "2", os.path.join(tmp_path, "id"), os.path.join(tmp_path, "ck")], capture_output=True).returncode == 2

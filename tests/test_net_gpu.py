@@ -339,7 +339,7 @@ def test_model_slots_do_not_leak(engine_mod):
 def test_bench_scale_replay_parity_with_the_conv_net(engine, oracle):
     """The bench configuration itself -- 8192 concurrent games, 100 sims/move, the bf16 C=512 net with conv1 / conv2 as table
     lookups, leaf de-duplication and the evaluation cache on -- held to the oracle: every game's NNet::predict rows are
-    recorded, 24 game ids picked at random are re-played on the oracle from their own records (replay parity: the oracle asks
+    recorded and ALL 8192 games are re-played on the oracle from their own records (replay parity: the oracle asks
     for the same states in the same order and gets the engine's rows back), and must match move for move, pi for pi, z for z.
     Game g depends only on (seed, g): what its 8191 neighbours do -- sharing its leaf rows through the election table and the
     cache -- must not show."""
@@ -352,17 +352,7 @@ def test_bench_scale_replay_parity_with_the_conv_net(engine, oracle):
     assert st["leaf_rows_executed"] < 0.8 * st["leaf_rows_requested"]            # the sharing really happened
     cnt, states, pis, vs = engine.selfplay_get_evals(n, cap)
     assert cnt.max() <= cap and cnt.min() > 0
-    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
-    for g in np.random.default_rng(1).choice(n, size=24, replace=False):
-        c = int(cnt[g])
-        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_REPLAY, seed=seed, first_game_id=int(g),
-                              replay=(np.array([0, c], np.int64), np.ascontiguousarray(states[g, :c]), np.ascontiguousarray(pis[g, :c]),
-                                      np.ascontiguousarray(vs[g, :c])))
-        assert not ref["replay_bad"].any(), g
-        L = int(ref["game_len"][0])
-        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
-        lo, hi = offs[g], offs[g + 1]
-        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+    _replay_every_episode(oracle, got, (cnt, states, pis, vs), sims, seed, n)
     # and the recorded rows are what NNet::predict returns for those states
     g = 17
     pi2, v2 = engine.predict_states(states[g, :256], 21)
@@ -403,15 +393,47 @@ def _flatten_log(cnt, states, pis, vs, ids):
     return off, cat(states), cat(pis), cat(vs)
 
 
+def _replay_every_episode(oracle, got, logs, sims, seed, n, sim_threads=1, chunk=1024):
+    """EVERY episode of a recorded self-play call re-played on the oracle from its own recorded rows (replay parity), `chunk`
+    episodes per oracle call on 16 threads: moves, pi and z bit for bit.  (Round 3 replayed 24 ids; the one product parity
+    bug of three rounds had sat behind a 16-of-4096 sample.)"""
+    cnt, states, pis, vs = logs
+    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
+    for lo in range(0, n, chunk):
+        ids = list(range(lo, min(n, lo + chunk)))
+        ref = oracle.selfplay(len(ids), sims, net_kind=oracle.NET_REPLAY, seed=seed, first_game_id=lo, threads=16, sim_threads=sim_threads,
+                              replay=_flatten_log(cnt, states, pis, vs, ids))
+        assert not ref["replay_bad"].any(), (lo, np.flatnonzero(ref["replay_bad"])[:5] + lo)
+        assert np.array_equal(ref["game_len"], got["game_len"][lo:lo + len(ids)]), lo
+        assert np.array_equal(ref["moves"], got["moves"][lo:lo + len(ids)]), lo
+        a, b = offs[lo], offs[lo + len(ids)]
+        assert np.array_equal(ref["pis"], got["pis"][a:b]) and np.array_equal(ref["zs"], got["zs"][a:b]), lo
+
+
+def _check_move_record(oracle, game_len, moves, results, start=(0, 0)):
+    """az_arena_get_moves: every recorded game, played move by move with the oracle's rules, ends exactly at its recorded length with
+    the recorded result (+1 first seat won, -1 second, 0 draw: src/arena.rs:51)."""
+    for g in range(len(results)):
+        s, player = start, 1
+        for k in range(int(game_len[g])):
+            assert oracle.c4_ended(*s) == 0.0, (g, k)
+            s = oracle.c4_play(s[0], s[1], int(moves[g, k]))
+            player = -player
+        e = oracle.c4_ended(*s)                        # for the side to move: -1 = the player who just moved won
+        assert e != 0.0, g
+        want = -player if e == -1.0 else (player if e == 1.0 else 0)
+        assert int(results[g]) == want, (g, e, player)
+
+
 def test_replay_parity_arena_with_two_conv_nets(engine, oracle):
     """BASELINE config 3 AS BENCHMARKED -- az_arena with two bf16 conv nets, the old model's searches on a second stream, the
     model-tagged evaluation cache shared by both, the small-batch conv3 path and the per-ply batch feedback -- held to the
     oracle by replay parity: az_arena records every NNet::predict row each tree consumed (per game, per player); the oracle
     re-plays the games feeding those rows back.  Same states requested in the same order, same results, same W/L/D.
-    First a 64-game, 100-sim arena in full, then 16 game ids picked at random out of the 4096-game, 400-sim arena itself."""
+    First a 64-game, 100-sim arena in full, then ALL 4096 games of the 400-sim arena itself (512 games per oracle call)."""
     engine.net_init_random(22, seed=5)
     engine.net_init_random(23, seed=6)
-    for num, sims, picks in ((64, 100, None), (4096, 400, 16)):
+    for num, sims, picks in ((64, 100, None), (4096, 400, 512)):
         cap = 22 * (sims + 1) + 8                                    # a player moves at most 21 times
         engine.reset_stats()
         wld, res = engine.arena(num, sims, new_model_id=23, old_model_id=22, seed=9, record_evals=cap)
@@ -422,15 +444,18 @@ def test_replay_parity_arena_with_two_conv_nets(engine, oracle):
         if picks is None:
             groups = [list(range(num))]                              # the whole small arena in one oracle call
         else:
-            groups = [[int(g)] for g in sorted(np.random.default_rng(2).choice(num, size=picks, replace=False))]
+            groups = [list(range(lo, min(num, lo + picks))) for lo in range(0, num, picks)]      # every game, `picks` per oracle call
+        tally = np.zeros(3, np.uint64)
         for sel in groups:
             rn, ro = (_flatten_log(*logs[w], sel) for w in (0, 1))
             owld, ores, bad = oracle.arena_ex(num, sims, first_game=sel[0], n_games=len(sel), net_kind=oracle.NET_REPLAY, seed=9,
-                                              threads=8, replay_new=rn, replay_old=ro)
-            assert not bad.any(), (num, sel[0])
+                                              threads=16, replay_new=rn, replay_old=ro)
+            assert not bad.any(), (num, sel[0], np.flatnonzero(bad)[:5] + sel[0])
             assert np.array_equal(ores, res[sel[0]:sel[0] + len(sel)]), (num, sel[0])
-            if picks is None:
-                assert owld.tolist() == wld.tolist()
+            tally += owld
+        assert tally.tolist() == wld.tolist()
+        glen, gmoves = engine.arena_get_moves(num)
+        _check_move_record(oracle, glen, gmoves, res)
         ids = [g for sel in groups for g in sel]
         # the recorded rows are what NNet::predict returns for those states, under the right model
         for w, mid in ((0, 23), (1, 22)):
@@ -443,8 +468,8 @@ def test_replay_parity_arena_with_two_conv_nets(engine, oracle):
 def test_replay_parity_selfplay_with_refill_and_the_conv_net(engine, oracle):
     """The bench's shape: more episodes than slots -- 16,384 episodes on 8,192 slots, C = 512, tables + de-duplication + the
     evaluation cache on, the drain of the last 8,192 on shrinking batches (ring / image-resident kernel switching) -- with
-    per-EPISODE eval logs that survive the slot refills.  24 episode ids, half of them from the last 8,192 (which drain),
-    replayed on the oracle from their own recorded rows: moves, pi and z bit for bit."""
+    per-EPISODE eval logs that survive the slot refills.  ALL 16,384 episodes (the last 8,192 drain) are replayed on the oracle
+    from their own recorded rows: moves, pi and z bit for bit."""
     engine.net_init_random(24, seed=8)
     n, conc, sims, seed = 16384, 8192, 100, 44
     cap = 42 * (sims + 1) + 8
@@ -452,28 +477,16 @@ def test_replay_parity_selfplay_with_refill_and_the_conv_net(engine, oracle):
     got = engine.selfplay(n_games=n, concurrent=conc, num_sims=sims, model_id=24, seed=seed, want_boards=False, record_evals=cap)
     st = engine.stats()
     assert st["games"] == n and st["leaf_rows_executed"] < 0.8 * st["leaf_rows_requested"]
-    cnt, states, pis, vs = engine.selfplay_get_evals(n, cap)
-    assert cnt.max() <= cap and cnt.min() > 0
-    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
-    rng = np.random.default_rng(4)
-    ids = np.concatenate([rng.choice(conc, size=12, replace=False), conc + rng.choice(n - conc, size=12, replace=False)])
-    for g in ids:
-        c = int(cnt[g])
-        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_REPLAY, seed=seed, first_game_id=int(g),
-                              replay=(np.array([0, c], np.int64), np.ascontiguousarray(states[g, :c]), np.ascontiguousarray(pis[g, :c]),
-                                      np.ascontiguousarray(vs[g, :c])))
-        assert not ref["replay_bad"].any(), g
-        L = int(ref["game_len"][0])
-        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
-        lo, hi = offs[g], offs[g + 1]
-        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+    logs = engine.selfplay_get_evals(n, cap)
+    assert logs[0].max() <= cap and logs[0].min() > 0
+    _replay_every_episode(oracle, got, logs, sims, seed, n)
 
 
 def test_replay_parity_lockstep_threads_with_the_conv_net(engine, oracle):
     """Several simulations in flight per tree (num_sim_threads = 4: the lock-step schedule of DESIGN.md 4.1a) with the real bf16 net,
     tables, de-duplication and the evaluation cache on, 2,048 slots x 4 threads = up to 8,192 rows per step, with slot refill: the
-    eval log holds every tree's rows in the order its threads consumed them, and the oracle's lock-step search re-plays 16 episodes
-    from them -- moves, pi and z bit for bit, no simulation spent differently."""
+    eval log holds every tree's rows in the order its threads consumed them, and the oracle's lock-step search re-plays ALL 4,096
+    episodes from them -- moves, pi and z bit for bit, no simulation spent differently."""
     engine.net_init_random(27, seed=12)
     n, conc, sims, T, seed = 4096, 2048, 100, 4, 21
     cap = 42 * (sims + 1) + 8
@@ -482,20 +495,7 @@ def test_replay_parity_lockstep_threads_with_the_conv_net(engine, oracle):
                           num_sim_threads=T)
     st = engine.stats()
     assert st["games"] == n and st["simulations"] == sims * int(got["game_len"].sum())
-    cnt, states, pis, vs = engine.selfplay_get_evals(n, cap)
-    offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
-    rng = np.random.default_rng(5)
-    ids = np.concatenate([rng.choice(conc, size=8, replace=False), conc + rng.choice(n - conc, size=8, replace=False)])
-    for g in ids:
-        c = int(cnt[g])
-        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_REPLAY, seed=seed, first_game_id=int(g), sim_threads=T,
-                              replay=(np.array([0, c], np.int64), np.ascontiguousarray(states[g, :c]), np.ascontiguousarray(pis[g, :c]),
-                                      np.ascontiguousarray(vs[g, :c])))
-        assert not ref["replay_bad"].any(), g
-        L = int(ref["game_len"][0])
-        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
-        lo, hi = offs[g], offs[g + 1]
-        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+    _replay_every_episode(oracle, got, engine.selfplay_get_evals(n, cap), sims, seed, n, sim_threads=T)
 
 
 def test_conv3_image_kernel_accounting(engine, oracle):

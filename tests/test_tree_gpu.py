@@ -275,19 +275,17 @@ def test_full_size_properties(engine):
 
 
 def test_full_size_spot_check_against_oracle(engine, oracle):
-    """BASELINE config-2 size (8192 concurrent games, 100 sims/move) with the hash net: 40 game ids picked at random
-    from the 8192 are replayed one by one on the oracle and must match move for move, tuple for tuple (the oracle
-    alone would need minutes for all of them; game g depends only on (seed, g), never on its neighbours)."""
+    """BASELINE config-2 size (8192 concurrent games, 100 sims/move) with the hash net: ALL 8192 games are played on the oracle
+    too (16 threads, 1024 games per call: tree-only CPU work, a few seconds) and must match move for move, tuple for tuple."""
     n, sims, seed = 8192, 100, 21
     got = engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=seed, want_boards=False)
     offs = np.concatenate([[0], np.cumsum(2 * got["game_len"].astype(np.int64))])
     assert offs[-1] == got["count"]
-    for g in np.random.default_rng(0).choice(n, size=40, replace=False):
-        ref = oracle.selfplay(1, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=seed, first_game_id=int(g))
-        L = int(ref["game_len"][0])
-        assert L == got["game_len"][g] and np.array_equal(ref["moves"][0, :L], got["moves"][g, :L]), g
-        lo, hi = offs[g], offs[g + 1]
-        assert np.array_equal(ref["pis"], got["pis"][lo:hi]) and np.array_equal(ref["zs"], got["zs"][lo:hi]), g
+    for lo in range(0, n, 1024):
+        ref = oracle.selfplay(1024, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=seed, first_game_id=lo, threads=16)
+        assert np.array_equal(ref["game_len"], got["game_len"][lo:lo + 1024]) and np.array_equal(ref["moves"], got["moves"][lo:lo + 1024]), lo
+        a, b = offs[lo], offs[lo + 1024]
+        assert np.array_equal(ref["pis"], got["pis"][a:b]) and np.array_equal(ref["zs"], got["zs"][a:b]), lo
 
 
 # ---- arena::play_games (C16) -----------------------------------------------------------------------
@@ -322,8 +320,8 @@ def test_arena_odd_and_empty(engine, engine_mod):
 
 def test_arena_full_size_properties(engine, engine_mod, oracle):
     """BASELINE config 3 (4096 paired games, 400 sims/move) with the hash nets: size-independent properties --
-    every game ends, W + L + D = 4096, the tally follows the per-game results under the seat swap, and swapping
-    which model is listed first mirrors wins and losses (play_games is symmetric in its two players)."""
+    every game ends, W + L + D = 4096, the tally follows the per-game results under the seat swap -- the three-shard
+    partitioning, EVERY game against the oracle, and the arena's move record."""
     engine.net_set_kind(41, engine_mod.NET_HASH, 9001)
     engine.net_set_kind(40, engine_mod.NET_HASH, 9001)
     engine.reset_stats()
@@ -342,11 +340,25 @@ def test_arena_full_size_properties(engine, engine_mod, oracle):
         tot += w
         parts.append(r)
     assert np.array_equal(np.concatenate(parts), res) and tot.tolist() == wld.tolist()
-    # 16 games picked at random replayed one by one on the oracle (game g depends on (seed, g) and its seating only)
-    for g in np.random.default_rng(3).choice(4096, size=16, replace=False):
-        _, ores, _ = oracle.arena_ex(4096, 400, first_game=int(g), n_games=1, net_kind=oracle.NET_HASH, salt=9001, seed=5,
-                                     new_model_id=41, old_model_id=40)
-        assert int(ores[0]) == int(res[g]), g
+    # ALL 4096 games played on the oracle as well (16 threads, 512 games per call), game for game; and the move record of the
+    # arena (az_arena_get_moves) leads, move by move under the oracle's rules, to exactly those results
+    tally = np.zeros(3, np.uint64)
+    for lo in range(0, 4096, 512):
+        w, ores, _ = oracle.arena_ex(4096, 400, first_game=lo, n_games=512, net_kind=oracle.NET_HASH, salt=9001, seed=5,
+                                     new_model_id=41, old_model_id=40, threads=16)
+        assert np.array_equal(ores, res[lo:lo + 512]), lo
+        tally += w
+    assert tally.tolist() == wld.tolist()
+    wld2, res2 = engine.arena(4096, 400, new_model_id=41, old_model_id=40, seed=5)
+    glen, gmoves = engine.arena_get_moves(4096)
+    assert np.array_equal(res2, res) and glen.min() >= 7 and glen.max() <= 42
+    for g in range(4096):
+        s, player = (0, 0), 1
+        for k in range(int(glen[g])):
+            s = oracle.c4_play(s[0], s[1], int(gmoves[g, k]))
+            player = -player
+        e = oracle.c4_ended(*s)
+        assert e != 0.0 and int(res[g]) == (-player if e == -1.0 else (player if e == 1.0 else 0)), g
 
 
 def test_arena_start_board(engine, oracle, engine_mod):
