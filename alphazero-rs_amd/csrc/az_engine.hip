@@ -286,6 +286,11 @@ struct az_engine {
     int dedup_stats = 1;            // "dedup_stats": the leaf-row accounting counters (requested / executed / hits / duplicates)
     uint64_t profile_tick = 0;
     int search_graph = 20;          // "search_graph": simulation steps per hipGraph launch (0 = every kernel launched on its own); not in profile mode
+    int selfplay_async = 0;         // "selfplay_async": 1 = az_selfplay with free-running slots (k_async_step) for nets that go through leaf batches; 0 (default) = lock-step
+                                    // moves.  Bit-identical games; measured in round 4: larger batches (4000 against 2700 rows per forward), fewer forwards, the same
+                                    // time per row -- the step is throughput-bound per row, so it is not the default (profiles/README.md)
+    int selfplay_async_launches = 2;   // "selfplay_async_launches": tree launches that share one leaf batch (cache-answered trees go on in the next one)
+    int selfplay_async_iters = 6;   // "selfplay_async_iters": stages (backup, root, move, select) a slot may run per launch
     int search_graph_rows = 1024;   // "search_graph_rows": ... for searches whose expected leaf batch has at most this many rows (the arena, a drain, single trees)
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
@@ -754,6 +759,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("conv2_table") && (value == 0 || value == 1)) { e->netopt.conv2_table = (int)value; return AZ_OK; }
     if (is("conv3_small") && (value == 0 || value == 1)) { e->netopt.conv3_small = (int)value; return AZ_OK; }
     if (is("conv3_tail") && (value == 0 || value == 1)) { e->netopt.conv3_tail = (int)value; return AZ_OK; }
+    if (is("ring_packed") && (value == 0 || value == 1)) { e->netopt.ring_packed = (int)value; return AZ_OK; }
     if (is("conv3_planes") && (value == 0 || value == 1)) { e->netopt.conv3_planes = (int)value; return AZ_OK; }
     if (is("narrow_rows") && value >= 0 && value <= 65536) { e->netopt.narrow_rows = (int)value; return AZ_OK; }
     if (is("tree_block4") && (value == 0 || value == 1)) { e->tree_block4 = (int)value; return AZ_OK; }
@@ -764,6 +770,9 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("profile") && (value == 0 || value == 1)) { e->prof.on = value != 0; return AZ_OK; }
     if (is("search_graph") && value >= 0 && value <= 1000 && value % 2 == 0) { e->search_graph = (int)value; return AZ_OK; }
     if (is("search_graph_rows") && value >= 0 && value <= 1000000) { e->search_graph_rows = (int)value; return AZ_OK; }
+    if (is("selfplay_async") && (value == 0 || value == 1)) { e->selfplay_async = (int)value; return AZ_OK; }
+    if (is("selfplay_async_launches") && value >= 1 && value <= 8) { e->selfplay_async_launches = (int)value; return AZ_OK; }
+    if (is("selfplay_async_iters") && value >= 2 && value <= 64) { e->selfplay_async_iters = (int)value; return AZ_OK; }
     if (is("fused_search") && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
     if (is("eval_dedup") && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
     if (is("eval_cache_log2") && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
@@ -1418,6 +1427,50 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         az_status result = AZ_OK;
         int active = C;                               // slots still playing (read back after every move)
         int rows_typ = 0;                             // expected rows per leaf batch (0 = unknown: assume `active`)
+        // "selfplay_async": free-running slots (k_async_step) -- conv nets (anything that goes through leaf batches), one simulation in
+        // flight per tree.  `launches` tree launches share one leaf batch, then the forward runs on it.
+        const bool async_mode = e->selfplay_async != 0 && T == 1 && (net->kind == AZ_NET_CONV || dedup_applies(e, *net)) && p->num_sims >= 1;
+        if (async_mode) {
+            gd.sims = mem.alloc<int32_t>(C);
+            HIPCHK(hipMemsetAsync(gd.sims, 0xFF, (size_t)C * sizeof(int32_t), s));       // -1: no root prepared yet
+            launch_selfplay_sync_active(th.d, gd, s);
+            th.d.block4 = e->tree_block4;
+            const bool dedup = dedup_applies(e, *net);
+            const EvalCache ec = cache_for(e, *net);
+            EvalBatch B[2] = {th.eb, th.eb2};
+            B[0].dedup = B[1].dedup = dedup ? 1 : 0;
+            B[0].max_n = B[1].max_n = gd.counters + 3;
+            const int launches = std::max(1, e->selfplay_async_launches), iters = std::max(2, e->selfplay_async_iters);
+            const int every = std::max(1, e->profile_every);
+            int fill = 0;
+            // every leaf costs a forward at the latest `launches` launches after it was requested; a move needs num_sims + 2 leaves
+            const long long cap_steps = (long long)(AZ_MAX_PLIES + 2) * (n_games / C + 2) * ((long long)p->num_sims + 3) + 64;
+            for (long long step = 0;; ++step) {
+                const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
+                for (int j = 0; j < launches; ++j) {
+                    hipEvent_t t0 = nullptr;
+                    if (timed && j == 0) t0 = e->prof.begin(s);
+                    launch_async_step(th.d, gd, B[fill ^ 1], B[fill], ec, sp, mp, p->num_sims, j == 0 ? 1 : 0, iters, s);
+                    if (timed && j == 0) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
+                    e->stats.tree_launches += 1;
+                }
+                if (mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
+                net_forward(e, *net, B[fill], active, s, rows_typ, timed);
+                fill ^= 1;
+                if ((step & 15) == 15) {                  // look at the counters now and then: finished? how many slots still play?
+                    HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    resolve_profile(e);
+                    active = std::max(1, (int)h_ctr[2]);
+                    rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)C) : 0;
+                    HIPCHK(hipMemsetAsync(gd.counters + 3, 0, sizeof(uint32_t), s));
+                    if (h_ctr[1] >= (uint32_t)n_games) break;
+                    result = check_tree_errors(e, th);
+                    if (result) break;
+                    if (step > cap_steps) { result = fail(e, AZ_ERR_HIP, "az_selfplay: episode loop did not terminate"); break; }
+                }
+            }
+        } else
         for (int iter = 0;; ++iter) {
             launch_selfplay_sync_active(th.d, gd, s);
             // tile choice from the largest batch of the previous move (de-duplication makes batches much smaller than the

@@ -277,6 +277,8 @@ struct GemmDesc {
     unsigned long long* acct;  // k_conv3_auto: {rows, working launches} it has processed (device counters of the workspace)
     const uint16_t* c3tab;     // conv_valid_tile<.., PLANES>: the LDS image's cell maps (Conv3Tables, built by convnet_prepare's workspace)
     const uint16_t* Wp;        // k_conv3_pp: the layer's weights packed as LDS stage images (ConvNet::wp3), nullptr = not available
+    const uint16_t* Wr;        // gemm_ring_body: the layer's weights as the ring's LDS stage images [N / 128][K / 64][128 rows][128 B] in K-step order
+                               // (ConvNet::wr: one stage = 16 KiB of CONSECUTIVE global bytes instead of 128 rows K * 2 bytes apart), nullptr = read W
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -441,8 +443,12 @@ __device__ __forceinline__ void gemm_ring_body(const GemmDesc& d, unsigned char*
         const int y = r / d.out_w, x = r - y * d.out_w;
         a_ob[q] = (uint32_t)(((b * d.in_h + y) * d.in_w + x) * d.in_c + chunk * 8) * 2u;
     }
-    const uint32_t b_ob = (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;      // W piece q: + q * w_stride on the SGPR base
-    const size_t w_stride = (size_t)64 * d.K;
+    const bool packed = d.Wr != nullptr;
+    const uint32_t b_ob = packed ? (uint32_t)(wave * 1024 + lane * 16)
+                                 : (uint32_t)((n0 + wave * 8 + lrow) * d.K + chunk * 8) * 2u;      // W piece q: + q * w_stride on the SGPR base
+    const size_t w_stride = packed ? (size_t)4096 : (size_t)64 * d.K;
+    const char* wr_tile = (const char*)d.Wr + (size_t)ntile * (size_t)(d.K / GBK) * 16384;
+    int ks_idx = 0;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)(smem + wave * 1024);
     // K-step walker (channel block outer, tap inner), scalars only
@@ -451,7 +457,8 @@ __device__ __forceinline__ void gemm_ring_body(const GemmDesc& d, unsigned char*
 #define AZ_RDMA(buf_)                                                                                   \
     {                                                                                                   \
         const char* abase = (const char*)(d.A + ks_toff);                                               \
-        const char* wbase = (const char*)(d.W + ks_kk);                                                 \
+        const char* wbase = packed ? wr_tile + (size_t)ks_idx * 16384 : (const char*)(d.W + ks_kk);     \
+        ++ks_idx;                                                                                       \
         const uint32_t la = lds0 + (buf_) * STAGE;                                                      \
         _Pragma("unroll") for (int q_ = 0; q_ < MT; ++q_) lds_dma16(abase, a_ob[q_], la + q_ * 4096);   \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) lds_dma16(wbase + q_ * w_stride, b_ob, la + BM * 128 + q_ * 4096); \
@@ -1746,6 +1753,7 @@ struct ConvNet {                      // the WEIGHTS of one model id (21 MB bf16
     uint16_t* w2r = nullptr;                           // conv2's folded weights rearranged [tap*C + co][ci] bf16 (the table GEMM's W)
     uint32_t* npat = nullptr;                          // device constant 19683 (the table GEMM's row count)
     uint16_t* wg[5] = {nullptr};                       // conv2,3,4, fc1, fc2 folded bf16 [N][K]
+    uint16_t* wr[5] = {nullptr};                       // conv2,3,4, fc1, fc2 as the ring's stage images (GemmDesc::Wr)
     uint16_t* wp3 = nullptr;                           // conv3's weights as k_conv3_pp's LDS stage images [N / 256][C / 64 * 18][256][32] (C % 256 == 0)
     float* bg[5] = {nullptr};                          // folded bias f32 [N]
     float *wh = nullptr, *bh = nullptr;              // heads f32 [8][512], [8]
@@ -1847,6 +1855,7 @@ ConvNet* convnet_create(int channels, const char** err) {
     for (int l = 0; l < 5; ++l) {
         ok &= (n->wg[l] = n->dalloc<uint16_t>(wk[l] * wn[l])) != nullptr;
         ok &= (n->bg[l] = n->dalloc<float>(wn[l])) != nullptr;
+        if (l >= 1) ok &= (n->wr[l] = n->dalloc<uint16_t>(wk[l] * wn[l])) != nullptr;
     }
     ok &= (n->wh = n->dalloc<float>(8 * 512)) != nullptr;
     ok &= (n->bh = n->dalloc<float>(8)) != nullptr;
@@ -1966,6 +1975,19 @@ bool convnet_set_params(ConvNet* net, const float* p, int64_t count) {
         }
         ok &= hipMemcpy(net->wg[l], w.data(), w.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
         ok &= hipMemcpy(net->bg[l], b.data(), b.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if (net->wr[l]) {   // the same bf16 values as the ring's stage images: K-steps in the walker's order (channel block outer, tap inner)
+            std::vector<uint16_t> wr(w.size());
+            const int cin = l <= 2 ? C : K[l], ntaps = K[l] / cin, nk = K[l] / 64;
+            for (int nt = 0; nt < N[l] / 128; ++nt)
+                for (int kt = 0; kt < nk; ++kt) {
+                    const int cb = kt / ntaps, tap = kt - cb * ntaps, kk = tap * cin + cb * 64;
+                    uint16_t* img = &wr[((size_t)nt * nk + kt) * 8192];
+                    for (int r = 0; r < 128; ++r)
+                        for (int sl = 0; sl < 8; ++sl)
+                            std::memcpy(img + r * 64 + sl * 8, &w[(size_t)(nt * 128 + r) * K[l] + kk + ((sl ^ (r & 7)) << 3)], 16);
+                }
+            ok &= hipMemcpy(net->wr[l], wr.data(), wr.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+        }
 #ifdef AZ_DIAG
         if (l == 1 && net->wp3) {   // conv3: the same bf16 values as k_conv3_pp's stage images (stage = channel block, tap, k half)
             std::vector<uint16_t> wp((size_t)9 * C * C);
@@ -2385,21 +2407,25 @@ void convnet_forward(ConvNet* n, NetWorkspace* ws, const EvalBatch& eb, int rows
     // conv3: 3x3 valid [6][7][C] -> [4][5][C]
     d.A = ws->act2; d.W = n->wg[1]; d.bias = n->bg[1]; d.out = ws->act3;
     d.rows_per_sample = 20; d.out_w = 5; d.in_h = 6; d.in_w = 7;
+    d.Wr = o.ring_packed ? n->wr[1] : nullptr;
     d.Wp = n->wp3;
     launch_gemm<2>(d, rows_hint, rows_typ, s, o);
     d.Wp = nullptr;
     if (timed) (void)hipEventRecord(rec.e2b, s);
     // conv4: 3x3 valid [4][5][C] -> [2][3][C]
     d.A = ws->act3; d.W = n->wg[2]; d.bias = n->bg[2]; d.out = ws->act4;
+    d.Wr = o.ring_packed ? n->wr[2] : nullptr;
     d.rows_per_sample = 6; d.out_w = 3; d.in_h = 4; d.in_w = 5;
     launch_gemm<3>(d, rows_hint, rows_typ, s, o);
     if (timed) (void)hipEventRecord(rec.e2c, s);
     // fc1: [6C] -> 1024
     d.A = ws->act4; d.W = n->wg[3]; d.bias = n->bg[3]; d.out = ws->fc1o;
+    d.Wr = o.ring_packed ? n->wr[3] : nullptr;
     d.rows_per_sample = 1; d.out_w = 1; d.in_h = 1; d.in_w = 1; d.in_c = 6 * C; d.tap_w = 1; d.cin = 6 * C; d.K = 6 * C; d.N = 1024;
     launch_gemm<4>(d, rows_hint, rows_typ, s, o);
     // fc2: 1024 -> 512
     d.A = ws->fc1o; d.W = n->wg[4]; d.bias = n->bg[4]; d.out = ws->fc2o;
+    d.Wr = o.ring_packed ? n->wr[4] : nullptr;
     d.in_c = 1024; d.cin = 1024; d.K = 1024; d.N = 512;
     launch_gemm<5>(d, rows_hint, rows_typ, s, o);
     hipLaunchKernelGGL(k_heads, dim3((rows_hint * 64 + 255) / 256), dim3(256), 0, s, eb, ws->fc2o, n->wh, n->bh, n_log);

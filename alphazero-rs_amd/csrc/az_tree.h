@@ -136,6 +136,7 @@ struct GamesDev {
     int32_t* ply;            // [C] moves played so far
     int32_t* gid;            // [C] index of the episode within this call, -1 = idle
     uint8_t* need_reset;     // [C] slot was refilled: its tree must be rebuilt
+    int32_t* sims;           // [C] free-running self-play (k_async_step): simulations of the current move done, -1 = root not prepared; else nullptr
     // per-episode outputs, indexed by gid
     int32_t n_games;
     ulonglong2* smp_state;   // [n_games*42]
@@ -206,6 +207,10 @@ void launch_call_readback(unsigned long long* totals, unsigned long long* dd_sta
 // sums the trees' counters into totals[ST_TOTALS] (u64, accumulated) and clears them; node_counts [G] may be nullptr
 void launch_harvest(const TreeDev& t, unsigned long long* totals, uint32_t* node_counts, hipStream_t s);
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s);
+// free-running self-play: one launch takes every slot through backup / move / root / select until its next leaf needs the net (at most
+// max_iters stages); first = the first launch behind a forward (eb_prev holds its rows)
+void launch_async_step(const TreeDev& t, const GamesDev& gd, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
+                       SelfplayMoveParams mp, int num_sims, int first, int max_iters, hipStream_t s);
 constexpr int GAME_COUNT = 2;    // 0 = ConnectFour (the reference's Game), 1 = ConnectThree (the seam's second instantiation)
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s);
 void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDev& ad, hipStream_t s);

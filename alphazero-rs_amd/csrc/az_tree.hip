@@ -894,17 +894,14 @@ __global__ __launch_bounds__(256) void k_call_readback(unsigned long long* total
     if (tid < ERR_COUNT) out->err[tid] = err[tid];
 }
 
-// ---- Coach::execute_episode, one ply for every slot (src/coach.rs:118-156) -------------------
+// ---- Coach::execute_episode, one ply of one slot (src/coach.rs:118-156) -------------------
+// Returns 0: the game goes on (gd.state / player / ply advanced); 1: the episode ended and the slot got the next one (its tree must be
+// rebuilt: need_reset); 2: the episode ended and the slot stays idle (h.active = 0).
 template <class G>
-__global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, SelfplayMoveParams mp) {
+AZ_D int selfplay_move_body(const TreeDev& t, TreeHead& h, const GamesDev& gd, const SelfplayMoveParams& mp, int g, int sub) {
     constexpr int GW = G::GROUP;
     constexpr int NA = G::ACTIONS;
-    int tid = blockIdx.x * 64 + threadIdx.x;
-    int g = tid / GW, sub = tid % GW;
-    if (g >= t.G) return;
     const int gi = gd.gid[g];
-    const TreeHead h = head_load(t, g);
-    if (gi < 0 || !h.active) return;
     const int ply = gd.ply[g];
     const int8_t player = gd.player[g];
     const typename G::State s = gd.state[g];
@@ -937,6 +934,7 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
     if (action < 0) action = 0;
     const typename G::State s2 = G::play(s, action);                        // :140-142
     const uint32_t ec = G::ended_code(s2);                                  // r = get_game_ended(cur_player), :144
+    int status = 0;
     if (sub == 0) {
         gd.smp_state[so] = s;
         gd.smp_player[so] = player;
@@ -959,9 +957,10 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
                 gd.player[g] = 1;
                 gd.ply[g] = 0;
                 gd.need_reset[g] = 1;
+                status = 1;
             } else {
-                t.head[g].head.active = 0;
                 atomicSub(&gd.counters[2], 1u);
+                status = 2;
             }
         } else {
             gd.state[g] = s2;
@@ -969,6 +968,86 @@ __global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, Se
             gd.ply[g] = ply + 1;
         }
     }
+    status = (int)gshfl<GW>((uint32_t)status, 0);
+    if (status == 2) h.active = 0;
+    return status;
+}
+template <class G>
+__global__ __launch_bounds__(64) void k_selfplay_move(TreeDev t, GamesDev gd, SelfplayMoveParams mp) {
+    constexpr int GW = G::GROUP;
+    int tid = blockIdx.x * 64 + threadIdx.x;
+    int g = tid / GW, sub = tid % GW;
+    if (g >= t.G) return;
+    const int gi = gd.gid[g];
+    TreeHead h = head_load(t, g);
+    if (gi < 0 || !h.active) return;
+    if (selfplay_move_body<G>(t, h, gd, mp, g, sub) == 2 && sub == 0) t.head[g].head.active = 0;
+}
+
+// ---- FREE-RUNNING self-play: every slot on its own timeline ("selfplay_async") -------------------------------------------------------
+// The lock-step driver runs one simulation per tree per forward, and every tree waits for the move boundary of all: of 8192 trees only
+// ~40 % put a row into a step's batch (the others hit the evaluation cache, a terminal node or a transposition), so the net runs on
+// batches of ~2900 rows.  Here a slot advances by itself: one launch takes a tree through backup -> [move, next root] -> select ...
+// until its next leaf needs the net (bounded by max_iters), and several launches share one leaf batch: trees whose leaf was answered by
+// the cache go on in the NEXT launch (the payload of an entry is only read one launch after its key was seen, as everywhere), trees
+// that took a row (or point at another tree's row) stay parked until the forward.  Moves, episode ends and slot refills happen inside the
+// kernel; a refilled slot's tree is rebuilt by k_reset_trees between two launches.  Each game still depends on (seed, game id) and the
+// net's rows alone -- the schedule decides when a row is evaluated, never what it is.
+//   gd.sims[g]   simulations of the current move done so far; -1 = the move's root is not prepared yet
+//   first        the first launch behind a forward: eb_prev holds that forward's rows (parked trees back up; its table is cleared)
+template <class G>
+__global__ __launch_bounds__(256) void k_async_step(TreeDev t, GamesDev gd, EvalBatch eb_prev, EvalBatch eb_next, EvalCache ec, SearchParams sp,
+                                                    SelfplayMoveParams mp, int num_sims, int first, int max_iters) {
+    constexpr int GW = G::GROUP;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;      // whole workgroups only (the launcher pads nothing: leaf_request synchronises)
+    const int g = tid / GW, sub = tid % GW;
+    if (first) {
+        if (tid == 0) { if (eb_prev.max_n && *eb_prev.n > *eb_prev.max_n) *eb_prev.max_n = *eb_prev.n; *eb_prev.n = 0; }
+        clear_election_keys(eb_prev);
+    }
+    if (g >= t.G) return;
+    TreeHead h = head_load(t, g);
+    PathRegs pth = path_load(t, g, sub);
+    uint32_t* path = t.path + (size_t)g * PATH_CAP;
+    int sims = gd.sims[g];
+    const bool alive = gd.gid[g] >= 0 && h.active != 0 && !gd.need_reset[g];
+    // a tree whose leaf waits for a row of the batch being filled stays parked; a leaf answered by the cache (or a value) can go on
+    const bool parked = h.leaf_kind != LEAF_NONE && h.leaf_kind != LEAF_VALUE && !(h.src & SRC_CACHE) && !first;
+    typename G::State leaf_s = G::init();
+    bool want = false;
+    if (alive && !parked) {
+        for (int it = 0; it < max_iters; ++it) {
+            if (h.leaf_kind != LEAF_NONE) {                                    // the pending leaf: store its prior, back its value up
+                const bool was_sim = h.leaf_kind != LEAF_ROOT;
+                group_memory_sync();
+                backup_body<G>(t, h, pth, eb_prev, ec, g, sub, path);
+                h.leaf_kind = LEAF_NONE;
+                if (was_sim) ++sims;
+                continue;
+            }
+            group_memory_sync();
+            if (sims < 0) {                                                    // get_action_prob's prologue for the slot's position (S10, S1)
+                leaf_s = root_prepare_body<G>(t, h, gd.state, g, sub);
+                sims = 0;
+                if (!h.active) break;                                          // a failed root (error flag set): the call ends with an error
+                if (h.leaf_kind == LEAF_ROOT) { want = true; break; }
+                continue;
+            }
+            if (sims >= num_sims) {                                            // the move (src/coach.rs:128-156), then the next position's root
+                const int st = selfplay_move_body<G>(t, h, gd, mp, g, sub);
+                sims = -1;
+                if (st != 0) break;                                            // episode over: idle, or wait for k_reset_trees
+                continue;
+            }
+            leaf_s = select_body<G>(t, h, pth, sp, g, sub, path);
+            if (h.leaf_kind == LEAF_EVAL) { want = true; break; }
+            if (h.leaf_kind == LEAF_NONE) ++sims;                              // an error cut the simulation short (flag set): it still counts
+        }
+    }
+    const uint32_t src = leaf_request<G>(eb_next, ec, want, leaf_s, sub);
+    if (want) h.src = src;
+    if (sub == 0) { head_store(t, g, h); gd.sims[g] = sims; }
+    path_store(t, g, sub, pth);
 }
 
 // ---- training tuples (TrainingSample, src/nnet.rs:22-27; z per B4, src/coach.rs:146-154) -----
@@ -1153,6 +1232,12 @@ void launch_call_readback(unsigned long long* totals, unsigned long long* dd_sta
 }
 void launch_selfplay_move(const TreeDev& t, const GamesDev& gd, SelfplayMoveParams mp, hipStream_t s) {
     AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_selfplay_move<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, gd, mp));
+}
+void launch_async_step(const TreeDev& t, const GamesDev& gd, const EvalBatch& eb_prev, const EvalBatch& eb_next, const EvalCache& ec, SearchParams sp,
+                       SelfplayMoveParams mp, int num_sims, int first, int max_iters, hipStream_t s) {
+    const bool four = t.block4 && (t.G * 8) % 256 == 0;
+    const dim3 grid(four ? (unsigned)(t.G * 8 / 256) : group_blocks(t.G)), block(four ? 256 : 64);
+    AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_async_step<TG>, grid, block, 0, s, t, gd, eb_prev, eb_next, ec, sp, mp, num_sims, first, max_iters));
 }
 void launch_selfplay_sync_active(const TreeDev& t, const GamesDev& gd, hipStream_t s) {
     hipLaunchKernelGGL(k_sync_active, dim3((t.G + 255) / 256), dim3(256), 0, s, t, gd);

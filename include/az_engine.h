@@ -140,6 +140,11 @@ const char* az_last_error(const az_engine* e);
  *            "search_graph_rows" n (default 1024): ... for searches whose expected leaf batch has at most n rows (the arena, the drain
  *                           of a self-play call, single trees: there the host's launch calls set the pace; on big batches the kernels do)
  *            "fused_search" 1 (default): the stub / hash nets run a whole search in one launch; 0: one launch per simulation
+ *            "selfplay_async" 0 (default) / 1: az_selfplay with FREE-RUNNING slots -- every slot runs backup, move, next root and select on
+ *                           its own timeline inside the tree kernel, "selfplay_async_launches" (default 2) launches share one leaf batch
+ *                           (trees the cache answered go on, trees that took a row wait for the forward), at most
+ *                           "selfplay_async_iters" (default 6) stages per slot and launch.  Same games bit for bit (a game depends on
+ *                           its seed, its id and the net's rows, never on the schedule); fewer, larger forwards
  *            "tree_block4"  1 (default): four waves per workgroup in the select / backup kernel; 0: one
  *   leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
  *   src/node.rs:282-289)

@@ -482,6 +482,36 @@ def test_replay_parity_selfplay_with_refill_and_the_conv_net(engine, oracle):
     _replay_every_episode(oracle, got, logs, sims, seed, n)
 
 
+def test_free_running_selfplay_plays_the_same_games(engine, oracle):
+    """az_set_option "selfplay_async" = 1: every slot on its own timeline (backup / move / next root / select inside k_async_step,
+    several tree launches per leaf batch, moves and refills inside the kernel) -- 4,096 episodes on 1,024 slots with the bf16 net, tables,
+    de-duplication and the cache on, for several (launches, stages) settings: the same moves, pi and z as the lock-step driver tuple for
+    tuple, and EVERY episode replays on the oracle from its own recorded rows.  The schedule decides when a row is evaluated, never what
+    it is."""
+    engine.net_init_random(29, seed=14)
+    n, conc, sims, seed = 4096, 1024, 100, 52
+    cap = 42 * (sims + 1) + 8
+    ref = engine.selfplay(n_games=n, concurrent=conc, num_sims=sims, model_id=29, seed=seed, want_boards=False)
+    try:
+        engine.set_option("selfplay_async", 1)
+        for launches, iters in ((2, 6), (1, 2), (3, 16)):
+            engine.set_option("selfplay_async_launches", launches)
+            engine.set_option("selfplay_async_iters", iters)
+            engine.reset_stats()
+            got = engine.selfplay(n_games=n, concurrent=conc, num_sims=sims, model_id=29, seed=seed, want_boards=False,
+                                  record_evals=cap if launches == 2 else 0)
+            st = engine.stats()
+            assert st["games"] == n and st["simulations"] == sims * int(got["game_len"].sum())
+            for k in ("game_len", "moves", "states", "pis", "zs"):
+                assert np.array_equal(got[k], ref[k]), (launches, iters, k)
+            if launches == 2:
+                _replay_every_episode(oracle, got, engine.selfplay_get_evals(n, cap), sims, seed, n)
+    finally:
+        engine.set_option("selfplay_async", 0)
+        engine.set_option("selfplay_async_launches", 2)
+        engine.set_option("selfplay_async_iters", 6)
+
+
 def test_replay_parity_lockstep_threads_with_the_conv_net(engine, oracle):
     """Several simulations in flight per tree (num_sim_threads = 4: the lock-step schedule of DESIGN.md 4.1a) with the real bf16 net,
     tables, de-duplication and the evaluation cache on, 2,048 slots x 4 threads = up to 8,192 rows per step, with slot refill: the
