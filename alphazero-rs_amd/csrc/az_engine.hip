@@ -190,7 +190,9 @@ struct TreeHost {
         d.T = T;
         d.G = G; d.R = (uint32_t)(blocks * BLOCK_SLOTS); d.H = H; d.reserve_nodes = (uint32_t)reserve_nodes;
         size_t slots = (size_t)G * d.R;
-        d.node = mem.alloc<uint4>(slots * 2);
+        if (d.R > MAX_TREE_SLOTS) throw HipFail{hipErrorInvalidValue, "a tree of more than 2^20 node slots (num_sims x plies too large for the 20-bit links of the node record)"};
+        d.node = mem.alloc<uint4>(slots);
+        d.key = mem.alloc<unsigned long long>(slots);
         d.hash = mem.alloc<uint32_t>((size_t)G * H);
         d.head = mem.alloc<TreeLine>(G);
         d.path = mem.alloc<uint32_t>((size_t)G * T * PATH_CAP);
@@ -696,6 +698,13 @@ bool on_device(const void* p) {
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// links and child blocks are 20-bit fields of the 16-byte node record (az_tree.h): a tree holds at most 2^20 slots
+az_status check_tree_slots(az_engine* e, uint64_t blocks) {
+    if (blocks * (uint64_t)BLOCK_SLOTS > (uint64_t)MAX_TREE_SLOTS)
+        return fail(e, AZ_ERR_CAPACITY, "a tree of more than 2^20 node slots: num_sims x plies exceeds what the node record's 20-bit links address");
+    return AZ_OK;
 }
 
 struct ScopedTimer {
@@ -1212,6 +1221,7 @@ az_status az_tree_create(az_engine* e, int32_t n_games, uint64_t reserve, int32_
         t->e = e;
         t->num_sims = num_sims; t->max_depth = max_depth; t->model_id = model_id; t->cpuct = cpuct;
         const uint64_t nodes = std::min<uint64_t>(reserve, reachable_slots(num_sims, AZ_MAX_PLIES));
+        if (az_status cs = check_tree_slots(e, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes))) return cs;
         t->th.create(n_games, reachable_blocks(num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(num_sims, AZ_MAX_PLIES), num_threads, e->cfg.game);
         t->d_root_states = t->mem.alloc<ulonglong2>(n_games);
         {
@@ -1375,6 +1385,7 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
         hipStream_t s = e->stream;
         const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
         TreeLease lease;
+        if (az_status cs = check_tree_slots(e, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes))) return cs;
         acquire_trees(e, lease, C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES), T, s);
         TreeHost& th = *lease;
         DeviceMem mem;
@@ -1613,6 +1624,7 @@ az_status az_arena(az_engine* e, const az_arena_params* p, uint64_t out_wld[3], 
         const int calls = AZ_MAX_PLIES / 2 + 1;
         const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, calls));
         TreeLease lease_n, lease_o;
+        if (az_status cs = check_tree_slots(e, reachable_blocks(p->num_sims, calls, nodes))) return cs;
         acquire_trees(e, lease_n, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), T, s);
         acquire_trees(e, lease_o, G, reachable_blocks(p->num_sims, calls, nodes), nodes, hash_entries(p->num_sims, calls), T, s);
         TreeHost &tn = *lease_n, &to = *lease_o;
@@ -1915,7 +1927,19 @@ int az_diag_tree_children(az_tree* t, int g, const int* path, int depth, unsigne
     std::vector<TreeLine> heads(d.G);
     if (hipMemcpy(heads.data(), d.head, heads.size() * sizeof(TreeLine), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     struct Rec { unsigned long long ctr, key; uint32_t prior, meta, link, child_base; };
-    auto load = [&](uint32_t slot, Rec* r) { return hipMemcpy(r, d.node + ((size_t)g * d.R + slot) * 2, 32, hipMemcpyDeviceToHost) == hipSuccess; };
+    auto load = [&](uint32_t slot, Rec* r) {
+        uint32_t raw[4];
+        if (hipMemcpy(raw, d.node + ((size_t)g * d.R + slot), 16, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(&r->key, d.key + ((size_t)g * d.R + slot), 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        const uint32_t w = raw[3], kind = (w >> 10) & 3u, payload = w >> 12;
+        r->ctr = ((unsigned long long)raw[1] << 32) | raw[0];
+        r->prior = raw[2];
+        r->meta = (w & 0x3Fu) | (((w >> 6) & 0xFu) << META_ECODE_SHIFT) | (kind == 2u ? META_EXPANDED : 0u);
+        r->link = kind == 1u ? payload : NONE;
+        r->child_base = kind == 2u ? payload * (uint32_t)BLOCK_SLOTS : 0u;
+        if (kind != 2u) r->key = 0;
+        return true;
+    };
     uint32_t cur = heads[g].head.root;
     Rec pr;
     if (!load(cur, &pr)) return -1;

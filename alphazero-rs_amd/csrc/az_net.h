@@ -73,7 +73,8 @@ struct NetOptions {
     int conv2_table = 1;    // 1: conv1 + conv2 as table gathers (k_conv2_table_x); 0: conv2 as the MFMA implicit GEMM (same function, other rounding)
     int conv3_small = 1;    // conv3 of a small expected batch on the 4-stage LDS-DMA ring (bit-identical)
     int conv3_planes = 1;   // conv3: the bank-conflict-free LDS image (Conv3Tables; bit-identical); 0 = image rows in order, 128 B each
-    int ring_packed = 0;    // the LDS-DMA ring reads its weight stages from the packed copy (16 KiB of consecutive bytes per stage; bit-identical)
+    int ring_packed = 1;    // the LDS-DMA ring reads its weight stages from the model's packed copy (one stage = 16 KiB of consecutive bytes instead of
+                            // 128 rows K * 2 bytes apart; conv4 -3 %; bit-identical); 0 = from the [N][K] weights
     int conv3_tail = 1;     // conv3: a short last round of workgroups is cut into half tiles (k_conv3_auto); 0 = full tiles only (bit-identical)
     int narrow_rows = 32;   // conv3 / conv4 / fc1 / fc2 of a batch of at most this many rows (x 2 for conv4, x 4 for the FCs) run as the register-fed
                             // skinny GEMM (k_gemm_skinny), decided on the device from the exact row count; 0 = never (bit-identical)

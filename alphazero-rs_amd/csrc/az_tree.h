@@ -2,17 +2,19 @@
 //
 // One TreeDev = G independent NodeStores (src/node.rs:129-375), G*R node slots in HBM, a game's slots contiguous.
 //
-// Node record = 32 bytes (array of structures: everything a selection level needs from a node is one record):
-//     +0  u64 ctr         packed win counter 0xWWWWWWWW_NNNN_VVVV (src/node.rs:17)
-//     +8  u64 key         Game::pack(state) of an expanded node (NodeMutableState.s); 0 on a placeholder
-//     +16 u32 prior       f32 bits of the edge prior parent -> this slot (parent.mu.p[a], src/node.rs:354)
-//     +20 u32 meta        a | nchild << 3 | expanded | ecode << 7 | has_prior   (az_common.h)
-//     +24 u32 link        NONE, or the tree-local slot of the canonical node (NodeLink.1, src/node.rs:129)
-//     +28 u32 child_base  first slot of the child block
-// Children are pushed contiguously at expansion (src/node.rs:313-317) into a CHILD BLOCK of Game::GROUP (8) slots =
-// 256 bytes, 256-byte aligned: lane j of the 8 lanes that serve a game loads child j's record, so a selection level
-// costs one 32-byte record for the parent and exactly two 128-byte lines for its children (the separate rec / ctr /
-// state arrays this replaces cost four to six lines per level).  Per-tree search state is one 64-byte TreeHead.
+// Node record = 16 bytes (everything a selection level needs from a child):
+//     +0  u64 ctr    packed win counter 0xWWWWWWWW_NNNN_VVVV (src/node.rs:17)
+//     +8  u32 prior  f32 bits of the edge prior parent -> this slot (parent.mu.p[a], src/node.rs:354)
+//     +12 u32 word   a | nchild << 3 | ecode << 6 | has_prior << 8 | locked << 9 | kind << 10 | payload << 12
+//                    kind 0: placeholder; 1: link, payload = tree-local slot of the canonical node (NodeLink.1, src/node.rs:129);
+//                    2: expanded (mu.s is Some), payload = index of its child block.  20 payload bits: a tree holds at most 2^20 slots
+//                    (the reference example's reserve_space of 1,000,000 fits)
+// plus, for expanded nodes only, key[slot] = Game::pack(state) (NodeMutableState.s) in an array of its own: the search reads it once
+// per simulation (the expansion plays the parent's state) and the transposition probe compares it.
+// Children are pushed contiguously at expansion (src/node.rs:313-317) into a CHILD BLOCK of Game::GROUP (8) slots = ONE 128-byte
+// line: lane j of the 8 lanes that serve a game loads child j's record, so a selection level costs exactly one line (round 3's
+// 32-byte records, with the state in the record, cost two; round 1's separate rec / ctr / state arrays four to six), and the
+// record of the chosen child is the next level's parent.  Per-tree search state is one 64-byte TreeHead.
 #pragma once
 #include "az_common.h"
 #include "az_game.h"
@@ -28,6 +30,7 @@ enum ErrIdx { ERR_CAPACITY = 0, ERR_TERMINAL_ROOT = 1, ERR_PATH = 2, ERR_HASH_FU
 enum LeafKind { LEAF_NONE = 0, LEAF_VALUE = 1, LEAF_EVAL = 2, LEAF_ROOT = 3 };
 
 constexpr int BLOCK_SLOTS = 8;         // slots of a child block (== Game::GROUP)
+constexpr uint32_t MAX_TREE_SLOTS = 1u << 20;   // links and child blocks are 20-bit fields of the node record
 
 // per-tree search state: one 64-byte line, read at the start and written at the end of every tree kernel
 struct TreeHead {
@@ -60,7 +63,8 @@ struct TreeDev {
     uint32_t H;              // hash entries per tree (power of two)
     int32_t game;            // az_game: which Game policy the kernels are instantiated with (0 = ConnectFour)
     uint32_t reserve_nodes;  // reserve_space (src/node.rs:146): pushes beyond it are the reference's assert (src/node.rs:237)
-    uint4* node;             // [G*R*2] 32-byte records as two uint4: {ctr.lo, ctr.hi, key.lo, key.hi} {prior, meta, link, child_base}
+    uint4* node;             // [G*R] 16-byte records {ctr.lo, ctr.hi, prior, word}
+    unsigned long long* key; // [G*R] Game::pack(state) of the expanded nodes
     uint32_t* hash;          // [G*H] `seen` (src/node.rs:135): open-addressing table of node slots, key = the node's own key word
     TreeLine* head;          // [G]
     uint32_t* path;          // [G*T*PATH_CAP] node_path entries beyond PATH_INLINE

@@ -34,25 +34,41 @@ template <int NA> AZ_D uint32_t nth_set_bit(uint32_t mask, uint32_t n) {
 }
 
 // ---- node record access (layout: az_tree.h) ---------------------------------------------------------------------------
+// The 16-byte record {ctr, prior, word}: word = a | nchild << 3 | ecode << 6 | has_prior << 8 | locked << 9 | kind << 10 | payload << 12,
+// kind 0 = placeholder, 1 = link (payload = the canonical node's slot), 2 = expanded (payload = child block index).  NodeRec keeps the
+// meta bits of az_common.h (EXPANDED = kind 2) so the search code reads as before; the packed state of an expanded node lives in t.key.
 struct NodeRec {
-    uint64_t ctr, key;
+    uint64_t ctr;
     uint32_t prior, meta, link, child_base;
 };
-AZ_D uint4* node_ptr(const TreeDev& t, size_t base, uint32_t slot) { return t.node + (base + slot) * 2; }
-AZ_D NodeRec node_load(const uint4* p) {
-    const uint4 a = p[0], b = p[1];
-    return NodeRec{((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, b.x, b.y, b.z, b.w};
+AZ_HD uint32_t node_word(uint32_t meta, uint32_t link, uint32_t child_base) {
+    const uint32_t kind = link != NONE ? 1u : ((meta & META_EXPANDED) ? 2u : 0u);
+    const uint32_t payload = kind == 1u ? link : (kind == 2u ? child_base / (uint32_t)BLOCK_SLOTS : 0u);
+    return (meta & 0x3Fu) | (((meta >> META_ECODE_SHIFT) & 0xFu) << 6) | (kind << 10) | (payload << 12);
 }
-AZ_D void node_store(uint4* p, uint64_t ctr, uint64_t key, uint32_t prior, uint32_t meta, uint32_t link, uint32_t child_base) {
-    p[0] = make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)key, (uint32_t)(key >> 32));
-    p[1] = make_uint4(prior, meta, link, child_base);
+AZ_D uint4* node_ptr(const TreeDev& t, size_t base, uint32_t slot) { return t.node + (base + slot); }
+AZ_D NodeRec node_load(const uint4* p) {
+    const uint4 a = p[0];
+    const uint32_t w = a.w, kind = (w >> 10) & 3u, payload = w >> 12;
+    NodeRec r;
+    r.ctr = ((uint64_t)a.y << 32) | a.x;
+    r.prior = a.z;
+    r.meta = (w & 0x3Fu) | (((w >> 6) & 0xFu) << META_ECODE_SHIFT) | (kind == 2u ? META_EXPANDED : 0u);
+    r.link = kind == 1u ? payload : NONE;
+    r.child_base = kind == 2u ? payload * (uint32_t)BLOCK_SLOTS : 0u;
+    return r;
+}
+AZ_D void node_store(const TreeDev& t, size_t base, uint32_t slot, uint64_t ctr, uint64_t key, uint32_t prior, uint32_t meta, uint32_t link,
+                     uint32_t child_base) {
+    t.node[base + slot] = make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), prior, node_word(meta, link, child_base));
+    if (meta & META_EXPANDED) t.key[base + slot] = key;           // only expanded nodes have a state (and only they are looked up by it)
 }
 AZ_D uint64_t node_ctr(const uint4* p) { return *(const unsigned long long*)p; }
 AZ_D void node_set_ctr(uint4* p, uint64_t v) { *(unsigned long long*)p = v; }
-AZ_D uint64_t node_key(const uint4* p) { return ((const unsigned long long*)p)[1]; }
-AZ_D void node_set_prior(uint4* p, uint32_t bits) { ((uint32_t*)p)[4] = bits; }
-AZ_D void node_set_meta(uint4* p, uint32_t meta) { ((uint32_t*)p)[5] = meta; }
-AZ_D void node_set_link(uint4* p, uint32_t link) { ((uint32_t*)p)[6] = link; }
+AZ_D uint64_t node_key(const TreeDev& t, size_t base, uint32_t slot) { return t.key[base + slot]; }
+AZ_D void node_set_prior(uint4* p, uint32_t bits) { ((uint32_t*)p)[2] = bits; }
+// rewrite the word of a record whose fields the caller holds (meta changes, or a placeholder becoming a link)
+AZ_D void node_set_word(uint4* p, uint32_t meta, uint32_t link, uint32_t child_base) { ((uint32_t*)p)[3] = node_word(meta, link, child_base); }
 
 // `seen.get(&s)` (src/node.rs:282): GW-wide linear probe.  found = node slot or NONE;
 // ins = first empty position (where `seen.insert` will go, src/node.rs:320).
@@ -68,7 +84,7 @@ AZ_D void hash_find(const TreeDev& t, int g, size_t base, typename G::State s, i
         uint32_t idx = tab[pos];
         bool empty = idx == NONE;
         bool match = false;
-        if (!empty) match = node_key(node_ptr(t, base, idx)) == key;
+        if (!empty) match = node_key(t, base, idx) == key;
         uint32_t em = gballot<GW>(empty), mm = gballot<GW>(match);
         int fe = em ? (__ffs((int)em) - 1) : GW;
         uint32_t before = mm & ((1u << fe) - 1u);
@@ -104,12 +120,12 @@ AZ_D bool node_upgrade(const TreeDev& t, TreeHead& h, int g, size_t base, uint32
     h.len = cbase + BLOCK_SLOTS;
     h.count += extra + nv;
     if (sub == 0) {
-        node_store(node_ptr(t, base, slot), ctr_value, G::pack(s), prior_bits,
+        node_store(t, base, slot, ctr_value, G::pack(s), prior_bits,
                    a | (nv << META_NCHILD_SHIFT) | META_EXPANDED | (ec << META_ECODE_SHIFT) | (ec == E_NONE ? lock_if_live : 0u), NONE, cbase);
         t.hash[(size_t)g * t.H + ins_pos] = slot;
     }
     if ((uint32_t)sub < nv)
-        node_store(node_ptr(t, base, cbase + sub), CTR_INIT, 0ull, 0u, nth_set_bit<G::ACTIONS>(vm, (uint32_t)sub), NONE, 0u);
+        node_store(t, base, cbase + sub, CTR_INIT, 0ull, 0u, nth_set_bit<G::ACTIONS>(vm, (uint32_t)sub), NONE, 0u);
     *ecode_out = ec;
     return true;
 }
@@ -367,7 +383,7 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth,
         // best_child, src/node.rs:343-370
         const uint32_t nchild = (pr.meta >> META_NCHILD_SHIFT) & 7u, cb = pr.child_base;
         const float sq = puct_sqrt_parent(ctr_n(pc));
-        NodeRec cr{0ull, 0ull, 0u, 0u, NONE, 0u};
+        NodeRec cr{0ull, 0u, 0u, NONE, 0u};
         float u = 0.0f;
         if ((uint32_t)sub < nchild) {
             // the child's record carries its own counter; only a link slot needs the second, dependent fetch of the
@@ -414,7 +430,6 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth,
         if (clink != NONE) { cur = clink; ++depth; continue; }  // Exists(false): follow the link (S2: one level per iteration)
         if (cmeta & META_EXPANDED) {                             // Exists(true)
             pr.ctr = gshfl64<GW>(cr.ctr, (int)best);
-            pr.key = gshfl64<GW>(cr.key, (int)best);
             pr.meta = cmeta;
             pr.child_base = gshfl<GW>(cr.child_base, (int)best);
             have_pr = true;
@@ -423,11 +438,12 @@ AZ_D typename G::State select_body(const TreeDev& t, TreeHead& h, PathRegs& pth,
             continue;
         }
         // PlaceHolder (:261-268, S3): expand it.  B1: play the child's own action.
-        const typename G::State s2 = G::play(G::unpack(pr.key), (int)(cmeta & META_A_MASK));       // :284-287 (B5)
+        // the parent's state: the one fetch of a simulation that goes to the key array (the levels above only read 16-byte records)
+        const typename G::State s2 = G::play(G::unpack(node_key(t, base, cur)), (int)(cmeta & META_A_MASK));       // :284-287 (B5)
         uint32_t found, ins;
         hash_find<G>(t, g, base, s2, sub, &found, &ins);
         if (found != NONE) {                                    // upgrade -> Some(false): become a link (src/node.rs:285-289)
-            if (sub == 0) node_set_link(node_ptr(t, base, cslot), found);
+            if (sub == 0) node_set_word(node_ptr(t, base, cslot), cmeta, found, 0u);
             cur = found;
             ++n_link;
             continue;                                           // :297-298
@@ -538,7 +554,7 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const 
     if (kind == LEAF_EVAL || kind == LEAF_ROOT) {
         uint4* lp = node_ptr(t, base, leaf);
         const NodeRec lr = node_load(lp);
-        const typename G::State s = G::unpack(lr.key);
+        const typename G::State s = G::unpack(node_key(t, base, leaf));
         const uint32_t src = h.src;
         if constexpr (INLINE_PV) {
             pv = pv_in;
@@ -580,7 +596,7 @@ AZ_D void backup_body(const TreeDev& t, TreeHead& h, const PathRegs& pth, const 
         const uint32_t myact = (uint32_t)sub < nchild ? nth_set_bit<NA>(vm, (uint32_t)sub) : 0u;
         const float pa = gshflf<GW>(p, (int)myact);
         if ((uint32_t)sub < nchild) node_set_prior(node_ptr(t, base, cb + sub), __float_as_uint(pa));   // set_policy, :348
-        if (sub == 0) node_set_meta(lp, (lr.meta | META_HAS_PRIOR) & ~META_LOCKED);      // set_policy + unlock, :348-351
+        if (sub == 0) node_set_word(lp, (lr.meta | META_HAS_PRIOR) & ~META_LOCKED, lr.link, lr.child_base);      // set_policy + unlock, :348-351
         h.stat[ST_LEAF_EVALS] += 1;
         val = -v;                                                   // :353 (C9)
     } else {
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(64) void k_root_policy(TreeDev t, float temp, uint6
     if (g >= t.G) return;
     const TreeHead h = head_load(t, g);
     if (!h.active) return;
-    const typename G::State s = G::unpack(node_key(node_ptr(t, (size_t)g * t.R, h.root)));
+    const typename G::State s = G::unpack(node_key(t, (size_t)g * t.R, h.root));
     RootPolicy rp = root_policy<G>(t, h.root, g, sub, temp, seed, first_game_id + (uint64_t)g, (uint64_t)G::stones(s));
     if (sub < NA) {
         pi[(size_t)g * NA + sub] = rp.pi;

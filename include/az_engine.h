@@ -134,6 +134,8 @@ const char* az_last_error(const az_engine* e);
  *            "conv3_small"  1 (default): conv3 of a small expected batch runs on the 4-stage LDS-DMA ring; 0: never.  Bit-identical
  *            "conv3_tail"   1 (default): a short last round of conv3 workgroups is cut into half tiles; 0: full tiles.  Bit-identical
  *            "conv3_planes" 1 (default): conv3's LDS image in the bank-conflict-free layout; 0: image rows in order.  Bit-identical
+ *            "ring_packed"  1 (default): the LDS-DMA ring kernels (conv4, fc1, fc2, small conv3) stream their weight stages from a packed
+ *                           copy of the model (16 KiB of consecutive bytes per stage); 0: from the [N][K] weights.  Bit-identical
  *            "narrow_rows"  n (default 32, 0 = off): batches of at most n boards (conv3; 2n for conv4, 4n for the FCs) run the
  *                           register-fed skinny GEMM; the hand-over is decided on the device from the exact row count.  Bit-identical
  *   search   "search_graph" n (default 20, even, 0 = off): n simulation steps per captured hipGraph replay (conv nets) ...

@@ -370,18 +370,20 @@ def test_shipped_kernel_choices_are_bit_identical(engine, oracle):
         for table in (1, 0):
             engine.set_option("conv2_table", table)
             for n in (8192, 5003, 3100, 2304, 1537, 771, 357, 300, 129, 64, 33, 13, 1):
-                for key in ("conv3_tail", "narrow_rows", "conv3_small", "conv3_planes"):
+                for key in ("conv3_tail", "narrow_rows", "conv3_small", "conv3_planes", "ring_packed"):
                     engine.set_option(key, 0)
                 ref = engine.predict_states(states[:n], 26)
-                for t3, nr, s3, pl in ((1, 0, 0, 0), (0, 8192, 0, 0), (1, 32, 1, 0), (0, 100, 1, 1), (1, 16, 0, 1), (0, 0, 0, 1), (1, 0, 0, 1)):
+                for t3, nr, s3, pl, rp in ((1, 0, 0, 0, 0), (0, 8192, 0, 0, 0), (1, 32, 1, 0, 1), (0, 100, 1, 1, 0), (1, 16, 0, 1, 1), (0, 0, 0, 1, 1),
+                                           (1, 0, 0, 1, 0), (0, 0, 1, 0, 1)):
                     engine.set_option("conv3_tail", t3)
                     engine.set_option("narrow_rows", nr)
                     engine.set_option("conv3_small", s3)
                     engine.set_option("conv3_planes", pl)
+                    engine.set_option("ring_packed", rp)     # the ring's weight stages from the packed copy (conv3 small, conv4, fc1, fc2)
                     got = engine.predict_states(states[:n], 26)
-                    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (table, n, t3, nr, s3, pl)
+                    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (table, n, t3, nr, s3, pl, rp)
     finally:
-        for key, val in (("conv2_table", 1), ("conv3_tail", 1), ("narrow_rows", 32), ("conv3_small", 1), ("conv3_planes", 1)):
+        for key, val in (("conv2_table", 1), ("conv3_tail", 1), ("narrow_rows", 32), ("conv3_small", 1), ("conv3_planes", 1), ("ring_packed", 1)):
             engine.set_option(key, val)
 
 
