@@ -274,6 +274,8 @@ struct GemmDesc {
     // estimate cannot tell; exactly one of them finds the batch's row count on its side of the line and runs):
     int m_min;                 // tiled kernels: do nothing when the batch has at most this many output rows (0 = always run)
     int m_max;                 // k_gemm_skinny: do nothing when the batch has more than this many output rows
+    int m_hi;                  // k_gemm_ring_auto: do nothing when the batch has more than this many output rows (0 = no upper bound): the two ring
+                               // families of a layer are both launched when the host's estimate cannot tell which one the batch needs
     unsigned long long* acct;  // k_conv3_auto: {rows, working launches} it has processed (device counters of the workspace)
     const uint16_t* c3tab;     // conv_valid_tile<.., PLANES>: the LDS image's cell maps (Conv3Tables, built by convnet_prepare's workspace)
     const uint16_t* Wp;        // k_conv3_pp: the layer's weights packed as LDS stage images (ConvNet::wp3), nullptr = not available
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void k_gemm_ring_auto(const
     constexpr int BMAX = NS == 2 ? 192 : 128;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BMAX * 128 + 16384)];
     const int M = (int)(*d.n_dev) * d.rows_per_sample;
-    if (M <= d.m_min) return;                          // the small-batch kernel launched beside this one takes the batch
+    if (M <= d.m_min || (d.m_hi > 0 && M > d.m_hi)) return;      // another kernel launched beside this one takes the batch
     const int bm = __builtin_amdgcn_readfirstlane(ring_pick_bm(M, d.N / GBN, NS, d.tap_w > 1));
     if constexpr (NS == 2) {
         if (bm == 96) gemm_ring_body<2, 96>(d, smem, M);
@@ -2136,11 +2138,28 @@ template <int LAYER>
 static void launch_ring_auto(const GemmDesc& d, int rows_hint, int rows_typ, hipStream_t s, bool force_one_per_cu = false) {
     const int m_est = (int)((rows_typ > 0 ? (long long)rows_typ * 115 / 100 : (long long)rows_hint) * d.rows_per_sample), ncol = d.N / GBN;
     const bool conv = d.tap_w > 1;
-    const bool one_per_cu = force_one_per_cu || (m_est + (conv ? 95 : 127)) / (conv ? 96 : 128) * ncol <= 256;
-    const int bmin = one_per_cu ? 64 : 96;                                   // the grid covers the smallest tile of the family
-    const int mtb = ((rows_hint * d.rows_per_sample + bmin - 1) / bmin + 7) / 8 * 8;
-    if (one_per_cu) hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 4>), dim3(mtb * ncol), dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 2>), dim3(mtb * ncol), dim3(256), 0, s, d);
+    const int tile_max = conv ? 96 : 128;                                    // the largest tile of the one-workgroup-per-CU family
+    const int m_one = 256 / ncol * tile_max;                                 // the most rows that family covers in ONE round
+    const int m_bound = rows_hint * d.rows_per_sample;
+    auto launch = [&](bool one_per_cu, const GemmDesc& dd, int m_cover) {
+        const int bmin = one_per_cu ? 64 : 96;                               // the grid covers the smallest tile of the family
+        const int mtb = ((m_cover + bmin - 1) / bmin + 7) / 8 * 8;
+        if (one_per_cu) hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 4>), dim3(mtb * ncol), dim3(256), 0, s, dd);
+        else hipLaunchKernelGGL((k_gemm_ring_auto<LAYER, 2>), dim3(mtb * ncol), dim3(256), 0, s, dd);
+    };
+    // The estimate (the previous move's largest batch) cannot tell the families apart near the line: a batch just under it on the two-per-CU
+    // family is 43 instead of ~30 us for fc1, one just over it on the one-per-CU family a whole second round.  Near the line BOTH are
+    // launched and each checks the batch's exact row count on the device (m_hi / m_min): one runs, the other exits at once.
+    if (!force_one_per_cu && !conv && m_bound > m_one && (long long)m_est * 100 >= (long long)m_one * 70 && (long long)m_est * 100 <= (long long)m_one * 140) {
+        GemmDesc lo = d, hi = d;
+        lo.m_hi = m_one;
+        hi.m_min = std::max(d.m_min, m_one);
+        launch(true, lo, std::min(m_bound, m_one));
+        launch(false, hi, m_bound);
+        return;
+    }
+    const bool one_per_cu = force_one_per_cu || m_bound <= m_one || (m_est + tile_max - 1) / tile_max * ncol <= 256;     // the bound itself fits one round
+    launch(one_per_cu, d, m_bound);
 }
 
 #ifdef AZ_DIAG

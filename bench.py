@@ -395,6 +395,14 @@ def main():
             "net_flops": {"per_row_executed": flop_exec, "per_row_as_dense": FLOP_PER_LEAF, "conv2_table": args.conv2_table,
                           "fraction_as_dense": (rows_exec / dt) * FLOP_PER_LEAF / (MFMA_PEAK_TFLOPS * 1e12 * world)} if args.net == "conv" else None,
         }
+        if args.net == "conv":
+            # exact, counted on the device over EVERY forward of the TIMED region (independent of the brackets): what a profiler's total
+            # k_conv3_auto time over the same region has to be divided by (the smallest batches run conv3 on the ring / skinny kernels,
+            # and the idle half of a dual launch does no work)
+            line["k_conv3_auto_accounting_timed_region"] = {
+                "rows": st_timed["net_conv3_image_rows"], "working_launches": st_timed["net_conv3_image_launches"],
+                "rows_per_working_launch": st_timed["net_conv3_image_rows"] / max(1, st_timed["net_conv3_image_launches"]),
+                "flop_per_row": 2.0 * 20 * 512 * 4608}
         roof = None
         if not args.no_profile and args.net == "conv" and st["net_launches"] > 0:
             pmc, pmc_name = committed_pmc()

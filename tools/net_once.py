@@ -9,6 +9,9 @@ e = azeng.Engine(device=0, max_batch=B, diag=True)
 e.net_init_random(0, 1)
 if len(sys.argv) > 3:
     e.set_option("gemm_variant", int(sys.argv[3]))
+for kv in filter(None, os.environ.get("OPT", "").split(",")):      # OPT=key=value,...: e.g. conv3_pp=1 (diagnostic library)
+    k, v = kv.split("=")
+    e.set_option(k, int(v))
 uniq = random_states(512, 3)
 states = uniq[np.random.default_rng(0).integers(0, 512, B)]
 for _ in range(reps):
