@@ -15,7 +15,12 @@
  *   - Every call returns an az_status (0 = ok).  The reference panics instead
  *     (unwrap/assert!); the panic sites map onto the status codes below.
  *   - A handle is used by one host thread at a time; calls are synchronous on
- *     return.  One HIP stream per engine.
+ *     return.  One HIP stream per engine.  Engines on different devices may be
+ *     driven from different host threads freely.  Two engines on the SAME device
+ *     driven from two threads at once need "search_graph" 0 on both: while one
+ *     thread captures its search loop as a hipGraph, HIP refuses the blocking
+ *     copies of the other thread (hipErrorStreamCaptureImplicit, reported as
+ *     AZ_ERR_HIP).  Measured gain of that arrangement: none (profiles/README.md).
  *   - Game state: Connect Four as two 7x6 bitboards in canonical form
  *     {mine, theirs} (side to move = mine); bit(col,row) = col*7 + row with
  *     row 0 = bottom; bit col*7+6 is always clear.
