@@ -170,7 +170,9 @@ const char* az_last_error(const az_engine* e);
  *   NNet::train  "train_epochs" (10), "train_batch" (64, <= 256), "train_seed" (0), "train_lr_e9" (1000000 = 1e-3),
  *            "train_dropout_e6" (300000 = 0.3), "train_graph" 1 (default) / 0: replay a step's launches as a captured hipGraph,
  *            "train_gemm" 1 (default): dgrad / wgrad as bf16 x 3 on the bf16 matrix cores (gradients within 1e-5 of float64
- *                           autograd), 0: every GEMM on v_mfma_f32_16x16x4_f32 (1e-6),
+ *                           autograd), 0: every GEMM on v_mfma_f32_16x16x4_f32 (1e-6).  Two numerics classes: the trained
+ *                           weights differ, as they do between two f32 summation orders (parity of NNet::train is unpinned by
+ *                           the reference, whose training script cannot run; tests/test_train_gpu.py bounds the drift),
  *            "train_fwd_dma" 1 (default): the forward GEMMs' tiles go global -> LDS by LDS-DMA (k_gemm_f32_dma), 0: register-staged
  * libaz_engine_diag.so (the same sources built with -DAZ_DIAG; alphazero-rs_amd/build.py) additionally takes the keys of the
  * SUPERSEDED kernel generations and the TIMING ABLATIONS WITH WRONG RESULTS -- "gemm_variant", "fc_ring", "ring_tile", "conv3_ring",
