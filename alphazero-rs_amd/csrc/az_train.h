@@ -49,6 +49,8 @@ bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards,
                        const int64_t* d_idx, int64_t steps, int b, uint64_t seed_key, uint64_t gstep0, hipStream_t s);
 void trainer_set_graph(Trainer* t, bool on);      // A/B switch: replay a captured graph (default) or launch directly
 void trainer_set_fwd_dma(Trainer* t, bool on);    // 1 (default): forward GEMMs fed by LDS-DMA (k_gemm_f32_dma); 0: register-staged k_gemm_f32
+void trainer_set_fork(Trainer* t, bool on);       // true: a step's wgrad chains on a second stream branch, joined before Adam (default false: no gain)
+void trainer_set_gemm3_ring(Trainer* t, bool on); // true (default): the big bf16 x 3 GEMMs on k_gemm3_ring (one 8-wave workgroup per CU, 3-stage ring)
 void trainer_set_gemm(Trainer* t, int mode);      // 1 (default): the GEMMs as bf16 x 3 on the bf16 matrix cores; 0: v_mfma_f32_16x16x4_f32
 
 }  // namespace az

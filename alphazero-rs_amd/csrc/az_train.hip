@@ -172,8 +172,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_dma(const GemmF32 g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int kbeg = blockIdx.z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+    // workgroup ids go round the 8 XCDs: XCD x takes the x-th eighth of the list of (K slice, row tile, column tile), so the column tiles
+    // that stream the same A rows share one XCD's L2 (k_gemm3_ring has the same map)
+    const int NT = g.N / 128, tiles = ((g.M + 127) / 128) * NT, total = tiles * g.splits;
+    const int nper = (total + 7) >> 3;
+    const int t = ((int)blockIdx.x & 7) * nper + ((int)blockIdx.x >> 3);
+    if (t >= total) return;
+    const int split = t / tiles, rem = t - split * tiles;
+    const int m0 = (rem / NT) * 128, n0 = (rem % NT) * 128;
+    const int kbeg = split * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg) / GD_BK;
     // DMA maps.  A: piece p (16 rows) of wave w = w, w + 4; lane -> row p*16 + (lane >> 2), position lane & 3 holding quad (lane & 3) ^ F(row)
     const uint32_t fA = (0x78u >> ((((uint32_t)lane >> 4) & 3u) * 2u)) & 3u;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_dma(const GemmF32 g) {
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef AZ_GDDMA
-    float* cbase = g.splits > 1 ? g.C + (int64_t)blockIdx.z * g.M * g.N : g.C;
+    float* cbase = g.splits > 1 ? g.C + (int64_t)split * g.M * g.N : g.C;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wr * 64 + mt * 16 + fr;
@@ -431,6 +438,124 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = m0 + wr * (G3_BM / 2) + mt * 16 + frow;
+            if (m >= g.M) continue;
+            *(float4*)(obase + (size_t)m * ldo + n) =
+                make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+        }
+    }
+}
+
+// The same product on ONE 8-wave workgroup per CU: tile 256 x 128, so a K-step moves 48 KiB (A hi / lo 16 KiB each, W hi / lo 8 KiB each)
+// for the MFMAs k_gemm3's two workgroups need 64 KiB for, and a ring of THREE stages keeps two of them in flight all the time (k_gemm3
+// has one, issued when the previous one has landed: its L2 -> LDS stream idles a latency per step and the kernel runs at about 11 B/clk
+// per CU where the inference side's rings reach 19-25).  Wave w = (row group w >> 1 of 64 rows, column half w & 1): the same 64 x 64
+// register tile, fragment geometry, chunk permutation and product order as k_gemm3 -- for one split-K plan the two kernels give the same
+// bits.  DMA pieces of 16 rows (1 KiB): wave w loads pieces w and w + 8 of A hi and of A lo, piece w of W hi and of W lo (6 per stage).
+constexpr int G3R_BM = 256, G3R_A = 256 * 64, G3R_W = 128 * 64, G3R_STAGE = 2 * G3R_A + 2 * G3R_W, G3R_NS = 3;
+
+__global__ __launch_bounds__(512, 1) void k_gemm3_ring(const Gemm3 g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_r[G3R_NS * G3R_STAGE];
+    constexpr int MT = 4;
+    // Workgroup ids go round the 8 XCDs: XCD x takes the x-th eighth of the list of (K slice, row tile, column tile) in that order, so the
+    // column tiles of a row tile -- which stream the same A rows -- run on one XCD at the same time and share its L2, and every XCD gets
+    // the same number of tiles whatever the tile counts are.
+    const int NT = g.N / 128, tiles = ((g.M + G3R_BM - 1) / G3R_BM) * NT, total = tiles * g.splits;
+    const int nper = (total + 7) >> 3;
+    const int t = ((int)blockIdx.x & 7) * nper + ((int)blockIdx.x >> 3);
+    if (t >= total) return;
+    const int split = t / tiles, rem = t - split * tiles;
+    const int mtile = rem / NT, ntile = rem - mtile * NT;
+    const int m0 = mtile * G3R_BM, n0 = ntile * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const uint32_t fD = (0x78u >> ((((uint32_t)lane >> 4) & 3u) * 2u)) & 3u;
+    const uint32_t chunk = ((uint32_t)lane & 3u) ^ fD;
+    uint32_t a_ob[2], b_ob;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + (wave + 8 * i) * 16 + (lane >> 2);
+        m = m < g.M ? m : g.M - 1;
+        a_ob[i] = (uint32_t)(m * g.lda + (int)chunk * 8) * 2u;
+    }
+    b_ob = (uint32_t)((n0 + wave * 16 + (lane >> 2)) * g.ldw + (int)chunk * 8) * 2u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)(smem_r + wave * 1024);
+    const int t0 = split * g.steps_per_split;
+    const int nk = min(g.Kc / 32, t0 + g.steps_per_split) - t0;
+    int kin = t0;
+#define AZ_G3RDMA(buf_)                                                                                 \
+    {                                                                                                   \
+        const char* ah = (const char*)(g.a_hi + kin * 32);                                              \
+        const char* al = (const char*)(g.a_lo + kin * 32);                                              \
+        const char* wh = (const char*)(g.w_hi + kin * 32);                                              \
+        const char* wl = (const char*)(g.w_lo + kin * 32);                                              \
+        const uint32_t la = lds0 + (buf_) * G3R_STAGE;                                                  \
+        train_dma16(ah, a_ob[0], la);                                                                   \
+        train_dma16(ah, a_ob[1], la + 8192);                                                            \
+        train_dma16(wh, b_ob, la + 2 * G3R_A);                                                          \
+        train_dma16(wl, b_ob, la + 2 * G3R_A + G3R_W);                                                  \
+        train_dma16(al, a_ob[0], la + G3R_A);                                                           \
+        train_dma16(al, a_ob[1], la + G3R_A + 8192);                                                    \
+        ++kin;                                                                                          \
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    const int coff = (fq ^ (int)((0x78u >> ((((uint32_t)frow >> 2) & 3u) * 2u)) & 3u)) << 4;
+    const int a_row = (wr * 64 + frow) * 64 + coff, b_row = (wc * 64 + frow) * 64 + coff;
+    if (nk > 0) AZ_G3RDMA(0);
+    if (nk > 1) AZ_G3RDMA(1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed: of this wave's pieces only stage kt + 1's six may still be in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... for every wave, and every wave is done with stage kt - 1's buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) { const int nb = buf == 0 ? 2 : buf - 1; AZ_G3RDMA(nb); }      // (kt + 2) % 3 == (kt - 1) % 3
+        const unsigned char* sAh = smem_r + buf * G3R_STAGE;
+        const unsigned char* sAl = sAh + G3R_A;
+        const unsigned char* sWh = sAh + 2 * G3R_A;
+        const unsigned char* sWl = sWh + G3R_W;
+        bf16x8_t ah[MT], al[MT], wh[4], wl[4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const bf16x8_t*)(sAh + a_row + mt * 1024);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wh[nt] = *(const bf16x8_t*)(sWh + b_row + nt * 1024);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wl[nt] = *(const bf16x8_t*)(sWl + b_row + nt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const bf16x8_t*)(sAl + a_row + mt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+#undef AZ_G3RDMA
+    float* obase = g.splits > 1 ? g.out + (size_t)split * g.M * g.N : g.out;
+    const int ldo = g.splits > 1 ? g.N : g.ldo;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias && g.splits == 1) bv = *(const float4*)(g.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wr * 64 + mt * 16 + frow;
             if (m >= g.M) continue;
             *(float4*)(obase + (size_t)m * ldo + n) =
                 make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
@@ -991,6 +1116,15 @@ struct Trainer {
     EpochCounters* counters = nullptr;
     bool use_graph = true;
     size_t splitk_floats = 0;
+    // second branch of a step (gemm_mode 1): the weight split and every layer's wgrad chain (transposes, k_gemm3, split-K reduce) run on
+    // `side`, forked from / joined to the caller's stream by events, with their own split-K workspace; the caller's stream keeps the
+    // chain the next layer waits for (BatchNorm backward, dgrad, col2im).  Same kernels on the same data: bit-identical to fork = false.
+    bool gemm3_ring = true;            // dgrad / wgrad with >= 192 rows on k_gemm3_ring (256 x 128 tiles, 3-stage ring) instead of k_gemm3
+    bool fork = false;                 // measured: no gain as direct launches, 7 % slower inside a hipGraph (profiles/README.md)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_start = nullptr, ev_sw = nullptr, ev_join = nullptr, ev_dz[6] = {nullptr}, ev_tr[6] = {nullptr};
+    float* splitk2 = nullptr;
+    size_t splitk2_floats = 0;
     int64_t step = 0;
     double pow1 = 1.0, pow2 = 1.0;     // beta1^step, beta2^step
     template <class T> T* dalloc(size_t n) {
@@ -1049,6 +1183,13 @@ Trainer* trainer_create(int channels, const char** err) {
     }
     t->splitk_floats = (size_t)96 << 20;      // 384 MiB (a conv2-sized dgrad at the largest batch has 49.5 M outputs; it is never split)
     ok &= (t->splitk = t->dalloc<float>(t->splitk_floats)) != nullptr;
+    t->splitk2_floats = (size_t)16 << 20;     // wgrad outputs are [K][N] <= 1152 x 128 or 768 x 1024 floats per slice
+    ok &= (t->splitk2 = t->dalloc<float>(t->splitk2_floats)) != nullptr;
+    ok &= hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t* ev : {&t->ev_start, &t->ev_sw, &t->ev_join}) ok &= hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; l < 6; ++l)
+        ok &= hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&t->ev_tr[l], hipEventDisableTiming) == hipSuccess;
     if (!ok) { if (err) *err = "hipMalloc failed for the trainer workspace"; trainer_destroy(t); return nullptr; }
     (void)hipMemset(t->loss_totals, 0, 2 * sizeof(double));
     return t;
@@ -1056,6 +1197,9 @@ Trainer* trainer_create(int channels, const char** err) {
 
 void trainer_destroy(Trainer* t) {
     if (!t) return;
+    if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    for (hipEvent_t ev : {t->ev_start, t->ev_sw, t->ev_join}) if (ev) (void)hipEventDestroy(ev);
+    for (int l = 0; l < 6; ++l) { if (t->ev_dz[l]) (void)hipEventDestroy(t->ev_dz[l]); if (t->ev_tr[l]) (void)hipEventDestroy(t->ev_tr[l]); }
     for (void* p : t->dev) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
     delete t;
@@ -1133,14 +1277,14 @@ void gemm_nn(const float* A, int64_t lda, const float* W, float* Cm, const float
     if (dma && M >= 128 && K % GD_BK == 0 && K >= 8 * GD_BK && N % 128 == 0 && lda % 4 == 0) {
         // k_gemm_f32_dma: 128 x 128 tiles, two workgroups per CU (512 slots a round), at least 8 K-steps per slice
         const int tiles = ((M + 127) / 128) * (N / 128), ksteps = K / GD_BK;
-        int splits = std::max(1, std::min((512 + tiles / 2) / tiles, ksteps / 8));
+        int splits = std::max(1, std::min(512 / tiles, ksteps / 8));      // never a second round of a few workgroups
         while (splits > 1 && (size_t)splits * M * N > wsn) --splits;
         const int k_per = ((ksteps + splits - 1) / splits) * GD_BK;
         splits = (K + k_per - 1) / k_per;
         g.k_per_split = k_per;
         g.splits = splits;
         if (splits > 1) { g.C = ws; g.bias = nullptr; }
-        hipLaunchKernelGGL(k_gemm_f32_dma, dim3(N / 128, (M + 127) / 128, splits), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(k_gemm_f32_dma, dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(256), 0, s, g);
         if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, Cm, (int64_t)N, bias);
         return;
     }
@@ -1162,9 +1306,26 @@ int red_parts(int M) { return std::max(1, std::min(RED_PARTS, (M + 63) / 64)); }
 // out[M][N] (row stride ldo) = A W^T (+ bias) as bf16 x 3: A hi / lo [M][lda], W hi / lo [N][ldw], both contiguous along the contraction
 // Kc.  Split-K so that about two workgroups per CU exist (a workgroup walks at least 8 K-steps); the slices are summed in slice order.
 void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* out, int ldo,
-                  const float* bias, int M, int N, int Kc, float* ws, size_t ws_floats, hipStream_t s) {
-    const int mt = (M + G3_BM - 1) / G3_BM, NT = N / 128, tiles = mt * NT;
+                  const float* bias, int M, int N, int Kc, float* ws, size_t ws_floats, hipStream_t s, bool ring = false) {
     const int steps = Kc / 32;
+    const int mt_r = (M + G3R_BM - 1) / G3R_BM;
+    // at most a tenth of the row tiles' rows beyond M, and a contraction long enough to fill and drain the ring (conv4's wgrad has 12
+    // K-steps: 14.9 us on k_gemm3, 15.8 on the ring)
+    if (ring && steps >= 16 && (mt_r * G3R_BM - M) * 10 <= mt_r * G3R_BM) {
+        // k_gemm3_ring: 256 x 128 tiles, ONE workgroup per CU: never more than 256 of them while the tiles fit (a second round of a few
+        // workgroups costs a whole round), at least 6 K-steps per slice (the ring is 3 deep)
+        const int mt = mt_r, NT = N / 128, tiles = mt * NT;
+        int splits = std::max(1, std::min(256 / tiles, steps / 6));
+        while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
+        const int sps = (steps + splits - 1) / splits;
+        splits = (steps + sps - 1) / sps;
+        Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, 0};
+        hipLaunchKernelGGL(k_gemm3_ring, dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
+        if (splits > 1)
+            hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
+        return;
+    }
+    const int mt = (M + G3_BM - 1) / G3_BM, NT = N / 128, tiles = mt * NT;
     int splits = std::max(1, std::min((512 + tiles / 2) / tiles, steps / 8));
     while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
     const int sps = (steps + splits - 1) / splits;
@@ -1218,6 +1379,22 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     constexpr int APPLY_ROWS = 32;      // rows per block of the apply kernels
     // ---- forward ----
     const bool x3 = t->gemm_mode == 1;
+    const bool fork = x3 && t->fork && t->side;
+    hipStream_t s2 = fork ? t->side : s;
+    auto hand = [&](hipEvent_t ev, hipStream_t from, hipStream_t to) {       // `to` continues after everything enqueued on `from` so far
+        if (fork) { (void)hipEventRecord(ev, from); (void)hipStreamWaitEvent(to, ev, 0); }
+    };
+    auto split_weights = [&]() {
+        SplitWeights sw{};
+        const int64_t offs[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
+        for (int i = 0; i < 5; ++i) { sw.off[i] = offs[i]; sw.count[i] = (int64_t)ld[i + 1].K * ld[i + 1].N; }
+        hipLaunchKernelGGL(k_split_weights, dim3(256, 5), dim3(256), 0, s2, (const float*)P, sw, t->w_hi, t->w_lo);
+    };
+    if (fork) {                      // the weight split needs the parameters only: under the forward pass
+        hand(t->ev_start, s, s2);
+        split_weights();
+        (void)hipEventRecord(t->ev_sw, s2);
+    }
     if (!col1_done) hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
@@ -1240,12 +1417,8 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     // ---- backward ----
     hipLaunchKernelGGL(k_heads_bwd, grid1(std::max<int64_t>(512 * 8 + 8, (int64_t)b * 512)), dim3(256), 0, s, t->a[5], t->dhead,
                        P + L.pi_w, P + L.v_w, b, G + L.pi_w, G + L.pi_b, G + L.v_w, G + L.v_b, t->dact, t->sample_loss, t->loss_totals);
-    if (x3) {
-        SplitWeights sw{};
-        const int64_t offs[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
-        for (int i = 0; i < 5; ++i) { sw.off[i] = offs[i]; sw.count[i] = (int64_t)ld[i + 1].K * ld[i + 1].N; }
-        hipLaunchKernelGGL(k_split_weights, dim3(256, 5), dim3(256), 0, s, (const float*)P, sw, t->w_hi, t->w_lo);
-    }
+    if (x3 && !fork) split_weights();
+    if (fork) (void)hipStreamWaitEvent(s, t->ev_sw, 0);
     for (int l = 5; l >= 0; --l) {
         const LayerDef& d = ld[l];
         // t->dact holds d loss / d a[l]  ->  dz (through dropout, ReLU and BatchNorm)
@@ -1253,6 +1426,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         const bool g3 = x3 && l >= 1;
         if (g3) { bn.out_hi = t->dz_hi; bn.out_lo = t->dz_lo; }
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
+        if (fork && l <= 4) (void)hipStreamWaitEvent(s, t->ev_tr[l + 1], 0);      // dz is rewritten: the layer above has transposed it
         if (d.M <= BN_SMALL_ROWS) {
             hipLaunchKernelGGL(k_bn_bwd_small, dim3(d.N / BN_COLS), dim3(256), 0, s, bn, G + d.bn, G + d.bn + d.N, st);
         } else {
@@ -1267,11 +1441,15 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             // wgrad: dW [K][N] = A^T dz, both operands transposed so that the contraction (the rows) is contiguous
             const int Mp = (d.M + 63) / 64 * 64;
             const TransposeJob jz{t->dz, t->dzt_hi, t->dzt_lo, d.N, (d.N + 63) / 64, d.N}, ja{d.A, t->at_hi, t->at_lo, d.K, (d.K + 63) / 64, d.lda};
-            launch_transpose_split2(ja, jz, d.M, Mp, s);          // the big one first
-            launch_gemm3(t->at_hi, t->at_lo, Mp, t->dzt_hi, t->dzt_lo, Mp, G + d.w, d.N, nullptr, d.K, d.N, Mp, t->splitk, t->splitk_floats, s);
+            hand(t->ev_dz[l], s, s2);
+            launch_transpose_split2(ja, jz, d.M, Mp, s2);         // the big one first
+            if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
+            launch_gemm3(t->at_hi, t->at_lo, Mp, t->dzt_hi, t->dzt_lo, Mp, G + d.w, d.N, nullptr, d.K, d.N, Mp, fork ? t->splitk2 : t->splitk,
+                         fork ? t->splitk2_floats : t->splitk_floats, s2, t->gemm3_ring);
             // dgrad: d input [M][K] = dz W^T, W [K][N] as stored
             float* din = l >= 4 ? t->dact : t->dcol;
-            launch_gemm3(t->dz_hi, t->dz_lo, d.N, t->w_hi + d.w, t->w_lo + d.w, d.N, din, d.K, nullptr, d.M, d.K, d.N, t->splitk, t->splitk_floats, s);
+            launch_gemm3(t->dz_hi, t->dz_lo, d.N, t->w_hi + d.w, t->w_lo + d.w, d.N, din, d.K, nullptr, d.M, d.K, d.N, t->splitk, t->splitk_floats, s,
+                         t->gemm3_ring);
         } else {
             gemm_tn(d.A, d.lda, t->dz, G + d.w, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
             if (l == 0) break;
@@ -1283,6 +1461,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             hipLaunchKernelGGL(k_col2im, grid1((int64_t)b * H * W * C / 4), dim3(256), 0, s, t->dcol, t->dact, b, H, W, C, pad);
         }
     }
+    hand(t->ev_join, s2, s);
     if (apply)
         hipLaunchKernelGGL(k_adam, grid1(L.total), dim3(256), 0, s, P, G, t->m, t->v, L.total, h.lr, h.beta1, h.beta2, h.adam_eps, st);
 }
@@ -1341,6 +1520,8 @@ bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards,
 
 void trainer_set_graph(Trainer* t, bool on) { if (t) t->use_graph = on; }
 void trainer_set_gemm(Trainer* t, int mode) { if (t) t->gemm_mode = mode; }
+void trainer_set_fork(Trainer* t, bool on) { if (t) t->fork = on; }
+void trainer_set_gemm3_ring(Trainer* t, bool on) { if (t) t->gemm3_ring = on; }
 void trainer_set_fwd_dma(Trainer* t, bool on) { if (t) t->fwd_dma = on; }
 
 }  // namespace az

@@ -517,21 +517,32 @@ def main():
             # synthetic samples at the recipe's batch of 64 -- the other dense workload of the Coach loop
             try:
                 rng = np.random.default_rng(0)
-                nb, bs = 200, 64
-                tb = (rng.random((nb * bs, 2, 6, 7)) < 0.2).astype(np.float32)
-                tp = rng.dirichlet(np.ones(7), nb * bs).astype(np.float32)
-                tv = rng.choice([-1.0, 1.0], nb * bs).astype(np.float32)
+                bs, n_short, n_long = 64, 200, 800
+                tb = (rng.random((n_long * bs, 2, 6, 7)) < 0.2).astype(np.float32)
+                tp = rng.dirichlet(np.ones(7), n_long * bs).astype(np.float32)
+                tv = rng.choice([-1.0, 1.0], n_long * bs).astype(np.float32)
                 e.set_option("train_epochs", 1)
                 e.set_option("train_batch", bs)
                 e.train(0, 1, tb[: 4 * bs], tp[: 4 * bs], tv[: 4 * bs])
-                t1 = time.perf_counter()
-                e.train(0, 1, tb, tp, tv)
-                dtt = time.perf_counter() - t1
-                line["nnet_train"] = {"ms_per_step": dtt / nb * 1e3, "samples_per_sec": nb * bs / dtt, "batch": bs, "steps": nb,
+
+                def call(nb):
+                    t1 = time.perf_counter()
+                    e.train(0, 1, tb[: nb * bs], tp[: nb * bs], tv[: nb * bs])
+                    return time.perf_counter() - t1
+                t_short, t_long = call(n_short), call(n_long)
+                step_s = (t_long - t_short) / (n_long - n_short)          # one optimisation step
+                fixed_s = max(0.0, t_short - n_short * step_s)            # per call: upload, graph capture, the trained model's inference tables
+                line["nnet_train"] = {"ms_per_step": step_s * 1e3, "samples_per_sec": bs / step_s, "batch": bs,
+                                      "steps": [n_short, n_long], "call_ms": [t_short * 1e3, t_long * 1e3], "fixed_ms_per_call": fixed_s * 1e3,
+                                      "ms_per_step_of_the_200_step_call": t_short / n_short * 1e3,
                                       "dtype": "f32 (forward GEMMs on v_mfma_f32_16x16x4_f32; dgrad / wgrad as bf16 x 3 on the bf16 matrix cores, f32 accumulate: "
                                                "gradients within 1e-5 of float64 autograd)",
-                                      "tflops": 3 * FLOP_PER_LEAF * bs / (dtt / nb) / 1e12,
-                                      "note": "az_net_train wall time incl. upload of the samples; ~3x forward FLOPs per sample (f32-equivalent)"}
+                                      "tflops": 3 * FLOP_PER_LEAF * bs / step_s / 1e12,
+                                      "note": "two az_net_train calls (200 and 800 steps of one epoch): ms_per_step is the slope, i.e. one optimisation step; "
+                                              "fixed_ms_per_call is what a call costs besides its steps (sample upload, graph capture, the stored model's "
+                                              "BatchNorm fold + conv tables + packed weights) -- the recipe's call has 10 x n / 64 steps (25,600 at the "
+                                              "example's literals), so rounds 1-3's figure, the 200-step call divided by 200, overstated a step by "
+                                              "fixed / 200; it is kept as ms_per_step_of_the_200_step_call. ~3x forward FLOPs per sample (f32-equivalent)"}
             except Exception as ex:
                 line["nnet_train"] = {"error": repr(ex)}
         if world == 1 and args.net == "conv" and not args.no_aux:

@@ -173,6 +173,8 @@ const char* az_last_error(const az_engine* e);
  *                           autograd), 0: every GEMM on v_mfma_f32_16x16x4_f32 (1e-6).  Two numerics classes: the trained
  *                           weights differ, as they do between two f32 summation orders (parity of NNet::train is unpinned by
  *                           the reference, whose training script cannot run; tests/test_train_gpu.py bounds the drift),
+ *            "train_fork" 0 (default) / 1: with "train_gemm" 1, a step's weight split and wgrad chains run on a second stream
+ *                           branch beside the BatchNorm-backward / dgrad chain (bit-identical; measured no faster, so off),
  *            "train_fwd_dma" 1 (default): the forward GEMMs' tiles go global -> LDS by LDS-DMA (k_gemm_f32_dma), 0: register-staged
  * libaz_engine_diag.so (the same sources built with -DAZ_DIAG; alphazero-rs_amd/build.py) additionally takes the keys of the
  * SUPERSEDED kernel generations and the TIMING ABLATIONS WITH WRONG RESULTS -- "gemm_variant", "fc_ring", "ring_tile", "conv3_ring",

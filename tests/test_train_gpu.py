@@ -218,6 +218,13 @@ def test_az_net_train_is_the_documented_sequence_of_steps(tengine):
         tengine.train(8, 10, boards, pis, vs)
         assert np.array_equal(got, tengine.net_get_params(10))
         tengine.set_option("train_graph", 1)
+        for graph in (1, 0):                                      # the wgrad chains on a second stream branch: the same kernels, the same bits
+            tengine.set_option("train_fork", 1)
+            tengine.set_option("train_graph", graph)
+            tengine.train(8, 10, boards, pis, vs)
+            assert np.array_equal(got, tengine.net_get_params(10)), graph
+        tengine.set_option("train_fork", 0)
+        tengine.set_option("train_graph", 1)
 
         def draw(t, j):
             r = int(mix64(np.uint64(seed)))
@@ -239,6 +246,7 @@ def test_az_net_train_is_the_documented_sequence_of_steps(tengine):
             assert np.allclose(hist[ep], m, rtol=1e-6), (hist[ep], m)
     finally:
         tengine.set_option("train_graph", 1)
+        tengine.set_option("train_fork", 0)
         for key, val in (("train_epochs", 10), ("train_batch", 64), ("train_seed", 0)):
             tengine.set_option(key, val)
 

@@ -20,6 +20,10 @@ if os.environ.get("TRAIN_GRAPH"):
     e.set_option("train_graph", int(os.environ["TRAIN_GRAPH"]))
 if os.environ.get("TRAIN_FWD_DMA"):
     e.set_option("train_fwd_dma", int(os.environ["TRAIN_FWD_DMA"]))
+if os.environ.get("TRAIN_FORK"):
+    e.set_option("train_fork", int(os.environ["TRAIN_FORK"]))
+if os.environ.get("TRAIN_G3RING"):
+    e.set_option("train_gemm3_ring", int(os.environ["TRAIN_G3RING"]))
 if os.environ.get("TRAIN_GEMM"):
     e.set_option("train_gemm", int(os.environ["TRAIN_GEMM"]))
 e.train(0, 1, boards[: 4 * batch], pis[: 4 * batch], vs[: 4 * batch])     # warm-up (allocations, code load)
@@ -27,4 +31,6 @@ t0 = time.time()
 hist = e.train(0, 1, boards, pis, vs)
 dt = time.time() - t0
 flop = 3 * 2 * 164_493_312 * (C / 512) ** 2 * batch    # ~3x the forward MACs (forward + dgrad + wgrad), C^2 scaling approx.
+import hashlib
+print("params sha", hashlib.sha256(e.net_get_params(1).tobytes()).hexdigest()[:16])
 print(f"C={C} batch={batch} steps={steps}: {dt / steps * 1e3:.3f} ms/step, {n / dt:.0f} samples/s, ~{flop / (dt / steps) / 1e12:.1f} TFLOP/s f32, loss {hist}")
