@@ -305,6 +305,24 @@ AZ_D void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
     hi = bf16_rne(x);
     lo = bf16_rne(x - bf16_f32(hi));
 }
+// the same split in IEEE half precision (11-bit significands: hi + lo carries 22 bits).  For operands that stay inside half's range -- the
+// forward pass's activations and its weights times 256 -- three products are f32-grade (2^-22), where bf16 x 3 is 2^-17.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+AZ_D void split_f16(float x, uint16_t& hi, uint16_t& lo) {
+    const _Float16 h = (_Float16)x;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (_Float16)(x - (float)h));
+}
+template <bool F16>
+AZ_D void split_any(float x, uint16_t& hi, uint16_t& lo) {
+    if constexpr (F16) split_f16(x, hi, lo);
+    else split_bf16(x, hi, lo);
+}
+template <bool F16>
+AZ_D f32x4 mfma3(const uint4 w, const uint4 a, const f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, a), c, 0, 0, 0);
+}
 AZ_D void split4(const float4 v, uint2& hi, uint2& lo) {
     uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
     split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
@@ -327,6 +345,7 @@ struct Gemm3 {
     int steps_per_split;            // 32-deep K-steps (of Kc / 32) per blockIdx.y
     int splits;
     int xcd_rows;                   // workgroup id -> tile mapping (k_gemm3)
+    float out_scale;                // the accumulators times this (a power of two: the f16 forward's weights are stored times 256), then + bias
 };
 
 // One stage = the four operand tiles of one 32-deep K-step -- A_hi, A_lo, W_hi, W_lo, 128 rows x 64 B each = 32 KiB -- shared by the step's
@@ -336,6 +355,7 @@ struct Gemm3 {
 // (k_gemm_f32_dma's A tile has the same geometry).
 constexpr int G3_BM = 128, G3_TILE = 128 * 64, G3_STAGE = 4 * G3_TILE;
 
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G3_STAGE];
     constexpr int MT = G3_BM / 32;
@@ -403,27 +423,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
         const unsigned char* sAl = sAh + G3_TILE;
         const unsigned char* sWh = sAh + 2 * G3_TILE;
         const unsigned char* sWl = sAh + 3 * G3_TILE;
-        bf16x8_t ah[MT], al[MT], wh[4], wl[4];
+        uint4 ah[MT], al[MT], wh[4], wl[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const bf16x8_t*)(sAh + a_row + mt * 1024);
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const uint4*)(sAh + a_row + mt * 1024);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wh[nt] = *(const bf16x8_t*)(sWh + b_row + nt * 1024);
+        for (int nt = 0; nt < 4; ++nt) wh[nt] = *(const uint4*)(sWh + b_row + nt * 1024);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wl[nt] = *(const bf16x8_t*)(sWl + b_row + nt * 1024);
+        for (int nt = 0; nt < 4; ++nt) wl[nt] = *(const uint4*)(sWl + b_row + nt * 1024);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const bf16x8_t*)(sAl + a_row + mt * 1024);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const uint4*)(sAl + a_row + mt * 1024);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<F16>(wh[nt], ah[mt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<F16>(wl[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<F16>(wh[nt], al[mt], acc[mt][nt]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef AZ_G3DMA
@@ -440,7 +460,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
             const int m = m0 + wr * (G3_BM / 2) + mt * 16 + frow;
             if (m >= g.M) continue;
             *(float4*)(obase + (size_t)m * ldo + n) =
-                make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+                make_float4(acc[mt][nt][0] * g.out_scale + bv.x, acc[mt][nt][1] * g.out_scale + bv.y, acc[mt][nt][2] * g.out_scale + bv.z,
+                            acc[mt][nt][3] * g.out_scale + bv.w);
         }
     }
 }
@@ -453,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const Gemm3 g) {
 // bits.  DMA pieces of 16 rows (1 KiB): wave w loads pieces w and w + 8 of A hi and of A lo, piece w of W hi and of W lo (6 per stage).
 constexpr int G3R_BM = 256, G3R_A = 256 * 64, G3R_W = 128 * 64, G3R_STAGE = 2 * G3R_A + 2 * G3R_W, G3R_NS = 3;
 
+template <bool F16>
 __global__ __launch_bounds__(512, 1) void k_gemm3_ring(const Gemm3 g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_r[G3R_NS * G3R_STAGE];
     constexpr int MT = 4;
@@ -521,27 +543,27 @@ __global__ __launch_bounds__(512, 1) void k_gemm3_ring(const Gemm3 g) {
         const unsigned char* sAl = sAh + G3R_A;
         const unsigned char* sWh = sAh + 2 * G3R_A;
         const unsigned char* sWl = sWh + G3R_W;
-        bf16x8_t ah[MT], al[MT], wh[4], wl[4];
+        uint4 ah[MT], al[MT], wh[4], wl[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const bf16x8_t*)(sAh + a_row + mt * 1024);
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const uint4*)(sAh + a_row + mt * 1024);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wh[nt] = *(const bf16x8_t*)(sWh + b_row + nt * 1024);
+        for (int nt = 0; nt < 4; ++nt) wh[nt] = *(const uint4*)(sWh + b_row + nt * 1024);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wl[nt] = *(const bf16x8_t*)(sWl + b_row + nt * 1024);
+        for (int nt = 0; nt < 4; ++nt) wl[nt] = *(const uint4*)(sWl + b_row + nt * 1024);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const bf16x8_t*)(sAl + a_row + mt * 1024);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const uint4*)(sAl + a_row + mt * 1024);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<F16>(wh[nt], ah[mt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<F16>(wl[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<F16>(wh[nt], al[mt], acc[mt][nt]);
         __builtin_amdgcn_sched_barrier(0);
         buf = buf == 2 ? 0 : buf + 1;
     }
@@ -558,7 +580,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm3_ring(const Gemm3 g) {
             const int m = m0 + wr * 64 + mt * 16 + frow;
             if (m >= g.M) continue;
             *(float4*)(obase + (size_t)m * ldo + n) =
-                make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+                make_float4(acc[mt][nt][0] * g.out_scale + bv.x, acc[mt][nt][1] * g.out_scale + bv.y, acc[mt][nt][2] * g.out_scale + bv.z,
+                            acc[mt][nt][3] * g.out_scale + bv.w);
         }
     }
 }
@@ -588,16 +611,17 @@ struct TransposeJob {
     int C, tiles_c;
     int64_t ld;
 };
-__global__ __launch_bounds__(256) void k_transpose_split(const TransposeJob j0, const TransposeJob j1, int R, int Rp) {
+template <bool F16>
+__global__ __launch_bounds__(256) void k_transpose_split(const TransposeJob j0, const TransposeJob j1, const TransposeJob j2, int R, int Rp, float scale) {
     __shared__ float tile[64][65];
-    const bool second = (int)blockIdx.x >= j0.tiles_c;
-    const TransposeJob& j = second ? j1 : j0;
-    const int r0 = blockIdx.y * 64, c0 = ((int)blockIdx.x - (second ? j0.tiles_c : 0)) * 64;
+    const int which = (int)blockIdx.x >= j0.tiles_c + j1.tiles_c ? 2 : ((int)blockIdx.x >= j0.tiles_c ? 1 : 0);
+    const TransposeJob& j = which == 2 ? j2 : (which == 1 ? j1 : j0);
+    const int r0 = blockIdx.y * 64, c0 = ((int)blockIdx.x - (which == 2 ? j0.tiles_c + j1.tiles_c : (which == 1 ? j0.tiles_c : 0))) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = ty + 4 * i;
-        tile[r][tx] = (r0 + r < R && c0 + tx < j.C) ? j.in[(size_t)(r0 + r) * j.ld + c0 + tx] : 0.0f;
+        tile[r][tx] = (r0 + r < R && c0 + tx < j.C) ? j.in[(size_t)(r0 + r) * j.ld + c0 + tx] * scale : 0.0f;
     }
     __syncthreads();
 #pragma unroll
@@ -605,7 +629,7 @@ __global__ __launch_bounds__(256) void k_transpose_split(const TransposeJob j0, 
         const int c = ty + 4 * i;
         if (c0 + c < j.C && r0 + tx < Rp) {
             uint16_t hi, lo;
-            split_bf16(tile[tx][c], hi, lo);
+            split_any<F16>(tile[tx][c], hi, lo);
             j.out_hi[(size_t)(c0 + c) * Rp + r0 + tx] = hi;
             j.out_lo[(size_t)(c0 + c) * Rp + r0 + tx] = lo;
         }
@@ -655,7 +679,9 @@ __global__ void k_boards_col1(const float* __restrict__ boards, float* __restric
 }
 
 // in [b][H][W][C] -> col [b*Ho*Wo][9*C], k = (ky*3+kx)*C + c; pad = 1 ('same') or 0 ('valid')
-__global__ void k_im2col(const float* __restrict__ in, float* __restrict__ col, int b, int H, int W, int C, int pad) {
+// col_hi / col_lo (may be null): 64 x the same matrix split into two halves (split_f16), the forward GEMM's operand when it runs as f16 x 3
+__global__ void k_im2col(const float* __restrict__ in, float* __restrict__ col, int b, int H, int W, int C, int pad,
+                         uint16_t* __restrict__ col_hi = nullptr, uint16_t* __restrict__ col_lo = nullptr) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2, c4n = C / 4;
     const int64_t total = (int64_t)b * Ho * Wo * 9 * c4n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -666,7 +692,15 @@ __global__ void k_im2col(const float* __restrict__ in, float* __restrict__ col, 
         const int iy = y + tap / 3 - pad, ix = x + tap % 3 - pad;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const float4*)(in + (((size_t)s * H + iy) * W + ix) * C + c4 * 4);
-        *(float4*)(col + (size_t)row * 9 * C + (size_t)tap * C + c4 * 4) = v;
+        const size_t o = (size_t)row * 9 * C + (size_t)tap * C + c4 * 4;
+        *(float4*)(col + o) = v;
+        if (col_hi) {
+            uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+            // times 64: a half below 2^-14 is subnormal, and the low halves of activations under 1/8 would be; scaled, that is under 1/512
+            split_f16(v.x * 64.0f, h0, l0); split_f16(v.y * 64.0f, h1, l1); split_f16(v.z * 64.0f, h2, l2); split_f16(v.w * 64.0f, h3, l3);
+            *(uint2*)(col_hi + o) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+            *(uint2*)(col_lo + o) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+        }
     }
 }
 
@@ -1119,6 +1153,9 @@ struct Trainer {
     // second branch of a step (gemm_mode 1): the weight split and every layer's wgrad chain (transposes, k_gemm3, split-K reduce) run on
     // `side`, forked from / joined to the caller's stream by events, with their own split-K workspace; the caller's stream keeps the
     // chain the next layer waits for (BatchNorm backward, dgrad, col2im).  Same kernels on the same data: bit-identical to fork = false.
+    // forward conv2..conv4 as f16 x 3 (fwd_x3): the im2col matrices and the transposed weights (times 256) as half-precision hi / lo pairs
+    bool fwd_x3 = true;
+    uint16_t *col_hi[4] = {nullptr}, *col_lo[4] = {nullptr}, *wt_hi[4] = {nullptr}, *wt_lo[4] = {nullptr};
     bool gemm3_ring = true;            // dgrad / wgrad with >= 192 rows on k_gemm3_ring (256 x 128 tiles, 3-stage ring) instead of k_gemm3
     bool fork = false;                 // measured: no gain as direct launches, 7 % slower inside a hipGraph (profiles/README.md)
     hipStream_t side = nullptr;
@@ -1180,6 +1217,10 @@ Trainer* trainer_create(int channels, const char** err) {
         for (uint16_t** q : {&t->dz_hi, &t->dz_lo}) ok &= (*q = t->dalloc<uint16_t>(B * 42 * NM)) != nullptr;
         for (uint16_t** q : {&t->dzt_hi, &t->dzt_lo}) ok &= (*q = t->dalloc<uint16_t>(NM * Mp)) != nullptr;
         for (uint16_t** q : {&t->at_hi, &t->at_lo}) ok &= (*q = t->dalloc<uint16_t>(9 * C * Mp)) != nullptr;
+        for (int l = 1; l < 4; ++l) {
+            for (uint16_t** q : {&t->col_hi[l], &t->col_lo[l]}) ok &= (*q = t->dalloc<uint16_t>(rows[l] * kin[l])) != nullptr;
+            for (uint16_t** q : {&t->wt_hi[l], &t->wt_lo[l]}) ok &= (*q = t->dalloc<uint16_t>(kin[l] * C)) != nullptr;
+        }
     }
     t->splitk_floats = (size_t)96 << 20;      // 384 MiB (a conv2-sized dgrad at the largest batch has 49.5 M outputs; it is never split)
     ok &= (t->splitk = t->dalloc<float>(t->splitk_floats)) != nullptr;
@@ -1306,7 +1347,8 @@ int red_parts(int M) { return std::max(1, std::min(RED_PARTS, (M + 63) / 64)); }
 // out[M][N] (row stride ldo) = A W^T (+ bias) as bf16 x 3: A hi / lo [M][lda], W hi / lo [N][ldw], both contiguous along the contraction
 // Kc.  Split-K so that about two workgroups per CU exist (a workgroup walks at least 8 K-steps); the slices are summed in slice order.
 void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* out, int ldo,
-                  const float* bias, int M, int N, int Kc, float* ws, size_t ws_floats, hipStream_t s, bool ring = false) {
+                  const float* bias, int M, int N, int Kc, float* ws, size_t ws_floats, hipStream_t s, bool ring = false, bool f16 = false,
+                  float out_scale = 1.0f) {
     const int steps = Kc / 32;
     const int mt_r = (M + G3R_BM - 1) / G3R_BM;
     // at most a tenth of the row tiles' rows beyond M, and a contraction long enough to fill and drain the ring (conv4's wgrad has 12
@@ -1319,8 +1361,9 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
         while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
         const int sps = (steps + splits - 1) / splits;
         splits = (steps + sps - 1) / sps;
-        Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, 0};
-        hipLaunchKernelGGL(k_gemm3_ring, dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
+        Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, 0, out_scale};
+        if (f16) hipLaunchKernelGGL((k_gemm3_ring<true>), dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm3_ring<false>), dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
         if (splits > 1)
             hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
         return;
@@ -1331,13 +1374,16 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
     const int sps = (steps + splits - 1) / splits;
     splits = (steps + sps - 1) / sps;
     const int xcd_rows = mt >= 8 ? 1 : 0;
-    Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, xcd_rows};
-    hipLaunchKernelGGL(k_gemm3, dim3((unsigned)((xcd_rows ? (mt + 7) / 8 * 8 : mt) * NT), (unsigned)splits), dim3(256), 0, s, g);
+    Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, xcd_rows, out_scale};
+    const dim3 grid((unsigned)((xcd_rows ? (mt + 7) / 8 * 8 : mt) * NT), (unsigned)splits);
+    if (f16) hipLaunchKernelGGL((k_gemm3<true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm3<false>), grid, dim3(256), 0, s, g);
     if (splits > 1)
         hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
 }
 void launch_transpose_split2(const TransposeJob& j0, const TransposeJob& j1, int R, int Rp, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_split, dim3((unsigned)(j0.tiles_c + j1.tiles_c), (unsigned)(Rp / 64)), dim3(256), 0, s, j0, j1, R, Rp);
+    hipLaunchKernelGGL((k_transpose_split<false>), dim3((unsigned)(j0.tiles_c + j1.tiles_c), (unsigned)(Rp / 64)), dim3(256), 0, s, j0, j1,
+                       TransposeJob{}, R, Rp, 1.0f);
 }
 
 }  // namespace
@@ -1396,9 +1442,20 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         (void)hipEventRecord(t->ev_sw, s2);
     }
     if (!col1_done) hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
+    const bool fx3 = t->fwd_x3 && C % 128 == 0;
+    if (fx3) {          // W [9C][C] of conv2..conv4 -> (256 W)^T as half hi / lo [C][9C], one launch
+        TransposeJob j[3];
+        for (int l = 1; l <= 3; ++l) j[l - 1] = TransposeJob{P + ld[l].w, t->wt_hi[l], t->wt_lo[l], C, C / 64, C};
+        hipLaunchKernelGGL((k_transpose_split<true>), dim3((unsigned)(3 * (C / 64)), (unsigned)(9 * C / 64)), dim3(256), 0, s, j[0], j[1], j[2], 9 * C,
+                           9 * C, 256.0f);
+    }
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
-        gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s, t->fwd_dma);
+        if (fx3 && l >= 1 && l <= 3)
+            launch_gemm3(t->col_hi[l], t->col_lo[l], 9 * C, t->wt_hi[l], t->wt_lo[l], 9 * C, t->z[l], d.N, P + d.bias, d.M, d.N, d.K, t->splitk,
+                         t->splitk_floats, s, t->gemm3_ring, true, 1.0f / (256.0f * 64.0f));
+        else
+            gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s, t->fwd_dma);
         BnLayer bn = bn_desc(l, t->a[l], nullptr);
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
         if (d.M <= BN_SMALL_ROWS) {
@@ -1408,9 +1465,11 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             hipLaunchKernelGGL(k_bn_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
                                APPLY_ROWS, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
         }
-        if (l == 0) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 42 * 9 * C / 4), dim3(256), 0, s, t->a[0], t->col[1], b, 6, 7, C, 1);
-        if (l == 1) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 20 * 9 * C / 4), dim3(256), 0, s, t->a[1], t->col[2], b, 6, 7, C, 0);
-        if (l == 2) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 6 * 9 * C / 4), dim3(256), 0, s, t->a[2], t->col[3], b, 4, 5, C, 0);
+        uint16_t* const ch = fx3 && l <= 2 ? t->col_hi[l + 1] : nullptr;
+        uint16_t* const cl = fx3 && l <= 2 ? t->col_lo[l + 1] : nullptr;
+        if (l == 0) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 42 * 9 * C / 4), dim3(256), 0, s, t->a[0], t->col[1], b, 6, 7, C, 1, ch, cl);
+        if (l == 1) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 20 * 9 * C / 4), dim3(256), 0, s, t->a[1], t->col[2], b, 6, 7, C, 0, ch, cl);
+        if (l == 2) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 6 * 9 * C / 4), dim3(256), 0, s, t->a[2], t->col[3], b, 4, 5, C, 0, ch, cl);
     }
     hipLaunchKernelGGL(k_heads_loss, dim3(b), dim3(64), 0, s, t->a[5], P + L.pi_w, P + L.pi_b, P + L.v_w, P + L.v_b, d_pis, d_vs, b,
                        t->dhead, t->sample_loss, t->logits);
@@ -1521,6 +1580,7 @@ bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards,
 void trainer_set_graph(Trainer* t, bool on) { if (t) t->use_graph = on; }
 void trainer_set_gemm(Trainer* t, int mode) { if (t) t->gemm_mode = mode; }
 void trainer_set_fork(Trainer* t, bool on) { if (t) t->fork = on; }
+void trainer_set_fwd_x3(Trainer* t, bool on) { if (t) t->fwd_x3 = on; }
 void trainer_set_gemm3_ring(Trainer* t, bool on) { if (t) t->gemm3_ring = on; }
 void trainer_set_fwd_dma(Trainer* t, bool on) { if (t) t->fwd_dma = on; }
 

@@ -535,8 +535,9 @@ def main():
                 line["nnet_train"] = {"ms_per_step": step_s * 1e3, "samples_per_sec": bs / step_s, "batch": bs,
                                       "steps": [n_short, n_long], "call_ms": [t_short * 1e3, t_long * 1e3], "fixed_ms_per_call": fixed_s * 1e3,
                                       "ms_per_step_of_the_200_step_call": t_short / n_short * 1e3,
-                                      "dtype": "f32 (forward GEMMs on v_mfma_f32_16x16x4_f32; dgrad / wgrad as bf16 x 3 on the bf16 matrix cores, f32 accumulate: "
-                                               "gradients within 1e-5 of float64 autograd)",
+                                      "dtype": "f32 parameters / activations / gradients; conv2..conv4 forward as f16 x 3 on the f16 matrix cores, dgrad / wgrad as "
+                                               "bf16 x 3 on the bf16 matrix cores, f32 accumulate (gradients within 1e-5 of float64 autograd); "
+                                               "conv1 / fc forward on v_mfma_f32_16x16x4_f32",
                                       "tflops": 3 * FLOP_PER_LEAF * bs / step_s / 1e12,
                                       "note": "two az_net_train calls (200 and 800 steps of one epoch): ms_per_step is the slope, i.e. one optimisation step; "
                                               "fixed_ms_per_call is what a call costs besides its steps (sample upload, graph capture, the stored model's "

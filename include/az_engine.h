@@ -173,6 +173,10 @@ const char* az_last_error(const az_engine* e);
  *                           autograd), 0: every GEMM on v_mfma_f32_16x16x4_f32 (1e-6).  Two numerics classes: the trained
  *                           weights differ, as they do between two f32 summation orders (parity of NNet::train is unpinned by
  *                           the reference, whose training script cannot run; tests/test_train_gpu.py bounds the drift),
+ *            "train_fwd_x3" 1 (default): the forward GEMMs of conv2..conv4 as f16 x 3 on the f16 matrix cores (activations x 64 and
+ *                           weights x 256 split into half-precision hi / lo pairs, three products, f32 accumulate: 2^-22, the grade of
+ *                           the f32 kernel's own accumulation -- gradients stay within 1e-5 of float64 autograd), 0: on
+ *                           v_mfma_f32_16x16x4_f32; "train_gemm3_ring" 1 (default) / 0: the big x 3 GEMMs on the 256 x 128 ring kernel,
  *            "train_fork" 0 (default) / 1: with "train_gemm" 1, a step's weight split and wgrad chains run on a second stream
  *                           branch beside the BatchNorm-backward / dgrad chain (bit-identical; measured no faster, so off),
  *            "train_fwd_dma" 1 (default): the forward GEMMs' tiles go global -> LDS by LDS-DMA (k_gemm_f32_dma), 0: register-staged

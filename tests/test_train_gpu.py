@@ -50,14 +50,16 @@ def perturbed_params(engine, model_id, seed):
     return p
 
 
-@pytest.fixture(scope="module", params=[(1, 1), (0, 1), (0, 0)], ids=["bf16x3_backward", "f32_gemms", "f32_register_staged"])
+@pytest.fixture(scope="module", params=[(1, 1, 1), (1, 1, 0), (0, 1, 0), (0, 0, 0)],
+                ids=["default_f16x3_forward_bf16x3_backward", "f32_forward_bf16x3_backward", "f32_gemms", "f32_register_staged"])
 def tengine(engine_mod, request):
-    """The GEMM sets of the trainer: the default (backward GEMMs as bf16 x 3 on the bf16 matrix cores, forward on
-    v_mfma_f32_16x16x4_f32 fed by LDS-DMA), every GEMM on the f32 matrix cores ("train_gemm" = 0), and that with round 2's
-    register-staged forward kernel ("train_fwd_dma" = 0).  Same bars for all."""
+    """The GEMM sets of the trainer: the default (conv2..conv4 forward as f16 x 3 on the f16 matrix cores, backward GEMMs as bf16 x 3 on the
+    bf16 matrix cores), the forward on v_mfma_f32_16x16x4_f32 fed by LDS-DMA instead ("train_fwd_x3" = 0), every GEMM on the f32
+    matrix cores ("train_gemm" = 0), and that with round 2's register-staged forward kernel ("train_fwd_dma" = 0).  Same bars for all."""
     e = engine_mod.Engine(device=0, max_batch=1024, net_channels=C)
     e.set_option("train_gemm", request.param[0])
     e.set_option("train_fwd_dma", request.param[1])
+    e.set_option("train_fwd_x3", request.param[2])
     yield e
     e.close()
 
@@ -107,6 +109,27 @@ def test_gradients_match_autograd(tengine, b):
             assert np.abs(p2[o + 3 * c:o + 4 * c] - rstats[k][1]).max() <= 1e-5, k
         else:
             assert np.array_equal(p2[o:o + n], p[o:o + n]), k
+
+
+def test_gradients_match_autograd_at_the_bench_width(engine_mod):
+    """The same check for the default GEMM set at C = 512, batch 64 -- the shapes bench.py's nnet_train probe and the example's
+    Coach run, where the big GEMMs take the 256 x 128 ring kernels (at C = 128 most of them fall back to the 128 x 128 ones)
+    and a forward GEMM sums 4608 products: typical error 1e-5 per tensor (tools/train_check.py), bar 1e-3."""
+    global C
+    saved, C = C, 512
+    e = engine_mod.Engine(device=0, max_batch=1024, net_channels=512)
+    try:
+        e.set_option("train_dropout_e6", 0)
+        p = perturbed_params(e, 1, seed=64)
+        boards, pis, vs = make_batch(64, seed=164)
+        e.train_begin(1)
+        (lp, lv), g = e.train_step(boards, pis, vs, apply=False, want_grads=True)
+        rlp, rlv, rg, _ = step_reference(p, 512, boards, pis, vs)
+        assert abs(lp - rlp) <= 1e-5 * max(1, abs(rlp)) and abs(lv - rlv) <= 1e-5 * max(1, abs(rlv)), (lp, rlp, lv, rlv)
+        compare_grads(g, rg, 1e-3, "C=512 b=64")
+    finally:
+        C = saved
+        e.close()
 
 
 def test_dropout_masks_match_the_counter_rng(tengine):
@@ -293,13 +316,13 @@ def test_train_argument_checks(tengine, engine_mod):
 
 
 def test_trained_weights_of_the_gemm_sets_drift_alike(engine_mod):
-    """The three GEMM sets of NNet::train are three numerics classes: per-step gradients agree with float64 autograd to 1e-5
-    / 1e-6 (test_gradients_match_autograd), the TRAINED weights are not bit-identical between any two of them, and nothing in
-    the reference pins them (its TF1 script cannot run, SURVEY.md B11: parity unpinned).  The recipe itself is chaotic (Adam's
-    first steps are sign-like, dropout + training-mode BatchNorm): two f32 kernels that differ only in SUMMATION ORDER
+    """The GEMM sets of NNet::train are numerics classes: per-step gradients agree with float64 autograd to 1e-5 / 1e-6
+    (test_gradients_match_autograd), the TRAINED weights are not bit-identical between any two of them, and nothing in the
+    reference pins them (its TF1 script cannot run, SURVEY.md B11: parity unpinned).  The recipe itself is chaotic (Adam's
+    first steps are sign-like, dropout + training-mode BatchNorm): two all-f32 sets that differ only in SUMMATION ORDER
     ("train_fwd_dma" 0 / 1) end 32 steps 0.28 of the update's own norm apart (measured).  What this test pins is that the
-    bf16 x 3 backward ("train_gemm" 1) is not a worse class than that: its drift from the f32 set is within 3 x the
-    f32-vs-f32 drift, every set's epoch losses fall, and the sets' losses stay within 20 % of each other."""
+    default set (f16 x 3 forward, bf16 x 3 backward) is not a worse class than that: its drift from the f32 set is within
+    3 x the f32-vs-f32 drift, every set's epoch losses fall, and the sets' losses stay within 20 % of each other."""
     n = 512
     boards, pis, vs = make_batch(n, seed=41)
     got = {}
@@ -309,18 +332,19 @@ def test_trained_weights_of_the_gemm_sets_drift_alike(engine_mod):
         start = e.net_get_params(1).astype(np.float64)
         for key, val in (("train_epochs", 4), ("train_batch", 64), ("train_seed", 3)):
             e.set_option(key, val)
-        for i, (g, d) in enumerate(((0, 1), (1, 1), (0, 0))):
+        for i, (name, g, d, x3) in enumerate((("f32", 0, 1, 0), ("default", 1, 1, 1), ("f32_other_order", 0, 0, 0))):
             e.set_option("train_gemm", g)
             e.set_option("train_fwd_dma", d)
+            e.set_option("train_fwd_x3", x3)
             hist = e.train(1, 2 + i, boards, pis, vs)
-            got[(g, d)] = (np.array(hist, np.float64), e.net_get_params(2 + i).astype(np.float64))
+            got[name] = (np.array(hist, np.float64), e.net_get_params(2 + i).astype(np.float64))
     finally:
         e.close()
-    h_ref, p_ref = got[(0, 1)]
+    h_ref, p_ref = got["f32"]
     moved = np.linalg.norm(p_ref - start)
     drift = {k: np.linalg.norm(p - p_ref) / moved for k, (_, p) in got.items()}
     print("drift from the f32 LDS-DMA set, in units of its update norm:", drift)
-    assert 0 < drift[(0, 0)] and 0 < drift[(1, 1)] <= 3 * drift[(0, 0)], drift
+    assert 0 < drift["f32_other_order"] and 0 < drift["default"] <= 3 * drift["f32_other_order"], drift
     for k, (h, _) in got.items():
         assert h[-1, 0] < h[0, 0] and h[-1, 1] < h[0, 1], (k, h)
         assert np.allclose(h, h_ref, rtol=0.2), (k, h, h_ref)

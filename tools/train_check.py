@@ -13,6 +13,8 @@ b = int(sys.argv[2]) if len(sys.argv) > 2 else 37
 T.C = C
 e = E.Engine(device=0, max_batch=1024, net_channels=C)
 e.set_option("train_dropout_e6", 0)
+if os.environ.get("TRAIN_FWD_X3"):
+    e.set_option("train_fwd_x3", int(os.environ["TRAIN_FWD_X3"]))
 if os.environ.get("TRAIN_GEMM"):
     e.set_option("train_gemm", int(os.environ["TRAIN_GEMM"]))
 p = T.perturbed_params(e, 1, seed=b)
@@ -27,7 +29,9 @@ for k, (o, shp) in layout(C)[0].items():
     print(f"{k:10s} |ref| {np.linalg.norm(r):.3e} rel err {np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-30):.3e} max abs {np.abs(a - r).max():.3e}")
 # step timing
 e.train_begin(1)
-t0 = time.time()
-for i in range(20):
+ts = []
+for i in range(30):
+    t0 = time.time()
     e.train_step(boards, pis, vs, apply=True)
-print("ms/step (incl. host copies + sync)", (time.time() - t0) / 20 * 1e3)
+    ts.append((time.time() - t0) * 1e3)
+print("ms per az_net_train_step call (incl. host copies + sync):", " ".join(f"{x:.2f}" for x in ts))
