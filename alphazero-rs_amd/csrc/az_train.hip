@@ -586,6 +586,150 @@ __global__ __launch_bounds__(512, 1) void k_gemm3_ring(const Gemm3 g) {
     }
 }
 
+// wgrad without the transposes: dW [Kin][N] = A^T dz with A [M][Kin] and dz [M][N] AS STORED (the contraction index m is the row, the
+// operand's own index is contiguous).  The MFMA operand of lane (i = lane & 15, g = lane >> 4) is 8 contraction values of index i, which
+// gfx950 reads straight out of such an image: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block,
+// two of them per fragment (rows 8g .. 8g+3, 8g+4 .. 8g+7).  k_transpose_split's pass over the layer's im2col matrix (32 us of a conv2-sized
+// step, 76 us per step in all) is gone; the matrices come as bf16 hi / lo from k_im2col and k_bn_bwd_apply.
+// Same tile and ring as k_gemm3_ring: 256 (Kin) x 128 (N), 8 waves as 4 x 2, a K-step = 32 rows of A (512-byte rows) and of dz (256-byte
+// rows), hi and lo, 48 KiB; three stages.  The DMA is lane-linear, so the bank spread is made on the source side: the 32-byte unit u of
+// row r sits at u ^ h(r), h(r) = (r & 3) | ((r >> 3) & 1) << 2 -- the eight rows a 32-lane half reads at once (4 per group, the groups 8
+// rows apart) land on eight different units of the 256-byte bank period.
+// Requires M % 32 == 0 (rows past M would have to read as zero), Kin % 256 == 0, N % 128 == 0.
+struct Wgrad3 {
+    const uint16_t *a_hi, *a_lo;    // [M][lda] bf16
+    const uint16_t *z_hi, *z_lo;    // [M][ldz] bf16
+    float* out;                     // splits == 1: dW [Kin][N]; else partial sums [splits][Kin][N]
+    int Kin, N, M, lda, ldz;
+    int steps_per_split, splits;    // 32-row K-steps per slice
+};
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+AZ_D uint2 lds_tr16(const unsigned char* p) {
+    typedef __attribute__((address_space(3))) v4s_t* lp;
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p));
+}
+
+__global__ __launch_bounds__(512, 1) void k_wgrad3_tr(const Wgrad3 g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_t[G3R_NS * G3R_STAGE];
+    constexpr int MT = 4;
+    const int NT = g.N / 128, tiles = (g.Kin / 256) * NT, total = tiles * g.splits;
+    const int nper = (total + 7) >> 3;
+    const int t = ((int)blockIdx.x & 7) * nper + ((int)blockIdx.x >> 3);      // XCD x takes the x-th eighth of (slice, row tile, column tile)
+    if (t >= total) return;
+    const int split = t / tiles, rem = t - split * tiles;
+    const int k0 = (rem / NT) * 256, n0 = (rem % NT) * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // DMA maps (a piece = 1 KiB of LDS = 64 lanes x 16 B): A piece p = rows 2p, 2p+1 (32 chunks each), dz piece p = rows 4p .. 4p+3 (16 chunks)
+    uint32_t a_ob[2], z_ob;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 2 * (wave + 8 * i) + (lane >> 5);
+        const int h = (r & 3) | (((r >> 3) & 1) << 2);
+        a_ob[i] = (uint32_t)(r * g.lda + k0) * 2u + (uint32_t)(((lane & 31) ^ (h << 1)) << 4);
+    }
+    {
+        const int r = 4 * wave + (lane >> 4);
+        const int h = (r & 3) | (((r >> 3) & 1) << 2);
+        z_ob = (uint32_t)(r * g.ldz + n0) * 2u + (uint32_t)(((lane & 15) ^ (h << 1)) << 4);
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)(smem_t + wave * 1024);
+    const int t0 = split * g.steps_per_split;
+    const int nk = min(g.M / 32, t0 + g.steps_per_split) - t0;
+    int kin = t0;
+#define AZ_WTDMA(buf_)                                                                                  \
+    {                                                                                                   \
+        const char* ah = (const char*)(g.a_hi + (size_t)kin * 32 * g.lda);                              \
+        const char* al = (const char*)(g.a_lo + (size_t)kin * 32 * g.lda);                              \
+        const char* zh = (const char*)(g.z_hi + (size_t)kin * 32 * g.ldz);                              \
+        const char* zl = (const char*)(g.z_lo + (size_t)kin * 32 * g.ldz);                              \
+        const uint32_t la = lds0 + (buf_) * G3R_STAGE;                                                  \
+        train_dma16(ah, a_ob[0], la);                                                                   \
+        train_dma16(ah, a_ob[1], la + 8192);                                                            \
+        train_dma16(zh, z_ob, la + 2 * G3R_A);                                                          \
+        train_dma16(zl, z_ob, la + 2 * G3R_A + G3R_W);                                                  \
+        train_dma16(al, a_ob[0], la + G3R_A);                                                           \
+        train_dma16(al, a_ob[1], la + G3R_A + 8192);                                                    \
+        ++kin;                                                                                          \
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposed-read addresses: lane 4q + p of group gq supplies row 8 gq + q (+ 4 for the second read), columns 4p .. 4p+3 of the block
+    const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int hh = q | ((gq & 1) << 2);
+    int a_off[MT], z_off[4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_off[mt] = (8 * gq + q) * 512 + (((wr * 4 + mt) ^ hh) << 5) + 8 * pp;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) z_off[nt] = (8 * gq + q) * 256 + (((wc * 4 + nt) ^ hh) << 5) + 8 * pp;
+    if (nk > 0) AZ_WTDMA(0);
+    if (nk > 1) AZ_WTDMA(1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) { const int nb = buf == 0 ? 2 : buf - 1; AZ_WTDMA(nb); }
+        const unsigned char* sAh = smem_t + buf * G3R_STAGE;
+        const unsigned char* sAl = sAh + G3R_A;
+        const unsigned char* sZh = sAh + 2 * G3R_A;
+        const unsigned char* sZl = sZh + G3R_W;
+        uint4 ah[MT], al[MT], zh[4], zl[4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint2 x = lds_tr16(sAh + a_off[mt]), y = lds_tr16(sAh + a_off[mt] + 4 * 512);
+            ah[mt] = make_uint4(x.x, x.y, y.x, y.y);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const uint2 x = lds_tr16(sZh + z_off[nt]), y = lds_tr16(sZh + z_off[nt] + 4 * 256);
+            zh[nt] = make_uint4(x.x, x.y, y.x, y.y);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const uint2 x = lds_tr16(sZl + z_off[nt]), y = lds_tr16(sZl + z_off[nt] + 4 * 256);
+            zl[nt] = make_uint4(x.x, x.y, y.x, y.y);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint2 x = lds_tr16(sAl + a_off[mt]), y = lds_tr16(sAl + a_off[mt] + 4 * 512);
+            al[mt] = make_uint4(x.x, x.y, y.x, y.y);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<false>(zh[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<false>(zl[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma3<false>(zh[nt], al[mt], acc[mt][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+#undef AZ_WTDMA
+    float* obase = g.splits > 1 ? g.out + (size_t)split * g.Kin * g.N : g.out;
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int k = k0 + wr * 64 + mt * 16 + frow;
+            *(float4*)(obase + (size_t)k * g.N + n) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+        }
+    }
+}
+
 // every weight matrix W [K][N] f32 -> hi / lo bf16 as stored (the dgrad operand), at the matrix's own offset of flat buffers the size of
 // the parameter vector.  blockIdx.y = matrix.
 struct SplitWeights {
@@ -679,9 +823,13 @@ __global__ void k_boards_col1(const float* __restrict__ boards, float* __restric
 }
 
 // in [b][H][W][C] -> col [b*Ho*Wo][9*C], k = (ky*3+kx)*C + c; pad = 1 ('same') or 0 ('valid')
-// col_hi / col_lo (may be null): 64 x the same matrix split into two halves (split_f16), the forward GEMM's operand when it runs as f16 x 3
-__global__ void k_im2col(const float* __restrict__ in, float* __restrict__ col, int b, int H, int W, int C, int pad,
-                         uint16_t* __restrict__ col_hi = nullptr, uint16_t* __restrict__ col_lo = nullptr) {
+// Every output is optional: col (f32: the f32 forward GEMM's and k_transpose_split's operand), col_hi / col_lo (64 x the matrix split into
+// two halves, split_f16: the forward GEMM's operand when it runs as f16 x 3), col_bhi / col_blo (the matrix as bf16 hi / lo: k_wgrad3_tr's).
+struct Im2colOut {
+    float* col;
+    uint16_t *col_hi, *col_lo, *col_bhi, *col_blo;
+};
+__global__ void k_im2col(const float* __restrict__ in, const Im2colOut out, int b, int H, int W, int C, int pad) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2, c4n = C / 4;
     const int64_t total = (int64_t)b * Ho * Wo * 9 * c4n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -693,13 +841,19 @@ __global__ void k_im2col(const float* __restrict__ in, float* __restrict__ col, 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const float4*)(in + (((size_t)s * H + iy) * W + ix) * C + c4 * 4);
         const size_t o = (size_t)row * 9 * C + (size_t)tap * C + c4 * 4;
-        *(float4*)(col + o) = v;
-        if (col_hi) {
+        if (out.col) *(float4*)(out.col + o) = v;
+        if (out.col_hi) {
             uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
             // times 64: a half below 2^-14 is subnormal, and the low halves of activations under 1/8 would be; scaled, that is under 1/512
             split_f16(v.x * 64.0f, h0, l0); split_f16(v.y * 64.0f, h1, l1); split_f16(v.z * 64.0f, h2, l2); split_f16(v.w * 64.0f, h3, l3);
-            *(uint2*)(col_hi + o) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
-            *(uint2*)(col_lo + o) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+            *(uint2*)(out.col_hi + o) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+            *(uint2*)(out.col_lo + o) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+        }
+        if (out.col_bhi) {
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            *(uint2*)(out.col_bhi + o) = hi;
+            *(uint2*)(out.col_blo + o) = lo;
         }
     }
 }
@@ -1156,6 +1310,9 @@ struct Trainer {
     // forward conv2..conv4 as f16 x 3 (fwd_x3): the im2col matrices and the transposed weights (times 256) as half-precision hi / lo pairs
     bool fwd_x3 = true;
     uint16_t *col_hi[4] = {nullptr}, *col_lo[4] = {nullptr}, *wt_hi[4] = {nullptr}, *wt_lo[4] = {nullptr};
+    // wgrad of conv2..conv4 on k_wgrad3_tr (transposed LDS reads, no k_transpose_split): the im2col matrices as bf16 hi / lo
+    bool wgrad_tr = true;
+    uint16_t *col_bhi[4] = {nullptr}, *col_blo[4] = {nullptr};
     bool gemm3_ring = true;            // dgrad / wgrad with >= 192 rows on k_gemm3_ring (256 x 128 tiles, 3-stage ring) instead of k_gemm3
     bool fork = false;                 // measured: no gain as direct launches, 7 % slower inside a hipGraph (profiles/README.md)
     hipStream_t side = nullptr;
@@ -1218,7 +1375,7 @@ Trainer* trainer_create(int channels, const char** err) {
         for (uint16_t** q : {&t->dzt_hi, &t->dzt_lo}) ok &= (*q = t->dalloc<uint16_t>(NM * Mp)) != nullptr;
         for (uint16_t** q : {&t->at_hi, &t->at_lo}) ok &= (*q = t->dalloc<uint16_t>(9 * C * Mp)) != nullptr;
         for (int l = 1; l < 4; ++l) {
-            for (uint16_t** q : {&t->col_hi[l], &t->col_lo[l]}) ok &= (*q = t->dalloc<uint16_t>(rows[l] * kin[l])) != nullptr;
+            for (uint16_t** q : {&t->col_hi[l], &t->col_lo[l], &t->col_bhi[l], &t->col_blo[l]}) ok &= (*q = t->dalloc<uint16_t>(rows[l] * kin[l])) != nullptr;
             for (uint16_t** q : {&t->wt_hi[l], &t->wt_lo[l]}) ok &= (*q = t->dalloc<uint16_t>(kin[l] * C)) != nullptr;
         }
     }
@@ -1381,6 +1538,18 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
     if (splits > 1)
         hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
 }
+// dW [Kin][N] = A^T dz on k_wgrad3_tr; split-K over the 32-row steps so that at most 256 workgroups exist, slices summed in slice order
+void launch_wgrad3_tr(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* z_hi, const uint16_t* z_lo, int ldz, float* out, int M,
+                      int Kin, int N, float* ws, size_t ws_floats, hipStream_t s) {
+    const int tiles = (Kin / 256) * (N / 128), steps = M / 32;
+    int splits = std::max(1, std::min(256 / tiles, steps / 6));
+    while (splits > 1 && (size_t)splits * Kin * N > ws_floats) --splits;
+    const int sps = (steps + splits - 1) / splits;
+    splits = (steps + sps - 1) / sps;
+    Wgrad3 g{a_hi, a_lo, z_hi, z_lo, splits > 1 ? ws : out, Kin, N, M, lda, ldz, sps, splits};
+    hipLaunchKernelGGL(k_wgrad3_tr, dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
+    if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)Kin * N), dim3(256), 0, s, ws, splits, Kin, N, out, (int64_t)N, nullptr);
+}
 void launch_transpose_split2(const TransposeJob& j0, const TransposeJob& j1, int R, int Rp, hipStream_t s) {
     hipLaunchKernelGGL((k_transpose_split<false>), dim3((unsigned)(j0.tiles_c + j1.tiles_c), (unsigned)(Rp / 64)), dim3(256), 0, s, j0, j1,
                        TransposeJob{}, R, Rp, 1.0f);
@@ -1442,7 +1611,9 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         (void)hipEventRecord(t->ev_sw, s2);
     }
     if (!col1_done) hipLaunchKernelGGL(k_boards_col1, grid1((int64_t)b * 42 * 20, 256, 1 << 20), dim3(256), 0, s, d_boards, t->col[0], b);
-    const bool fx3 = t->fwd_x3 && C % 128 == 0;
+    const bool fx3 = x3 && t->fwd_x3;           // "train_gemm" 0 keeps every GEMM on the f32 matrix cores
+    // k_wgrad3_tr's shape constraints (a batch of 64 meets them at every width that is a multiple of 256 / 9 ... i.e. 9 C % 256 == 0)
+    auto tr_ok = [&](int l) { return x3 && t->wgrad_tr && l >= 1 && l <= 3 && ld[l].M % 32 == 0 && ld[l].K % 256 == 0 && ld[l].N % 128 == 0; };
     if (fx3) {          // W [9C][C] of conv2..conv4 -> (256 W)^T as half hi / lo [C][9C], one launch
         TransposeJob j[3];
         for (int l = 1; l <= 3; ++l) j[l - 1] = TransposeJob{P + ld[l].w, t->wt_hi[l], t->wt_lo[l], C, C / 64, C};
@@ -1465,11 +1636,15 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             hipLaunchKernelGGL(k_bn_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
                                APPLY_ROWS, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
         }
-        uint16_t* const ch = fx3 && l <= 2 ? t->col_hi[l + 1] : nullptr;
-        uint16_t* const cl = fx3 && l <= 2 ? t->col_lo[l + 1] : nullptr;
-        if (l == 0) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 42 * 9 * C / 4), dim3(256), 0, s, t->a[0], t->col[1], b, 6, 7, C, 1, ch, cl);
-        if (l == 1) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 20 * 9 * C / 4), dim3(256), 0, s, t->a[1], t->col[2], b, 6, 7, C, 0, ch, cl);
-        if (l == 2) hipLaunchKernelGGL(k_im2col, grid1((int64_t)b * 6 * 9 * C / 4), dim3(256), 0, s, t->a[2], t->col[3], b, 4, 5, C, 0, ch, cl);
+        if (l <= 2) {
+            const int ln = l + 1;                // the layer this matrix feeds
+            Im2colOut io{};
+            if (fx3) { io.col_hi = t->col_hi[ln]; io.col_lo = t->col_lo[ln]; }
+            if (tr_ok(ln)) { io.col_bhi = t->col_bhi[ln]; io.col_blo = t->col_blo[ln]; }
+            if (!fx3 || !tr_ok(ln)) io.col = t->col[ln];
+            const int H = l == 2 ? 4 : 6, W = l == 2 ? 5 : 7, pad = l == 0 ? 1 : 0;
+            hipLaunchKernelGGL(k_im2col, grid1((int64_t)ld[ln].M * 9 * C / 4), dim3(256), 0, s, t->a[l], io, b, H, W, C, pad);
+        }
     }
     hipLaunchKernelGGL(k_heads_loss, dim3(b), dim3(64), 0, s, t->a[5], P + L.pi_w, P + L.pi_b, P + L.v_w, P + L.v_b, d_pis, d_vs, b,
                        t->dhead, t->sample_loss, t->logits);
@@ -1499,12 +1674,18 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         if (g3) {
             // wgrad: dW [K][N] = A^T dz, both operands transposed so that the contraction (the rows) is contiguous
             const int Mp = (d.M + 63) / 64 * 64;
-            const TransposeJob jz{t->dz, t->dzt_hi, t->dzt_lo, d.N, (d.N + 63) / 64, d.N}, ja{d.A, t->at_hi, t->at_lo, d.K, (d.K + 63) / 64, d.lda};
             hand(t->ev_dz[l], s, s2);
-            launch_transpose_split2(ja, jz, d.M, Mp, s2);         // the big one first
-            if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
-            launch_gemm3(t->at_hi, t->at_lo, Mp, t->dzt_hi, t->dzt_lo, Mp, G + d.w, d.N, nullptr, d.K, d.N, Mp, fork ? t->splitk2 : t->splitk,
-                         fork ? t->splitk2_floats : t->splitk_floats, s2, t->gemm3_ring);
+            if (tr_ok(l)) {       // A and dz as stored: no transposes
+                launch_wgrad3_tr(t->col_bhi[l], t->col_blo[l], (int)d.lda, t->dz_hi, t->dz_lo, d.N, G + d.w, d.M, d.K, d.N, fork ? t->splitk2 : t->splitk,
+                                 fork ? t->splitk2_floats : t->splitk_floats, s2);
+                if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
+            } else {
+                const TransposeJob jz{t->dz, t->dzt_hi, t->dzt_lo, d.N, (d.N + 63) / 64, d.N}, ja{d.A, t->at_hi, t->at_lo, d.K, (d.K + 63) / 64, d.lda};
+                launch_transpose_split2(ja, jz, d.M, Mp, s2);         // the big one first
+                if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
+                launch_gemm3(t->at_hi, t->at_lo, Mp, t->dzt_hi, t->dzt_lo, Mp, G + d.w, d.N, nullptr, d.K, d.N, Mp, fork ? t->splitk2 : t->splitk,
+                             fork ? t->splitk2_floats : t->splitk_floats, s2, t->gemm3_ring);
+            }
             // dgrad: d input [M][K] = dz W^T, W [K][N] as stored
             float* din = l >= 4 ? t->dact : t->dcol;
             launch_gemm3(t->dz_hi, t->dz_lo, d.N, t->w_hi + d.w, t->w_lo + d.w, d.N, din, d.K, nullptr, d.M, d.K, d.N, t->splitk, t->splitk_floats, s,
@@ -1581,6 +1762,7 @@ void trainer_set_graph(Trainer* t, bool on) { if (t) t->use_graph = on; }
 void trainer_set_gemm(Trainer* t, int mode) { if (t) t->gemm_mode = mode; }
 void trainer_set_fork(Trainer* t, bool on) { if (t) t->fork = on; }
 void trainer_set_fwd_x3(Trainer* t, bool on) { if (t) t->fwd_x3 = on; }
+void trainer_set_wgrad_tr(Trainer* t, bool on) { if (t) t->wgrad_tr = on; }
 void trainer_set_gemm3_ring(Trainer* t, bool on) { if (t) t->gemm3_ring = on; }
 void trainer_set_fwd_dma(Trainer* t, bool on) { if (t) t->fwd_dma = on; }
 

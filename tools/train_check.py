@@ -15,6 +15,8 @@ e = E.Engine(device=0, max_batch=1024, net_channels=C)
 e.set_option("train_dropout_e6", 0)
 if os.environ.get("TRAIN_FWD_X3"):
     e.set_option("train_fwd_x3", int(os.environ["TRAIN_FWD_X3"]))
+if os.environ.get("TRAIN_WGRAD_TR"):
+    e.set_option("train_wgrad_tr", int(os.environ["TRAIN_WGRAD_TR"]))
 if os.environ.get("TRAIN_GEMM"):
     e.set_option("train_gemm", int(os.environ["TRAIN_GEMM"]))
 p = T.perturbed_params(e, 1, seed=b)
