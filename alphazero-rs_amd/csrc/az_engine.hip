@@ -283,6 +283,7 @@ struct az_engine {
     int train_gemm3_ring = 1;       // "train_gemm3_ring"
     int train_fwd_x3 = 1;           // "train_fwd_x3"
     int train_wgrad_tr = 1;         // "train_wgrad_tr"
+    int train_implicit = 1;         // "train_implicit"
     int train_fork = 0;             // "train_fork": the wgrad chains of a step on a second stream branch (csrc/az_train.hip)
     int train_fwd_dma = 1;
     std::vector<float> train_history;              // (loss_pi, loss_v) mean per epoch of the last az_net_train
@@ -799,6 +800,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("train_gemm3_ring") && (value == 0 || value == 1)) { e->train_gemm3_ring = (int)value; if (e->trainer) trainer_set_gemm3_ring(e->trainer, value != 0); return AZ_OK; }
     if (is("train_fwd_x3") && (value == 0 || value == 1)) { e->train_fwd_x3 = (int)value; if (e->trainer) trainer_set_fwd_x3(e->trainer, value != 0); return AZ_OK; }
     if (is("train_wgrad_tr") && (value == 0 || value == 1)) { e->train_wgrad_tr = (int)value; if (e->trainer) trainer_set_wgrad_tr(e->trainer, value != 0); return AZ_OK; }
+    if (is("train_implicit") && (value == 0 || value == 1)) { e->train_implicit = (int)value; if (e->trainer) trainer_set_implicit(e->trainer, value != 0); return AZ_OK; }
     if (is("train_fork") && (value == 0 || value == 1)) { e->train_fork = (int)value; if (e->trainer) trainer_set_fork(e->trainer, value != 0); return AZ_OK; }
     if (is("train_gemm") && (value == 0 || value == 1)) { e->train_gemm = (int)value; if (e->trainer) trainer_set_gemm(e->trainer, (int)value); return AZ_OK; }
     if (is("train_fwd_dma") && (value == 0 || value == 1)) { e->train_fwd_dma = (int)value; if (e->trainer) trainer_set_fwd_dma(e->trainer, value != 0); return AZ_OK; }
@@ -1113,6 +1115,7 @@ az_status az_net_train_begin(az_engine* e, int32_t previous_model_id) {
             trainer_set_graph(e->trainer, e->train_graph != 0);
             trainer_set_gemm(e->trainer, e->train_gemm);
             trainer_set_fork(e->trainer, e->train_fork != 0);
+            trainer_set_implicit(e->trainer, e->train_implicit != 0);
             trainer_set_wgrad_tr(e->trainer, e->train_wgrad_tr != 0);
             trainer_set_fwd_x3(e->trainer, e->train_fwd_x3 != 0);
             trainer_set_gemm3_ring(e->trainer, e->train_gemm3_ring != 0);

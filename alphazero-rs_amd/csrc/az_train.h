@@ -53,6 +53,7 @@ void trainer_set_fork(Trainer* t, bool on);       // true: a step's wgrad chains
 void trainer_set_gemm3_ring(Trainer* t, bool on); // true (default): the big bf16 x 3 GEMMs on k_gemm3_ring (one 8-wave workgroup per CU, 3-stage ring)
 void trainer_set_fwd_x3(Trainer* t, bool on);     // true (default): conv2..conv4 forward as f16 x 3 on the f16 matrix cores; false: v_mfma_f32_16x16x4_f32
 void trainer_set_wgrad_tr(Trainer* t, bool on);   // true (default): conv wgrad on k_wgrad3_tr (transposed LDS reads; no transpose kernels)
+void trainer_set_implicit(Trainer* t, bool on);   // true (default): conv2..conv4's GEMMs gather their rows from the activations (no im2col / col2im)
 void trainer_set_gemm(Trainer* t, int mode);      // 1 (default): the GEMMs as bf16 x 3 on the bf16 matrix cores; 0: v_mfma_f32_16x16x4_f32
 
 }  // namespace az

@@ -335,6 +335,19 @@ AZ_D void train_dma16(const void* sbase /*uniform*/, uint32_t voff, uint32_t lds
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
+// A rows gathered from an activation tensor instead of read from an im2col matrix (k_gemm3_ring, k_wgrad3_tr): row m of the matrix is
+// the position (s, y, x) of an Ht x Wt map, its K index is (tap, channel), and element (m, tap, c) is channel c of the source tensor
+// [s][Hs][Ws][Cs] at (y + sgn * dy + off, x + sgn * dx + off), tap = 3 dy + dx -- or of the all-zero row at byte offset zero_off when that
+// position is outside the source map.  Forward and wgrad: rows = output positions, source = the layer's input, sgn = +1, off = -pad;
+// dgrad: rows = input positions, source = dz over the output positions, sgn = -1, off = +pad (the transposed convolution).  A 32-deep K-step
+// never straddles a tap (Cs % 32 == 0).  The im2col matrix (9 x the tensor) is never written, and the tensor's rows come from L2.
+struct ImplicitA {
+    int on;
+    int Ht, Wt, Hs, Ws, Cs;
+    int sgn, off;
+    uint32_t zero_off;
+};
+
 struct Gemm3 {
     const uint16_t *a_hi, *a_lo;    // [M][lda] bf16, contiguous along the contraction
     const uint16_t *w_hi, *w_lo;    // [N][ldw] bf16, contiguous along the contraction
@@ -346,6 +359,7 @@ struct Gemm3 {
     int splits;
     int xcd_rows;                   // workgroup id -> tile mapping (k_gemm3)
     float out_scale;                // the accumulators times this (a power of two: the f16 forward's weights are stored times 256), then + bias
+    ImplicitA ia;                   // k_gemm3_ring only
 };
 
 // One stage = the four operand tiles of one 32-deep K-step -- A_hi, A_lo, W_hi, W_lo, 128 rows x 64 B each = 32 KiB -- shared by the step's
@@ -494,11 +508,17 @@ __global__ __launch_bounds__(512, 1) void k_gemm3_ring(const Gemm3 g) {
     const uint32_t fD = (0x78u >> ((((uint32_t)lane >> 4) & 3u) * 2u)) & 3u;
     const uint32_t chunk = ((uint32_t)lane & 3u) ^ fD;
     uint32_t a_ob[2], b_ob;
+    int rs[2], ry[2], rx[2];          // implicit A: this lane's two rows as (sample, y, x)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int m = m0 + (wave + 8 * i) * 16 + (lane >> 2);
         m = m < g.M ? m : g.M - 1;
         a_ob[i] = (uint32_t)(m * g.lda + (int)chunk * 8) * 2u;
+        rs[i] = ry[i] = rx[i] = 0;
+        if (g.ia.on) {
+            const int hw = g.ia.Ht * g.ia.Wt, p = m % hw;
+            rs[i] = m / hw; ry[i] = p / g.ia.Wt; rx[i] = p - ry[i] * g.ia.Wt;
+        }
     }
     b_ob = (uint32_t)((n0 + wave * 16 + (lane >> 2)) * g.ldw + (int)chunk * 8) * 2u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -506,19 +526,38 @@ __global__ __launch_bounds__(512, 1) void k_gemm3_ring(const Gemm3 g) {
     const int t0 = split * g.steps_per_split;
     const int nk = min(g.Kc / 32, t0 + g.steps_per_split) - t0;
     int kin = t0;
+    int tap = 0, tc = 0;              // implicit A: the tap and first channel of K-step kin
+    if (g.ia.on) { tap = (t0 * 32) / g.ia.Cs; tc = t0 * 32 - tap * g.ia.Cs; }
 #define AZ_G3RDMA(buf_)                                                                                 \
     {                                                                                                   \
         const char* ah = (const char*)(g.a_hi + kin * 32);                                              \
         const char* al = (const char*)(g.a_lo + kin * 32);                                              \
         const char* wh = (const char*)(g.w_hi + kin * 32);                                              \
         const char* wl = (const char*)(g.w_lo + kin * 32);                                              \
+        uint32_t ao0 = a_ob[0], ao1 = a_ob[1];                                                          \
+        if (g.ia.on) {                                                                                  \
+            const int dy_ = tap / 3, dx_ = tap - 3 * dy_;                                               \
+            const int sy0 = ry[0] + g.ia.sgn * dy_ + g.ia.off, sx0 = rx[0] + g.ia.sgn * dx_ + g.ia.off; \
+            const int sy1 = ry[1] + g.ia.sgn * dy_ + g.ia.off, sx1 = rx[1] + g.ia.sgn * dx_ + g.ia.off; \
+            const uint32_t cb = (uint32_t)(tc + (int)chunk * 8) * 2u;                                   \
+            ao0 = ((unsigned)sy0 < (unsigned)g.ia.Hs && (unsigned)sx0 < (unsigned)g.ia.Ws)              \
+                      ? (uint32_t)(((rs[0] * g.ia.Hs + sy0) * g.ia.Ws + sx0) * g.ia.Cs) * 2u + cb       \
+                      : g.ia.zero_off + chunk * 16u;                                                    \
+            ao1 = ((unsigned)sy1 < (unsigned)g.ia.Hs && (unsigned)sx1 < (unsigned)g.ia.Ws)              \
+                      ? (uint32_t)(((rs[1] * g.ia.Hs + sy1) * g.ia.Ws + sx1) * g.ia.Cs) * 2u + cb       \
+                      : g.ia.zero_off + chunk * 16u;                                                    \
+            ah = (const char*)g.a_hi;                                                                   \
+            al = (const char*)g.a_lo;                                                                   \
+            tc += 32;                                                                                   \
+            if (tc == g.ia.Cs) { tc = 0; ++tap; }                                                       \
+        }                                                                                               \
         const uint32_t la = lds0 + (buf_) * G3R_STAGE;                                                  \
-        train_dma16(ah, a_ob[0], la);                                                                   \
-        train_dma16(ah, a_ob[1], la + 8192);                                                            \
+        train_dma16(ah, ao0, la);                                                                       \
+        train_dma16(ah, ao1, la + 8192);                                                                \
         train_dma16(wh, b_ob, la + 2 * G3R_A);                                                          \
         train_dma16(wl, b_ob, la + 2 * G3R_A + G3R_W);                                                  \
-        train_dma16(al, a_ob[0], la + G3R_A);                                                           \
-        train_dma16(al, a_ob[1], la + G3R_A + 8192);                                                    \
+        train_dma16(al, ao0, la + G3R_A);                                                               \
+        train_dma16(al, ao1, la + G3R_A + 8192);                                                        \
         ++kin;                                                                                          \
     }
     f32x4 acc[MT][4];
@@ -602,6 +641,8 @@ struct Wgrad3 {
     float* out;                     // splits == 1: dW [Kin][N]; else partial sums [splits][Kin][N]
     int Kin, N, M, lda, ldz;
     int steps_per_split, splits;    // 32-row K-steps per slice
+    ImplicitA ia;                   // on: A is the im2col matrix of a_hi / a_lo = the layer's input tensor [s][Hs][Ws][Cs], Kin = 9 Cs, Cs % 256 == 0
+    int inv_hw, inv_w;              // ceil(65536 / (Ht Wt)), ceil(65536 / Wt): the row walk's divisions as multiply-shifts
 };
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 AZ_D uint2 lds_tr16(const unsigned char* p) {
@@ -639,19 +680,49 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3_tr(const Wgrad3 g) {
     const int t0 = split * g.steps_per_split;
     const int nk = min(g.M / 32, t0 + g.steps_per_split) - t0;
     int kin = t0;
+    // implicit A: the tile's 256 columns lie inside one tap (Cs % 256 == 0); this lane's two rows of K-step kin as (sample, position)
+    int ws_[2] = {0, 0}, wp_[2] = {0, 0};
+    uint32_t icb[2] = {0u, 0u};
+    int idy = 0, idx = 0;
+    if (g.ia.on) {
+        const int tap = k0 / g.ia.Cs, c0 = k0 - tap * g.ia.Cs, hw = g.ia.Ht * g.ia.Wt;
+        idy = tap / 3; idx = tap - 3 * idy;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 2 * (wave + 8 * i) + (lane >> 5), m = t0 * 32 + r;
+            const int h = (r & 3) | (((r >> 3) & 1) << 2);
+            ws_[i] = m / hw; wp_[i] = m - ws_[i] * hw;
+            icb[i] = (uint32_t)c0 * 2u + (uint32_t)(((lane & 31) ^ (h << 1)) << 4);
+        }
+    }
 #define AZ_WTDMA(buf_)                                                                                  \
     {                                                                                                   \
         const char* ah = (const char*)(g.a_hi + (size_t)kin * 32 * g.lda);                              \
         const char* al = (const char*)(g.a_lo + (size_t)kin * 32 * g.lda);                              \
         const char* zh = (const char*)(g.z_hi + (size_t)kin * 32 * g.ldz);                              \
         const char* zl = (const char*)(g.z_lo + (size_t)kin * 32 * g.ldz);                              \
+        uint32_t ao_[2] = {a_ob[0], a_ob[1]};                                                          \
+        if (g.ia.on) {                                                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
+                const int y_ = (wp_[i_] * g.inv_w) >> 16, x_ = wp_[i_] - y_ * g.ia.Wt;                  \
+                const int sy_ = y_ + idy + g.ia.off, sx_ = x_ + idx + g.ia.off;                         \
+                ao_[i_] = ((unsigned)sy_ < (unsigned)g.ia.Hs && (unsigned)sx_ < (unsigned)g.ia.Ws)      \
+                              ? (uint32_t)(((ws_[i_] * g.ia.Hs + sy_) * g.ia.Ws + sx_) * g.ia.Cs) * 2u + icb[i_] \
+                              : g.ia.zero_off + (icb[i_] & 0x1F0u);                                     \
+                const int p_ = wp_[i_] + 32, q_ = (p_ * g.inv_hw) >> 16;      /* the next K-step's rows are 32 further */ \
+                ws_[i_] += q_;                                                                          \
+                wp_[i_] = p_ - q_ * g.ia.Ht * g.ia.Wt;                                                  \
+            }                                                                                           \
+            ah = (const char*)g.a_hi;                                                                   \
+            al = (const char*)g.a_lo;                                                                   \
+        }                                                                                               \
         const uint32_t la = lds0 + (buf_) * G3R_STAGE;                                                  \
-        train_dma16(ah, a_ob[0], la);                                                                   \
-        train_dma16(ah, a_ob[1], la + 8192);                                                            \
+        train_dma16(ah, ao_[0], la);                                                                    \
+        train_dma16(ah, ao_[1], la + 8192);                                                             \
         train_dma16(zh, z_ob, la + 2 * G3R_A);                                                          \
         train_dma16(zl, z_ob, la + 2 * G3R_A + G3R_W);                                                  \
-        train_dma16(al, a_ob[0], la + G3R_A);                                                           \
-        train_dma16(al, a_ob[1], la + G3R_A + 8192);                                                    \
+        train_dma16(al, ao_[0], la + G3R_A);                                                            \
+        train_dma16(al, ao_[1], la + G3R_A + 8192);                                                     \
         ++kin;                                                                                          \
     }
     f32x4 acc[MT][4];
@@ -734,16 +805,24 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3_tr(const Wgrad3 g) {
 // the parameter vector.  blockIdx.y = matrix.
 struct SplitWeights {
     int64_t off[5], count[5];
+    int perm_c[5], perm_n[5];     // perm_c > 0: row (tap, c) of W [9 perm_c][perm_n] goes to row c, columns tap * perm_n .. of [perm_c][9 perm_n]
 };
 __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ P, const SplitWeights sw, uint16_t* __restrict__ w_hi,
                                                        uint16_t* __restrict__ w_lo) {
     const int mi = blockIdx.y;
     const int64_t n4 = sw.count[mi] / 4, base = sw.off[mi];
+    const int pc = sw.perm_c[mi], pn = sw.perm_n[mi];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         uint2 hi, lo;
         split4(*(const float4*)(P + base + i * 4), hi, lo);
-        *(uint2*)(w_hi + base + i * 4) = hi;
-        *(uint2*)(w_lo + base + i * 4) = lo;
+        int64_t o = i * 4;
+        if (pc) {      // the dgrad of a convolution as a GEMM over (tap, n): W_d [c][tap][n] = W [tap][c][n]
+            const int64_t row = o / pn;
+            const int n = (int)(o - row * pn), tap = (int)(row / pc), c = (int)(row - (int64_t)tap * pc);
+            o = ((int64_t)c * 9 + tap) * pn + n;
+        }
+        *(uint2*)(w_hi + base + o) = hi;
+        *(uint2*)(w_lo + base + o) = lo;
     }
 }
 
@@ -918,6 +997,9 @@ struct BnLayer {
     uint32_t keep_thresh;
     float drop_scale;
     uint16_t *out_hi, *out_lo;   // k_bn_bwd_apply, not nullptr: dz also as hi / lo bf16 (the dgrad operand), same [M][N] layout
+    // k_bn_apply, not nullptr: the activations also as 64 x a in half-precision hi / lo (the next layer's f16 x 3 forward operand) and as
+    // bf16 hi / lo (its wgrad operand), same [M][N] layout -- what k_im2col writes 9 x of when the GEMMs do not gather (ImplicitA)
+    uint16_t *act_hi, *act_lo, *act_bhi, *act_blo;
 };
 
 
@@ -1034,6 +1116,16 @@ __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double*
             y.w = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 3, L.keep_thresh) ? y.w * L.drop_scale : 0.0f;
         }
         *(float4*)(L.out + i) = y;
+        if (L.act_hi) {
+            uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+            split_f16(y.x * 64.0f, h0, l0); split_f16(y.y * 64.0f, h1, l1); split_f16(y.z * 64.0f, h2, l2); split_f16(y.w * 64.0f, h3, l3);
+            *(uint2*)(L.act_hi + i) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+            *(uint2*)(L.act_lo + i) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+            uint2 bh, bl;
+            split4(y, bh, bl);
+            *(uint2*)(L.act_bhi + i) = bh;
+            *(uint2*)(L.act_blo + i) = bl;
+        }
     }
 }
 
@@ -1313,6 +1405,11 @@ struct Trainer {
     // wgrad of conv2..conv4 on k_wgrad3_tr (transposed LDS reads, no k_transpose_split): the im2col matrices as bf16 hi / lo
     bool wgrad_tr = true;
     uint16_t *col_bhi[4] = {nullptr}, *col_blo[4] = {nullptr};
+    // the three conv GEMMs of conv2..conv4 gather their A rows from the activations (ImplicitA): no im2col matrix, no col2im.  The
+    // activations a[0..2] as half / bf16 pairs, each with one all-zero row behind the largest batch's rows (act_zero_off[l] bytes in)
+    bool implicit = true;
+    uint16_t *act_hi[3] = {nullptr}, *act_lo[3] = {nullptr}, *act_bhi[3] = {nullptr}, *act_blo[3] = {nullptr};
+    uint32_t act_zero_off[3] = {0, 0, 0}, dz_zero_off = 0;
     bool gemm3_ring = true;            // dgrad / wgrad with >= 192 rows on k_gemm3_ring (256 x 128 tiles, 3-stage ring) instead of k_gemm3
     bool fork = false;                 // measured: no gain as direct launches, 7 % slower inside a hipGraph (profiles/README.md)
     hipStream_t side = nullptr;
@@ -1371,9 +1468,21 @@ Trainer* trainer_create(int channels, const char** err) {
     {
         const size_t NM = std::max<size_t>(C, 1024), Mp = (B * 42 + 63) / 64 * 64;
         for (uint16_t** q : {&t->w_hi, &t->w_lo}) ok &= (*q = t->dalloc<uint16_t>(T)) != nullptr;
-        for (uint16_t** q : {&t->dz_hi, &t->dz_lo}) ok &= (*q = t->dalloc<uint16_t>(B * 42 * NM)) != nullptr;
+        for (uint16_t** q : {&t->dz_hi, &t->dz_lo}) {      // + one all-zero row (the gathered dgrad's out-of-map positions)
+            ok &= (*q = t->dalloc<uint16_t>((B * 42 + 1) * NM)) != nullptr;
+            if (*q) ok &= hipMemset(*q, 0, (B * 42 + 1) * NM * sizeof(uint16_t)) == hipSuccess;
+        }
+        t->dz_zero_off = (uint32_t)(B * 42 * NM * sizeof(uint16_t));
         for (uint16_t** q : {&t->dzt_hi, &t->dzt_lo}) ok &= (*q = t->dalloc<uint16_t>(NM * Mp)) != nullptr;
         for (uint16_t** q : {&t->at_hi, &t->at_lo}) ok &= (*q = t->dalloc<uint16_t>(9 * C * Mp)) != nullptr;
+        for (int l = 0; l < 3; ++l) {
+            const size_t n = (rows[l] + 1) * C;
+            for (uint16_t** q : {&t->act_hi[l], &t->act_lo[l], &t->act_bhi[l], &t->act_blo[l]}) {
+                ok &= (*q = t->dalloc<uint16_t>(n)) != nullptr;
+                if (*q) ok &= hipMemset(*q, 0, n * sizeof(uint16_t)) == hipSuccess;
+            }
+            t->act_zero_off[l] = (uint32_t)(rows[l] * C * sizeof(uint16_t));
+        }
         for (int l = 1; l < 4; ++l) {
             for (uint16_t** q : {&t->col_hi[l], &t->col_lo[l], &t->col_bhi[l], &t->col_blo[l]}) ok &= (*q = t->dalloc<uint16_t>(rows[l] * kin[l])) != nullptr;
             for (uint16_t** q : {&t->wt_hi[l], &t->wt_lo[l]}) ok &= (*q = t->dalloc<uint16_t>(kin[l] * C)) != nullptr;
@@ -1505,12 +1614,12 @@ int red_parts(int M) { return std::max(1, std::min(RED_PARTS, (M + 63) / 64)); }
 // Kc.  Split-K so that about two workgroups per CU exist (a workgroup walks at least 8 K-steps); the slices are summed in slice order.
 void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* out, int ldo,
                   const float* bias, int M, int N, int Kc, float* ws, size_t ws_floats, hipStream_t s, bool ring = false, bool f16 = false,
-                  float out_scale = 1.0f) {
+                  float out_scale = 1.0f, const ImplicitA* ia = nullptr) {
     const int steps = Kc / 32;
     const int mt_r = (M + G3R_BM - 1) / G3R_BM;
     // at most a tenth of the row tiles' rows beyond M, and a contraction long enough to fill and drain the ring (conv4's wgrad has 12
     // K-steps: 14.9 us on k_gemm3, 15.8 on the ring)
-    if (ring && steps >= 16 && (mt_r * G3R_BM - M) * 10 <= mt_r * G3R_BM) {
+    if (ia || (ring && steps >= 16 && (mt_r * G3R_BM - M) * 10 <= mt_r * G3R_BM)) {      // a gathered A exists on the ring kernel only
         // k_gemm3_ring: 256 x 128 tiles, ONE workgroup per CU: never more than 256 of them while the tiles fit (a second round of a few
         // workgroups costs a whole round), at least 6 K-steps per slice (the ring is 3 deep)
         const int mt = mt_r, NT = N / 128, tiles = mt * NT;
@@ -1518,7 +1627,7 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
         while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
         const int sps = (steps + splits - 1) / splits;
         splits = (steps + sps - 1) / sps;
-        Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, 0, out_scale};
+        Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, 0, out_scale, ia ? *ia : ImplicitA{}};
         if (f16) hipLaunchKernelGGL((k_gemm3_ring<true>), dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
         else hipLaunchKernelGGL((k_gemm3_ring<false>), dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
         if (splits > 1)
@@ -1531,7 +1640,7 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
     const int sps = (steps + splits - 1) / splits;
     splits = (steps + sps - 1) / sps;
     const int xcd_rows = mt >= 8 ? 1 : 0;
-    Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, xcd_rows, out_scale};
+    Gemm3 g{a_hi, a_lo, w_hi, w_lo, splits > 1 ? ws : out, bias, M, N, Kc, lda, ldw, ldo, sps, splits, xcd_rows, out_scale, ImplicitA{}};
     const dim3 grid((unsigned)((xcd_rows ? (mt + 7) / 8 * 8 : mt) * NT), (unsigned)splits);
     if (f16) hipLaunchKernelGGL((k_gemm3<true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm3<false>), grid, dim3(256), 0, s, g);
@@ -1540,13 +1649,14 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
 }
 // dW [Kin][N] = A^T dz on k_wgrad3_tr; split-K over the 32-row steps so that at most 256 workgroups exist, slices summed in slice order
 void launch_wgrad3_tr(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* z_hi, const uint16_t* z_lo, int ldz, float* out, int M,
-                      int Kin, int N, float* ws, size_t ws_floats, hipStream_t s) {
+                      int Kin, int N, float* ws, size_t ws_floats, hipStream_t s, const ImplicitA* ia = nullptr) {
     const int tiles = (Kin / 256) * (N / 128), steps = M / 32;
     int splits = std::max(1, std::min(256 / tiles, steps / 6));
     while (splits > 1 && (size_t)splits * Kin * N > ws_floats) --splits;
     const int sps = (steps + splits - 1) / splits;
     splits = (steps + sps - 1) / sps;
-    Wgrad3 g{a_hi, a_lo, z_hi, z_lo, splits > 1 ? ws : out, Kin, N, M, lda, ldz, sps, splits};
+    Wgrad3 g{a_hi, a_lo, z_hi, z_lo, splits > 1 ? ws : out, Kin, N, M, lda, ldz, sps, splits, ia ? *ia : ImplicitA{},
+             ia ? (65536 + ia->Ht * ia->Wt - 1) / (ia->Ht * ia->Wt) : 0, ia ? (65536 + ia->Wt - 1) / ia->Wt : 0};
     hipLaunchKernelGGL(k_wgrad3_tr, dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
     if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)Kin * N), dim3(256), 0, s, ws, splits, Kin, N, out, (int64_t)N, nullptr);
 }
@@ -1595,6 +1705,17 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     // ---- forward ----
     const bool x3 = t->gemm_mode == 1;
     const bool fork = x3 && t->fork && t->side;
+    // the gathered conv GEMMs need the f16 x 3 forward, k_wgrad3_tr's shapes (42 b, 20 b, 6 b rows in 32s: b % 16 == 0; C % 256 == 0)
+    const bool impl = x3 && t->implicit && t->fwd_x3 && t->wgrad_tr && b % 16 == 0 && b * 20 > BN_SMALL_ROWS && C % 256 == 0;
+    const int geo[4][3] = {{6, 7, 1}, {6, 7, 1}, {6, 7, 0}, {4, 5, 0}};      // conv layer l: input H, W, pad
+    auto gather = [&](int l, bool dgrad) {      // ImplicitA of conv layer l (1..3): forward / wgrad rows = outputs, dgrad rows = inputs
+        const int H = geo[l][0], W = geo[l][1], pad = geo[l][2], Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+        ImplicitA ia{};
+        ia.on = 1; ia.Cs = C;
+        if (!dgrad) { ia.Ht = Ho; ia.Wt = Wo; ia.Hs = H; ia.Ws = W; ia.sgn = 1; ia.off = -pad; ia.zero_off = t->act_zero_off[l - 1]; }
+        else { ia.Ht = H; ia.Wt = W; ia.Hs = Ho; ia.Ws = Wo; ia.sgn = -1; ia.off = pad; ia.zero_off = t->dz_zero_off; }
+        return ia;
+    };
     hipStream_t s2 = fork ? t->side : s;
     auto hand = [&](hipEvent_t ev, hipStream_t from, hipStream_t to) {       // `to` continues after everything enqueued on `from` so far
         if (fork) { (void)hipEventRecord(ev, from); (void)hipStreamWaitEvent(to, ev, 0); }
@@ -1603,6 +1724,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         SplitWeights sw{};
         const int64_t offs[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
         for (int i = 0; i < 5; ++i) { sw.off[i] = offs[i]; sw.count[i] = (int64_t)ld[i + 1].K * ld[i + 1].N; }
+        if (impl) for (int i = 0; i < 3; ++i) { sw.perm_c[i] = C; sw.perm_n[i] = C; }
         hipLaunchKernelGGL(k_split_weights, dim3(256, 5), dim3(256), 0, s2, (const float*)P, sw, t->w_hi, t->w_lo);
     };
     if (fork) {                      // the weight split needs the parameters only: under the forward pass
@@ -1622,12 +1744,17 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     }
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
-        if (fx3 && l >= 1 && l <= 3)
+        if (impl && l >= 1 && l <= 3) {
+            const ImplicitA ia = gather(l, false);
+            launch_gemm3(t->act_hi[l - 1], t->act_lo[l - 1], 0, t->wt_hi[l], t->wt_lo[l], 9 * C, t->z[l], d.N, P + d.bias, d.M, d.N, d.K, t->splitk,
+                         t->splitk_floats, s, true, true, 1.0f / (256.0f * 64.0f), &ia);
+        } else if (fx3 && l >= 1 && l <= 3)
             launch_gemm3(t->col_hi[l], t->col_lo[l], 9 * C, t->wt_hi[l], t->wt_lo[l], 9 * C, t->z[l], d.N, P + d.bias, d.M, d.N, d.K, t->splitk,
                          t->splitk_floats, s, t->gemm3_ring, true, 1.0f / (256.0f * 64.0f));
         else
             gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s, t->fwd_dma);
         BnLayer bn = bn_desc(l, t->a[l], nullptr);
+        if (impl && l <= 2) { bn.act_hi = t->act_hi[l]; bn.act_lo = t->act_lo[l]; bn.act_bhi = t->act_bhi[l]; bn.act_blo = t->act_blo[l]; }
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
         if (d.M <= BN_SMALL_ROWS) {
             hipLaunchKernelGGL(k_bn_fwd_small, dim3(d.N / BN_COLS), dim3(256), 0, s, bn, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
@@ -1636,7 +1763,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             hipLaunchKernelGGL(k_bn_apply, dim3(d.N / BN_COLS, (d.M + APPLY_ROWS - 1) / APPLY_ROWS), dim3(256), 0, s, bn, t->partial, parts,
                                APPLY_ROWS, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
         }
-        if (l <= 2) {
+        if (l <= 2 && !impl) {
             const int ln = l + 1;                // the layer this matrix feeds
             Im2colOut io{};
             if (fx3) { io.col_hi = t->col_hi[ln]; io.col_lo = t->col_lo[ln]; }
@@ -1675,7 +1802,12 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             // wgrad: dW [K][N] = A^T dz, both operands transposed so that the contraction (the rows) is contiguous
             const int Mp = (d.M + 63) / 64 * 64;
             hand(t->ev_dz[l], s, s2);
-            if (tr_ok(l)) {       // A and dz as stored: no transposes
+            if (impl && l <= 3) {     // A gathered from the layer's input, dz as stored
+                const ImplicitA ia = gather(l, false);
+                launch_wgrad3_tr(t->act_bhi[l - 1], t->act_blo[l - 1], 0, t->dz_hi, t->dz_lo, d.N, G + d.w, d.M, d.K, d.N, fork ? t->splitk2 : t->splitk,
+                                 fork ? t->splitk2_floats : t->splitk_floats, s2, &ia);
+                if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
+            } else if (tr_ok(l)) {       // A and dz as stored: no transposes
                 launch_wgrad3_tr(t->col_bhi[l], t->col_blo[l], (int)d.lda, t->dz_hi, t->dz_lo, d.N, G + d.w, d.M, d.K, d.N, fork ? t->splitk2 : t->splitk,
                                  fork ? t->splitk2_floats : t->splitk_floats, s2);
                 if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
@@ -1688,6 +1820,13 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             }
             // dgrad: d input [M][K] = dz W^T, W [K][N] as stored
             float* din = l >= 4 ? t->dact : t->dcol;
+            if (impl && l <= 3) {     // d input [b Hin Win][C] = the transposed convolution as ONE GEMM over (tap, n): no dcol, no col2im
+                const ImplicitA ia = gather(l, true);
+                ImplicitA ig = ia;
+                ig.Cs = d.N;
+                launch_gemm3(t->dz_hi, t->dz_lo, 0, t->w_hi + d.w, t->w_lo + d.w, 9 * d.N, t->dact, C, nullptr, b * ia.Ht * ia.Wt, C, 9 * d.N, t->splitk,
+                             t->splitk_floats, s, true, false, 1.0f, &ig);
+            } else
             launch_gemm3(t->dz_hi, t->dz_lo, d.N, t->w_hi + d.w, t->w_lo + d.w, d.N, din, d.K, nullptr, d.M, d.K, d.N, t->splitk, t->splitk_floats, s,
                          t->gemm3_ring);
         } else {
@@ -1696,7 +1835,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             if (l >= 4) gemm_nt(t->dz, P + d.w, t->dact, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);      // FC: d a[l-1] directly
             else gemm_nt(t->dz, P + d.w, t->dcol, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
         }
-        if (l >= 1 && l <= 3) {
+        if (l >= 1 && l <= 3 && !(impl && g3)) {
             const int H = l == 3 ? 4 : 6, W = l == 3 ? 5 : 7, pad = l == 1 ? 1 : 0;
             hipLaunchKernelGGL(k_col2im, grid1((int64_t)b * H * W * C / 4), dim3(256), 0, s, t->dcol, t->dact, b, H, W, C, pad);
         }
@@ -1763,6 +1902,7 @@ void trainer_set_gemm(Trainer* t, int mode) { if (t) t->gemm_mode = mode; }
 void trainer_set_fork(Trainer* t, bool on) { if (t) t->fork = on; }
 void trainer_set_fwd_x3(Trainer* t, bool on) { if (t) t->fwd_x3 = on; }
 void trainer_set_wgrad_tr(Trainer* t, bool on) { if (t) t->wgrad_tr = on; }
+void trainer_set_implicit(Trainer* t, bool on) { if (t) t->implicit = on; }
 void trainer_set_gemm3_ring(Trainer* t, bool on) { if (t) t->gemm3_ring = on; }
 void trainer_set_fwd_dma(Trainer* t, bool on) { if (t) t->fwd_dma = on; }
 

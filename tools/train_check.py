@@ -17,6 +17,8 @@ if os.environ.get("TRAIN_FWD_X3"):
     e.set_option("train_fwd_x3", int(os.environ["TRAIN_FWD_X3"]))
 if os.environ.get("TRAIN_WGRAD_TR"):
     e.set_option("train_wgrad_tr", int(os.environ["TRAIN_WGRAD_TR"]))
+if os.environ.get("TRAIN_IMPLICIT"):
+    e.set_option("train_implicit", int(os.environ["TRAIN_IMPLICIT"]))
 if os.environ.get("TRAIN_GEMM"):
     e.set_option("train_gemm", int(os.environ["TRAIN_GEMM"]))
 p = T.perturbed_params(e, 1, seed=b)
