@@ -1724,7 +1724,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
         SplitWeights sw{};
         const int64_t offs[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
         for (int i = 0; i < 5; ++i) { sw.off[i] = offs[i]; sw.count[i] = (int64_t)ld[i + 1].K * ld[i + 1].N; }
-        if (impl) for (int i = 0; i < 3; ++i) { sw.perm_c[i] = C; sw.perm_n[i] = C; }
+        if (impl) { sw.perm_c[0] = C; sw.perm_n[0] = C; }      // conv2 only: its dgrad is the gathered GEMM
         hipLaunchKernelGGL(k_split_weights, dim3(256, 5), dim3(256), 0, s2, (const float*)P, sw, t->w_hi, t->w_lo);
     };
     if (fork) {                      // the weight split needs the parameters only: under the forward pass
@@ -1820,7 +1820,10 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             }
             // dgrad: d input [M][K] = dz W^T, W [K][N] as stored
             float* din = l >= 4 ? t->dact : t->dcol;
-            if (impl && l <= 3) {     // d input [b Hin Win][C] = the transposed convolution as ONE GEMM over (tap, n): no dcol, no col2im
+            // d input [b Hin Win][C] = the transposed convolution as ONE GEMM over (tap, n): no dcol, no col2im -- for the 'same' convolution
+            // (conv2) only: a 'valid' one has fewer output than input positions, and the gathered form multiplies every input position by
+            // all nine taps (conv3 2.1 x, conv4 3.3 x the products of dz W^T + col2im; measured 49 vs 41 and 34 vs 24 us)
+            if (impl && l == 1) {
                 const ImplicitA ia = gather(l, true);
                 ImplicitA ig = ia;
                 ig.Cs = d.N;
@@ -1835,7 +1838,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             if (l >= 4) gemm_nt(t->dz, P + d.w, t->dact, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);      // FC: d a[l-1] directly
             else gemm_nt(t->dz, P + d.w, t->dcol, d.K, d.M, d.N, d.K, t->splitk, t->splitk_floats, s);
         }
-        if (l >= 1 && l <= 3 && !(impl && g3)) {
+        if (l >= 1 && l <= 3 && !(impl && g3 && l == 1)) {
             const int H = l == 3 ? 4 : 6, W = l == 3 ? 5 : 7, pad = l == 1 ? 1 : 0;
             hipLaunchKernelGGL(k_col2im, grid1((int64_t)b * H * W * C / 4), dim3(256), 0, s, t->dcol, t->dact, b, H, W, C, pad);
         }
