@@ -807,12 +807,11 @@ struct SplitWeights {
     int64_t off[5], count[5];
     int perm_c[5], perm_n[5];     // perm_c > 0: row (tap, c) of W [9 perm_c][perm_n] goes to row c, columns tap * perm_n .. of [perm_c][9 perm_n]
 };
-__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ P, const SplitWeights sw, uint16_t* __restrict__ w_hi,
-                                                       uint16_t* __restrict__ w_lo) {
-    const int mi = blockIdx.y;
+AZ_D void split_weights_body(const float* __restrict__ P, const SplitWeights& sw, uint16_t* __restrict__ w_hi, uint16_t* __restrict__ w_lo, int bx,
+                             int mi, int gx) {
     const int64_t n4 = sw.count[mi] / 4, base = sw.off[mi];
     const int pc = sw.perm_c[mi], pn = sw.perm_n[mi];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gx * blockDim.x) {
         uint2 hi, lo;
         split4(*(const float4*)(P + base + i * 4), hi, lo);
         int64_t o = i * 4;
@@ -825,6 +824,10 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
         *(uint2*)(w_lo + base + o) = lo;
     }
 }
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ P, const SplitWeights sw, uint16_t* __restrict__ w_hi,
+                                                       uint16_t* __restrict__ w_lo) {
+    split_weights_body(P, sw, w_hi, w_lo, blockIdx.x, blockIdx.y, gridDim.x);
+}
 
 // in [R][C] f32 (row stride ld) -> out hi / lo [C][Rp] bf16, rows R .. Rp-1 of the source taken as zero; 64 x 64 tiles.  One launch
 // transposes BOTH wgrad operands of a layer (dz and the layer's input): the tiles of the second follow the first's in blockIdx.x.
@@ -835,11 +838,11 @@ struct TransposeJob {
     int64_t ld;
 };
 template <bool F16>
-__global__ __launch_bounds__(256) void k_transpose_split(const TransposeJob j0, const TransposeJob j1, const TransposeJob j2, int R, int Rp, float scale) {
-    __shared__ float tile[64][65];
-    const int which = (int)blockIdx.x >= j0.tiles_c + j1.tiles_c ? 2 : ((int)blockIdx.x >= j0.tiles_c ? 1 : 0);
+AZ_D void transpose_split_body(const TransposeJob& j0, const TransposeJob& j1, const TransposeJob& j2, int R, int Rp, float scale, int bx, int by,
+                               float (*tile)[65]) {
+    const int which = bx >= j0.tiles_c + j1.tiles_c ? 2 : (bx >= j0.tiles_c ? 1 : 0);
     const TransposeJob& j = which == 2 ? j2 : (which == 1 ? j1 : j0);
-    const int r0 = blockIdx.y * 64, c0 = ((int)blockIdx.x - (which == 2 ? j0.tiles_c + j1.tiles_c : (which == 1 ? j0.tiles_c : 0))) * 64;
+    const int r0 = by * 64, c0 = (bx - (which == 2 ? j0.tiles_c + j1.tiles_c : (which == 1 ? j0.tiles_c : 0))) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -857,6 +860,22 @@ __global__ __launch_bounds__(256) void k_transpose_split(const TransposeJob j0, 
             j.out_lo[(size_t)(c0 + c) * Rp + r0 + tx] = lo;
         }
     }
+}
+template <bool F16>
+__global__ __launch_bounds__(256) void k_transpose_split(const TransposeJob j0, const TransposeJob j1, const TransposeJob j2, int R, int Rp, float scale) {
+    __shared__ float tile[64][65];
+    transpose_split_body<F16>(j0, j1, j2, R, Rp, scale, blockIdx.x, blockIdx.y, tile);
+}
+// One launch for everything a step derives from the parameters: blocks [0, tx * ty) transpose conv2..conv4's matrices into the f16 x 3
+// forward's operand ((256 W)^T as half pairs), the rest split the five matrices for dgrad (bf16 pairs, conv2's rows permuted).
+__global__ __launch_bounds__(256) void k_weight_prep(const TransposeJob j0, const TransposeJob j1, const TransposeJob j2, int R, int Rp, float scale,
+                                                     int tgx, int tgy, const float* __restrict__ P, const SplitWeights sw, uint16_t* __restrict__ w_hi,
+                                                     uint16_t* __restrict__ w_lo, int sgx) {
+    __shared__ float tile[64][65];
+    const int id = blockIdx.x;
+    if (id < tgx * tgy) { transpose_split_body<true>(j0, j1, j2, R, Rp, scale, id % tgx, id / tgx, tile); return; }
+    const int r = id - tgx * tgy;
+    split_weights_body(P, sw, w_hi, w_lo, r % sgx, r / sgx, sgx);
 }
 
 // what changes from step to step lives in device memory, so the launch sequence of a step is the same every time
@@ -1121,6 +1140,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double*
             split_f16(y.x * 64.0f, h0, l0); split_f16(y.y * 64.0f, h1, l1); split_f16(y.z * 64.0f, h2, l2); split_f16(y.w * 64.0f, h3, l3);
             *(uint2*)(L.act_hi + i) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
             *(uint2*)(L.act_lo + i) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+        }
+        if (L.act_bhi) {
             uint2 bh, bl;
             split4(y, bh, bl);
             *(uint2*)(L.act_bhi + i) = bh;
@@ -1245,6 +1266,12 @@ __global__ __launch_bounds__(256) void k_bn_fwd_small(const BnLayer L, float eps
             y.w = dropout_keep(mask_seed, L.drop_layer, (uint64_t)i + 3, L.keep_thresh) ? y.w * L.drop_scale : 0.0f;
         }
         *(float4*)(L.out + i) = y;
+        if (L.act_bhi) {
+            uint2 bh, bl;
+            split4(y, bh, bl);
+            *(uint2*)(L.act_bhi + i) = bh;
+            *(uint2*)(L.act_blo + i) = bl;
+        }
     }
 }
 
@@ -1408,7 +1435,7 @@ struct Trainer {
     // the three conv GEMMs of conv2..conv4 gather their A rows from the activations (ImplicitA): no im2col matrix, no col2im.  The
     // activations a[0..2] as half / bf16 pairs, each with one all-zero row behind the largest batch's rows (act_zero_off[l] bytes in)
     bool implicit = true;
-    uint16_t *act_hi[3] = {nullptr}, *act_lo[3] = {nullptr}, *act_bhi[3] = {nullptr}, *act_blo[3] = {nullptr};
+    uint16_t *act_hi[3] = {nullptr}, *act_lo[3] = {nullptr}, *act_bhi[5] = {nullptr}, *act_blo[5] = {nullptr};      // [3], [4]: the FC layers' inputs (their wgrad)
     uint32_t act_zero_off[3] = {0, 0, 0}, dz_zero_off = 0;
     bool gemm3_ring = true;            // dgrad / wgrad with >= 192 rows on k_gemm3_ring (256 x 128 tiles, 3-stage ring) instead of k_gemm3
     bool fork = false;                 // measured: no gain as direct launches, 7 % slower inside a hipGraph (profiles/README.md)
@@ -1483,6 +1510,8 @@ Trainer* trainer_create(int channels, const char** err) {
             }
             t->act_zero_off[l] = (uint32_t)(rows[l] * C * sizeof(uint16_t));
         }
+        for (int l = 3; l < 5; ++l)
+            for (uint16_t** q : {&t->act_bhi[l], &t->act_blo[l]}) ok &= (*q = t->dalloc<uint16_t>(rows[l] * nout[l])) != nullptr;
         for (int l = 1; l < 4; ++l) {
             for (uint16_t** q : {&t->col_hi[l], &t->col_lo[l], &t->col_bhi[l], &t->col_blo[l]}) ok &= (*q = t->dalloc<uint16_t>(rows[l] * kin[l])) != nullptr;
             for (uint16_t** q : {&t->wt_hi[l], &t->wt_lo[l]}) ok &= (*q = t->dalloc<uint16_t>(kin[l] * C)) != nullptr;
@@ -1707,6 +1736,8 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     const bool fork = x3 && t->fork && t->side;
     // the gathered conv GEMMs need the f16 x 3 forward, k_wgrad3_tr's shapes (42 b, 20 b, 6 b rows in 32s: b % 16 == 0; C % 256 == 0)
     const bool impl = x3 && t->implicit && t->fwd_x3 && t->wgrad_tr && b % 16 == 0 && b * 20 > BN_SMALL_ROWS && C % 256 == 0;
+    // the FC layers' wgrad on k_wgrad3_tr as well (A = the previous layer's activations as bf16 pairs, two 32-row K-steps at batch 64)
+    auto fc_tr = [&](int l) { return x3 && t->wgrad_tr && l >= 4 && b % 32 == 0 && ld[l].K % 256 == 0 && ld[l].N % 128 == 0; };
     const int geo[4][3] = {{6, 7, 1}, {6, 7, 1}, {6, 7, 0}, {4, 5, 0}};      // conv layer l: input H, W, pad
     auto gather = [&](int l, bool dgrad) {      // ImplicitA of conv layer l (1..3): forward / wgrad rows = outputs, dgrad rows = inputs
         const int H = geo[l][0], W = geo[l][1], pad = geo[l][2], Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
@@ -1720,11 +1751,15 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     auto hand = [&](hipEvent_t ev, hipStream_t from, hipStream_t to) {       // `to` continues after everything enqueued on `from` so far
         if (fork) { (void)hipEventRecord(ev, from); (void)hipStreamWaitEvent(to, ev, 0); }
     };
-    auto split_weights = [&]() {
+    auto split_desc = [&]() {
         SplitWeights sw{};
         const int64_t offs[5] = {L.conv_w[1], L.conv_w[2], L.conv_w[3], L.fc_w[0], L.fc_w[1]};
         for (int i = 0; i < 5; ++i) { sw.off[i] = offs[i]; sw.count[i] = (int64_t)ld[i + 1].K * ld[i + 1].N; }
         if (impl) { sw.perm_c[0] = C; sw.perm_n[0] = C; }      // conv2 only: its dgrad is the gathered GEMM
+        return sw;
+    };
+    auto split_weights = [&]() {
+        const SplitWeights sw = split_desc();
         hipLaunchKernelGGL(k_split_weights, dim3(256, 5), dim3(256), 0, s2, (const float*)P, sw, t->w_hi, t->w_lo);
     };
     if (fork) {                      // the weight split needs the parameters only: under the forward pass
@@ -1736,11 +1771,18 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     const bool fx3 = x3 && t->fwd_x3;           // "train_gemm" 0 keeps every GEMM on the f32 matrix cores
     // k_wgrad3_tr's shape constraints (a batch of 64 meets them at every width that is a multiple of 256 / 9 ... i.e. 9 C % 256 == 0)
     auto tr_ok = [&](int l) { return x3 && t->wgrad_tr && l >= 1 && l <= 3 && ld[l].M % 32 == 0 && ld[l].K % 256 == 0 && ld[l].N % 128 == 0; };
-    if (fx3) {          // W [9C][C] of conv2..conv4 -> (256 W)^T as half hi / lo [C][9C], one launch
+    const bool prep_one = fx3 && !fork;      // both weight preparations in one launch, ahead of the forward pass
+    if (fx3) {          // W [9C][C] of conv2..conv4 -> (256 W)^T as half hi / lo [C][9C]
         TransposeJob j[3];
         for (int l = 1; l <= 3; ++l) j[l - 1] = TransposeJob{P + ld[l].w, t->wt_hi[l], t->wt_lo[l], C, C / 64, C};
-        hipLaunchKernelGGL((k_transpose_split<true>), dim3((unsigned)(3 * (C / 64)), (unsigned)(9 * C / 64)), dim3(256), 0, s, j[0], j[1], j[2], 9 * C,
-                           9 * C, 256.0f);
+        const int tgx = 3 * (C / 64), tgy = 9 * C / 64;
+        if (prep_one) {
+            const SplitWeights sw = split_desc();
+            hipLaunchKernelGGL(k_weight_prep, dim3((unsigned)(tgx * tgy + 256 * 5)), dim3(256), 0, s, j[0], j[1], j[2], 9 * C, 9 * C, 256.0f, tgx, tgy,
+                               (const float*)P, sw, t->w_hi, t->w_lo, 256);
+        } else {
+            hipLaunchKernelGGL((k_transpose_split<true>), dim3((unsigned)tgx, (unsigned)tgy), dim3(256), 0, s, j[0], j[1], j[2], 9 * C, 9 * C, 256.0f);
+        }
     }
     for (int l = 0; l < 6; ++l) {
         const LayerDef& d = ld[l];
@@ -1755,6 +1797,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
             gemm_nn(d.A, d.lda, P + d.w, t->z[l], P + d.bias, d.M, d.N, d.K, t->splitk, t->splitk_floats, s, t->fwd_dma);
         BnLayer bn = bn_desc(l, t->a[l], nullptr);
         if (impl && l <= 2) { bn.act_hi = t->act_hi[l]; bn.act_lo = t->act_lo[l]; bn.act_bhi = t->act_bhi[l]; bn.act_blo = t->act_blo[l]; }
+        if ((l == 3 || l == 4) && fc_tr(l + 1)) { bn.act_bhi = t->act_bhi[l]; bn.act_blo = t->act_blo[l]; }
         const int parts = red_parts(d.M), rpb = (d.M + parts - 1) / parts;
         if (d.M <= BN_SMALL_ROWS) {
             hipLaunchKernelGGL(k_bn_fwd_small, dim3(d.N / BN_COLS), dim3(256), 0, s, bn, h.bn_eps, h.bn_momentum, P + d.bn + 2 * d.N, P + d.bn + 3 * d.N, st);
@@ -1778,7 +1821,7 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
     // ---- backward ----
     hipLaunchKernelGGL(k_heads_bwd, grid1(std::max<int64_t>(512 * 8 + 8, (int64_t)b * 512)), dim3(256), 0, s, t->a[5], t->dhead,
                        P + L.pi_w, P + L.v_w, b, G + L.pi_w, G + L.pi_b, G + L.v_w, G + L.v_b, t->dact, t->sample_loss, t->loss_totals);
-    if (x3 && !fork) split_weights();
+    if (x3 && !fork && !prep_one) split_weights();
     if (fork) (void)hipStreamWaitEvent(s, t->ev_sw, 0);
     for (int l = 5; l >= 0; --l) {
         const LayerDef& d = ld[l];
@@ -1806,6 +1849,10 @@ void enqueue_step(Trainer* t, const TrainHyper& h, const float* d_boards, const 
                 const ImplicitA ia = gather(l, false);
                 launch_wgrad3_tr(t->act_bhi[l - 1], t->act_blo[l - 1], 0, t->dz_hi, t->dz_lo, d.N, G + d.w, d.M, d.K, d.N, fork ? t->splitk2 : t->splitk,
                                  fork ? t->splitk2_floats : t->splitk_floats, s2, &ia);
+                if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
+            } else if (fc_tr(l)) {
+                launch_wgrad3_tr(t->act_bhi[l - 1], t->act_blo[l - 1], d.K, t->dz_hi, t->dz_lo, d.N, G + d.w, d.M, d.K, d.N, fork ? t->splitk2 : t->splitk,
+                                 fork ? t->splitk2_floats : t->splitk_floats, s2);
                 if (fork) (void)hipEventRecord(t->ev_tr[l], s2);
             } else if (tr_ok(l)) {       // A and dz as stored: no transposes
                 launch_wgrad3_tr(t->col_bhi[l], t->col_blo[l], (int)d.lda, t->dz_hi, t->dz_lo, d.N, G + d.w, d.M, d.K, d.N, fork ? t->splitk2 : t->splitk,

@@ -177,6 +177,10 @@ const char* az_last_error(const az_engine* e);
  *                           weights x 256 split into half-precision hi / lo pairs, three products, f32 accumulate: 2^-22, the grade of
  *                           the f32 kernel's own accumulation -- gradients stay within 1e-5 of float64 autograd), 0: on
  *                           v_mfma_f32_16x16x4_f32; "train_gemm3_ring" 1 (default) / 0: the big x 3 GEMMs on the 256 x 128 ring kernel,
+ *            "train_wgrad_tr" 1 (default) / 0: conv wgrad from the operands as stored, transposed LDS reads (k_wgrad3_tr) instead of
+ *                           transpose kernels + k_gemm3; "train_implicit" 1 (default) / 0: conv2..conv4's GEMMs gather their A rows from
+ *                           the activations instead of reading im2col matrices (needs batch % 16 == 0 and net_channels % 256 == 0,
+ *                           else the im2col path runs); every combination is held to the same bars by tests/test_train_gpu.py,
  *            "train_fork" 0 (default) / 1: with "train_gemm" 1, a step's weight split and wgrad chains run on a second stream
  *                           branch beside the BatchNorm-backward / dgrad chain (bit-identical; measured no faster, so off),
  *            "train_fwd_dma" 1 (default): the forward GEMMs' tiles go global -> LDS by LDS-DMA (k_gemm_f32_dma), 0: register-staged
