@@ -801,7 +801,11 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("train_fwd_x3") && (value == 0 || value == 1)) { e->train_fwd_x3 = (int)value; if (e->trainer) trainer_set_fwd_x3(e->trainer, value != 0); return AZ_OK; }
     if (is("train_wgrad_tr") && (value == 0 || value == 1)) { e->train_wgrad_tr = (int)value; if (e->trainer) trainer_set_wgrad_tr(e->trainer, value != 0); return AZ_OK; }
     if (is("train_implicit") && (value == 0 || value == 1)) { e->train_implicit = (int)value; if (e->trainer) trainer_set_implicit(e->trainer, value != 0); return AZ_OK; }
-    if (is("train_fork") && (value == 0 || value == 1)) { e->train_fork = (int)value; if (e->trainer) trainer_set_fork(e->trainer, value != 0); return AZ_OK; }
+    if (is("train_fork") && (value == 0 || value == 1)) {
+        e->train_fork = (int)value;
+        if (e->trainer) { (void)hipSetDevice(e->device); trainer_set_fork(e->trainer, value != 0); }
+        return AZ_OK;
+    }
     if (is("train_gemm") && (value == 0 || value == 1)) { e->train_gemm = (int)value; if (e->trainer) trainer_set_gemm(e->trainer, (int)value); return AZ_OK; }
     if (is("train_fwd_dma") && (value == 0 || value == 1)) { e->train_fwd_dma = (int)value; if (e->trainer) trainer_set_fwd_dma(e->trainer, value != 0); return AZ_OK; }
     if (is("train_lr_e9") && value > 0) { e->hyper.lr = (float)((double)value * 1e-9); return AZ_OK; }

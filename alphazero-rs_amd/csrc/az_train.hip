@@ -1521,11 +1521,6 @@ Trainer* trainer_create(int channels, const char** err) {
     ok &= (t->splitk = t->dalloc<float>(t->splitk_floats)) != nullptr;
     t->splitk2_floats = (size_t)16 << 20;     // wgrad outputs are [K][N] <= 1152 x 128 or 768 x 1024 floats per slice
     ok &= (t->splitk2 = t->dalloc<float>(t->splitk2_floats)) != nullptr;
-    ok &= hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess;
-    for (hipEvent_t* ev : {&t->ev_start, &t->ev_sw, &t->ev_join}) ok &= hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
-    for (int l = 0; l < 6; ++l)
-        ok &= hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&t->ev_tr[l], hipEventDisableTiming) == hipSuccess;
     if (!ok) { if (err) *err = "hipMalloc failed for the trainer workspace"; trainer_destroy(t); return nullptr; }
     (void)hipMemset(t->loss_totals, 0, 2 * sizeof(double));
     return t;
@@ -1949,7 +1944,21 @@ bool trainer_run_epoch(Trainer* t, const TrainHyper& h, const float* all_boards,
 
 void trainer_set_graph(Trainer* t, bool on) { if (t) t->use_graph = on; }
 void trainer_set_gemm(Trainer* t, int mode) { if (t) t->gemm_mode = mode; }
-void trainer_set_fork(Trainer* t, bool on) { if (t) t->fork = on; }
+// The branch's stream and events exist only once the option has been switched on: an idle extra stream still takes one of the device's
+// few hardware queues, and the arena's two search streams then share one (measured: az_arena 2755 -> 1860 games/s in a process whose
+// trainer merely owned a second stream).
+void trainer_set_fork(Trainer* t, bool on) {
+    if (!t) return;
+    if (on && !t->side) {
+        bool ok = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess;
+        for (hipEvent_t* ev : {&t->ev_start, &t->ev_sw, &t->ev_join}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+        for (int l = 0; l < 6 && ok; ++l)
+            ok = hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&t->ev_tr[l], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { if (t->side) { (void)hipStreamDestroy(t->side); t->side = nullptr; } on = false; }
+    }
+    t->fork = on;
+}
 void trainer_set_fwd_x3(Trainer* t, bool on) { if (t) t->fwd_x3 = on; }
 void trainer_set_wgrad_tr(Trainer* t, bool on) { if (t) t->wgrad_tr = on; }
 void trainer_set_implicit(Trainer* t, bool on) { if (t) t->implicit = on; }

@@ -21,6 +21,9 @@
  *     thread captures its search loop as a hipGraph, HIP refuses the blocking
  *     copies of the other thread (hipErrorStreamCaptureImplicit, reported as
  *     AZ_ERR_HIP).  Measured gain of that arrangement: none (profiles/README.md).
+ *     az_arena overlaps its two models' searches on two HIP streams; streams share the device's few hardware queues, so a
+ *     process that keeps many other streams alive can make the two share one (measured: 2755 -> 1860 games/s with one extra
+ *     idle stream).
  *   - Game state: Connect Four as two 7x6 bitboards in canonical form
  *     {mine, theirs} (side to move = mine); bit(col,row) = col*7 + row with
  *     row 0 = bottom; bit col*7+6 is always clear.
