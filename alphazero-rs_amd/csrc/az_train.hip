@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__(256) void k_colreduce(const BnLayer L, int rpb, dou
 AZ_D void bn_sum_partials(const double* __restrict__ partial, int nparts, int N, int col0, double (*sums)[2]) {
     const int cl = threadIdx.x >> 1, v = threadIdx.x & 1;
     double t = 0.0;
-    for (int p = 0; p < nparts; ++p) t += partial[((size_t)p * N + col0 + cl) * 2 + v];
+#pragma unroll 8
+    for (int p = 0; p < nparts; ++p) t += partial[((size_t)p * N + col0 + cl) * 2 + v];      // unrolled: the loads go out together, the sum keeps its order
     sums[cl][v] = t;
 }
 
@@ -1100,6 +1101,16 @@ __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double*
     __shared__ double sums[BN_COLS][2];
     __shared__ __attribute__((aligned(16))) float s_mean[BN_COLS], s_inv[BN_COLS];
     const int col0 = blockIdx.x * BN_COLS;
+    // this thread's rows (rpb <= 32: at most four, 8 apart) are requested BEFORE the statistics are summed, so that their round trip
+    // runs under that prologue instead of after it
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
+    const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
+    float4 zpre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + ty + q * BN_LANES;
+        zpre[q] = r < r1 ? *(const float4*)(L.z + (size_t)r * L.N + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     bn_sum_partials(partial, nparts, L.N, col0, sums);
     __syncthreads();
     if (threadIdx.x < BN_COLS) {
@@ -1117,15 +1128,11 @@ __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double*
         }
     }
     __syncthreads();
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
     const float4 mean = *(const float4*)(s_mean + tx * 4), inv = *(const float4*)(s_inv + tx * 4);
     const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
     const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
-    const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
-#pragma unroll 4
-    for (int r = r0 + ty; r < r1; r += BN_LANES) {
+    auto row = [&](int r, const float4 z) {
         const size_t i = (size_t)r * L.N + c;
-        const float4 z = *(const float4*)(L.z + i);
         float4 y = make_float4(fmaxf(gamma.x * ((z.x - mean.x) * inv.x) + beta.x, 0.0f), fmaxf(gamma.y * ((z.y - mean.y) * inv.y) + beta.y, 0.0f),
                                fmaxf(gamma.z * ((z.z - mean.z) * inv.z) + beta.z, 0.0f), fmaxf(gamma.w * ((z.w - mean.w) * inv.w) + beta.w, 0.0f));
         if (L.keep_thresh) {
@@ -1147,7 +1154,13 @@ __global__ __launch_bounds__(256) void k_bn_apply(const BnLayer L, const double*
             *(uint2*)(L.act_bhi + i) = bh;
             *(uint2*)(L.act_blo + i) = bl;
         }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + ty + q * BN_LANES;
+        if (r < r1) row(r, zpre[q]);
     }
+    for (int r = r0 + ty + 4 * BN_LANES; r < r1; r += BN_LANES) row(r, *(const float4*)(L.z + (size_t)r * L.N + c));
 }
 
 // dz = gamma * invstd * (g - (dbeta + xhat * dgamma) / M), dgamma = sum g*xhat, dbeta = sum g (same grid as k_bn_apply)
@@ -1157,6 +1170,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnLayer L, const dou
     __shared__ double sums[BN_COLS][2];
     __shared__ __attribute__((aligned(16))) float s_db[BN_COLS], s_dg[BN_COLS];
     const int col0 = blockIdx.x * BN_COLS;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
+    const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
+    float4 zpre[4], gpre[4];          // requested before the prologue (see k_bn_apply)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + ty + q * BN_LANES;
+        const size_t i = (size_t)r * L.N + c;
+        zpre[q] = r < r1 ? *(const float4*)(L.z + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gpre[q] = r < r1 ? *(const float4*)(L.grad_out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     bn_sum_partials(partial, nparts, L.N, col0, sums);
     __syncthreads();
     if (threadIdx.x < BN_COLS) {
@@ -1165,17 +1188,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnLayer L, const dou
         if (blockIdx.y == 0) { dbeta[c] = (float)sums[cl][0]; dgamma[c] = (float)sums[cl][1]; }
     }
     __syncthreads();
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c = col0 + tx * 4;
     const float4 mean = *(const float4*)(L.mean + c), invstd = *(const float4*)(L.invstd + c);
     const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
     const float4 db = *(const float4*)(s_db + tx * 4), dg = *(const float4*)(s_dg + tx * 4);
     const float inv_m = 1.0f / (float)L.M;
     const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
-    const int r0 = blockIdx.y * rpb, r1 = min(L.M, r0 + rpb);
-#pragma unroll 4
-    for (int r = r0 + ty; r < r1; r += BN_LANES) {
+    auto row = [&](int r, const float4 z, const float4 go) {
         const size_t i = (size_t)r * L.N + c;
-        const float4 z = *(const float4*)(L.z + i), go = *(const float4*)(L.grad_out + i);
         float xh;
         float4 dz;
         float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); dz.x = gamma.x * invstd.x * (g - (db.x + xh * dg.x) * inv_m);
@@ -1189,27 +1208,53 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnLayer L, const dou
             *(uint2*)(L.out_hi + i) = hi;
             *(uint2*)(L.out_lo + i) = lo;
         }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + ty + q * BN_LANES;
+        if (r < r1) row(r, zpre[q], gpre[q]);
+    }
+    for (int r = r0 + ty + 4 * BN_LANES; r < r1; r += BN_LANES) {
+        const size_t i = (size_t)r * L.N + c;
+        row(r, *(const float4*)(L.z + i), *(const float4*)(L.grad_out + i));
     }
 }
 
 // The FC layers' BatchNorm (at most BN_SMALL_ROWS rows: one slice): both stages in ONE launch -- a block owns 128 columns of EVERY row, so
 // it has the complete column sums itself (same lane-order summation as k_colreduce with one slice: identical results).
 constexpr int BN_SMALL_ROWS = 64;
+// A thread's rows (at most BN_SMALL_ROWS / BN_LANES = 8, 8 apart) are loaded ONCE, all in flight together, and kept in registers for
+// both stages: the kernels were four dependent round trips (two per stage), now one.
+constexpr int BN_SMALL_PER = BN_SMALL_ROWS / BN_LANES;
+template <int KIND>
+AZ_D void bn_small_load(const BnLayer& L, float4 (&zr)[BN_SMALL_PER], float4 (&gr)[BN_SMALL_PER]) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * BN_COLS + tx * 4;
+#pragma unroll
+    for (int q = 0; q < BN_SMALL_PER; ++q) {
+        const int r = ty + q * BN_LANES;
+        const size_t i = (size_t)r * L.N + c;
+        zr[q] = r < L.M ? *(const float4*)(L.z + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND == 1) gr[q] = r < L.M ? *(const float4*)(L.grad_out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 template <int KIND>
 AZ_D void bn_small_sums(const BnLayer& L, uint64_t mask_seed, float4 mean, float4 invstd, float4 gamma, float4 beta, double (*red)[32][8],
-                        double (*sums)[2]) {
+                        double (*sums)[2], const float4 (&zr)[BN_SMALL_PER], const float4 (&gr)[BN_SMALL_PER]) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * BN_COLS + tx * 4;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-#pragma unroll 4
-    for (int r = ty; r < L.M; r += BN_LANES) {
+#pragma unroll
+    for (int q = 0; q < BN_SMALL_PER; ++q) {
+        const int r = ty + q * BN_LANES;
+        if (r >= L.M) break;
         const size_t i = (size_t)r * L.N + c;
-        const float4 z = *(const float4*)(L.z + i);
+        const float4 z = zr[q];
         if (KIND == 0) {
             s0[0] += z.x; s1[0] += (double)z.x * z.x; s0[1] += z.y; s1[1] += (double)z.y * z.y;
             s0[2] += z.z; s1[2] += (double)z.z * z.z; s0[3] += z.w; s1[3] += (double)z.w * z.w;
         } else {
-            const float4 go = *(const float4*)(L.grad_out + i);
+            const float4 go = gr[q];
             float xh;
             float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); s0[0] += g; s1[0] += (double)g * xh;
             g = bn_grad_in(L, mask_seed, i + 1, z.y, go.y, mean.y, invstd.y, gamma.y, beta.y, xh); s0[1] += g; s1[1] += (double)g * xh;
@@ -1234,7 +1279,9 @@ __global__ __launch_bounds__(256) void k_bn_fwd_small(const BnLayer L, float eps
     __shared__ double sums[BN_COLS][2];
     __shared__ __attribute__((aligned(16))) float s_mean[BN_COLS], s_inv[BN_COLS];
     const float4 z4 = make_float4(0, 0, 0, 0);
-    bn_small_sums<0>(L, 0, z4, z4, z4, z4, red, sums);
+    float4 zr[BN_SMALL_PER], gr[BN_SMALL_PER];
+    bn_small_load<0>(L, zr, gr);
+    bn_small_sums<0>(L, 0, z4, z4, z4, z4, red, sums, zr, gr);
     const int col0 = blockIdx.x * BN_COLS;
     if (threadIdx.x < BN_COLS) {
         const int cl = threadIdx.x, c = col0 + cl;
@@ -1253,10 +1300,12 @@ __global__ __launch_bounds__(256) void k_bn_fwd_small(const BnLayer L, float eps
     const float4 mean = *(const float4*)(s_mean + tx * 4), inv = *(const float4*)(s_inv + tx * 4);
     const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
     const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
-#pragma unroll 4
-    for (int r = ty; r < L.M; r += BN_LANES) {
+#pragma unroll
+    for (int q = 0; q < BN_SMALL_PER; ++q) {
+        const int r = ty + q * BN_LANES;
+        if (r >= L.M) break;
         const size_t i = (size_t)r * L.N + c;
-        const float4 z = *(const float4*)(L.z + i);
+        const float4 z = zr[q];
         float4 y = make_float4(fmaxf(gamma.x * ((z.x - mean.x) * inv.x) + beta.x, 0.0f), fmaxf(gamma.y * ((z.y - mean.y) * inv.y) + beta.y, 0.0f),
                                fmaxf(gamma.z * ((z.z - mean.z) * inv.z) + beta.z, 0.0f), fmaxf(gamma.w * ((z.w - mean.w) * inv.w) + beta.w, 0.0f));
         if (L.keep_thresh) {
@@ -1284,15 +1333,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_small(const BnLayer L, float* __
     const float4 mean = *(const float4*)(L.mean + c), invstd = *(const float4*)(L.invstd + c);
     const float4 gamma = *(const float4*)(L.gamma + c), beta = *(const float4*)(L.beta + c);
     const uint64_t mask_seed = L.keep_thresh ? st->mask_seed : 0;
-    bn_small_sums<1>(L, mask_seed, mean, invstd, gamma, beta, red, sums);
+    float4 zr[BN_SMALL_PER], gr[BN_SMALL_PER];
+    bn_small_load<1>(L, zr, gr);
+    bn_small_sums<1>(L, mask_seed, mean, invstd, gamma, beta, red, sums, zr, gr);
     if (threadIdx.x < BN_COLS) { dbeta[col0 + threadIdx.x] = (float)sums[threadIdx.x][0]; dgamma[col0 + threadIdx.x] = (float)sums[threadIdx.x][1]; }
     const float4 db = make_float4((float)sums[tx * 4][0], (float)sums[tx * 4 + 1][0], (float)sums[tx * 4 + 2][0], (float)sums[tx * 4 + 3][0]);
     const float4 dg = make_float4((float)sums[tx * 4][1], (float)sums[tx * 4 + 1][1], (float)sums[tx * 4 + 2][1], (float)sums[tx * 4 + 3][1]);
     const float inv_m = 1.0f / (float)L.M;
-#pragma unroll 4
-    for (int r = ty; r < L.M; r += BN_LANES) {
+#pragma unroll
+    for (int q = 0; q < BN_SMALL_PER; ++q) {
+        const int r = ty + q * BN_LANES;
+        if (r >= L.M) break;
         const size_t i = (size_t)r * L.N + c;
-        const float4 z = *(const float4*)(L.z + i), go = *(const float4*)(L.grad_out + i);
+        const float4 z = zr[q], go = gr[q];
         float xh;
         float4 dz;
         float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); dz.x = gamma.x * invstd.x * (g - (db.x + xh * dg.x) * inv_m);
@@ -1359,18 +1412,21 @@ __global__ void k_heads_bwd(const float* __restrict__ a, const float* __restrict
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {       // fixed-order sum of the per-sample losses into the running totals (b <= 256)
         double lp = 0.0, lv = 0.0;
-        for (int j = 0; j < b; ++j) { lp += sample_loss[2 * j]; lv += sample_loss[2 * j + 1]; }
+#pragma unroll 16
+        for (int j = 0; j < b; ++j) { lp += sample_loss[2 * j]; lv += sample_loss[2 * j + 1]; }      // unrolled: the loads go out together, the sum keeps its order
         totals[0] += lp / b;
         totals[1] += lv / b;
     }
     if (i < 512 * 8) {
         const int k = i >> 3, o = i & 7;
         float s = 0.0f;
+#pragma unroll 16
         for (int j = 0; j < b; ++j) s += a[(size_t)j * 512 + k] * dhead[(size_t)j * 8 + o];
         if (o < 7) d_pi_w[k * 7 + o] = s; else d_v_w[k] = s;
     } else if (i < 512 * 8 + 8) {
         const int o = i - 512 * 8;
         float s = 0.0f;
+#pragma unroll 16
         for (int j = 0; j < b; ++j) s += dhead[(size_t)j * 8 + o];
         if (o < 7) d_pi_b[o] = s; else d_v_b[0] = s;
     }
