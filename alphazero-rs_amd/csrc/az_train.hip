@@ -273,8 +273,38 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, i
         const int n = (int)(i % N);
         const int64_t m = i / N;
         float s = partial[i];
+#pragma unroll 8
         for (int z = 1; z < splits; ++z) s += partial[(int64_t)z * total + i];
         C[m * ldc + n] = s + (bias ? bias[n] : 0.0f);
+    }
+}
+// the same four columns at a time (N % 4 == 0, ldc % 4 == 0, 16-byte-aligned bases): the slices' loads of an element go out together
+// (unrolled; the sum keeps its slice order), 16 bytes per lane
+__global__ void k_splitk_reduce4(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int64_t ldc,
+                                 const float* __restrict__ bias) {
+    const int64_t total4 = (int64_t)M * N / 4;
+    const int n4 = N / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % n4) * 4;
+        const int64_t m = i / n4;
+        float4 s = *(const float4*)(partial + i * 4);
+#pragma unroll 8
+        for (int z = 1; z < splits; ++z) {
+            const float4 v = *(const float4*)(partial + ((int64_t)z * total4 + i) * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (bias) { const float4 b = *(const float4*)(bias + n); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+        *(float4*)(C + m * ldc + n) = s;
+    }
+}
+void launch_splitk_reduce(const float* partial, int splits, int M, int N, float* C, int64_t ldc, const float* bias, hipStream_t s) {
+    const bool v4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)partial & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
+    if (v4) {
+        const int64_t n = (int64_t)M * N / 4;
+        hipLaunchKernelGGL(k_splitk_reduce4, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, partial, splits, M, N, C, ldc, bias);
+    } else {
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, partial, splits, M, N, C, ldc, bias);
     }
 }
 
@@ -1054,20 +1084,34 @@ __global__ __launch_bounds__(256) void k_colreduce(const BnLayer L, int rpb, dou
         gamma = *(const float4*)(L.gamma + c); beta = *(const float4*)(L.beta + c);
         if (L.keep_thresh) mask_seed = st->mask_seed;
     }
-#pragma unroll 4
-    for (int r = r0 + ty; r < r1; r += BN_LANES) {
-        const size_t i = (size_t)r * L.N + c;
-        const float4 z = *(const float4*)(L.z + i);
+    // a thread's rows of the slice are requested together, twelve at a time (a slice of the conv layers has 64 .. 84 rows = 8 .. 11 per thread):
+    // one round trip per slice instead of one per four rows
+    auto accum = [&](size_t i, const float4 z, const float4 go) {
         if (KIND == 0) {
             s0[0] += z.x; s1[0] += (double)z.x * z.x; s0[1] += z.y; s1[1] += (double)z.y * z.y;
             s0[2] += z.z; s1[2] += (double)z.z * z.z; s0[3] += z.w; s1[3] += (double)z.w * z.w;
         } else {
-            const float4 go = *(const float4*)(L.grad_out + i);
             float xh;
             float g = bn_grad_in(L, mask_seed, i + 0, z.x, go.x, mean.x, invstd.x, gamma.x, beta.x, xh); s0[0] += g; s1[0] += (double)g * xh;
             g = bn_grad_in(L, mask_seed, i + 1, z.y, go.y, mean.y, invstd.y, gamma.y, beta.y, xh); s0[1] += g; s1[1] += (double)g * xh;
             g = bn_grad_in(L, mask_seed, i + 2, z.z, go.z, mean.z, invstd.z, gamma.z, beta.z, xh); s0[2] += g; s1[2] += (double)g * xh;
             g = bn_grad_in(L, mask_seed, i + 3, z.w, go.w, mean.w, invstd.w, gamma.w, beta.w, xh); s0[3] += g; s1[3] += (double)g * xh;
+        }
+    };
+    constexpr int PER = 12;
+    for (int rb = r0 + ty; rb < r1; rb += PER * BN_LANES) {
+        float4 zv[PER], gv[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int r = rb + q * BN_LANES;
+            const size_t i = (size_t)r * L.N + c;
+            zv[q] = r < r1 ? *(const float4*)(L.z + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KIND == 1) gv[q] = r < r1 ? *(const float4*)(L.grad_out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int r = rb + q * BN_LANES;
+            if (r < r1) accum((size_t)r * L.N + c, zv[q], KIND == 1 ? gv[q] : zv[q]);
         }
     }
 #pragma unroll
@@ -1654,7 +1698,7 @@ void launch_gemm_f32(GemmF32 g, float* ws, size_t ws_floats, hipStream_t s) {
     if (big) hipLaunchKernelGGL((k_gemm_f32<A_K1, B_N1, 128>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_f32<A_K1, B_N1, 64>), grid, dim3(256), 0, s, g);
     if (splits > 1)
-        hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)g.M * g.N), dim3(256), 0, s, ws, splits, g.M, g.N, out, ldc, bias);
+        launch_splitk_reduce(ws, splits, g.M, g.N, out, ldc, bias, s);
 }
 
 // C[M][N] = A[M][K] W[K][N] + bias
@@ -1672,7 +1716,7 @@ void gemm_nn(const float* A, int64_t lda, const float* W, float* Cm, const float
         g.splits = splits;
         if (splits > 1) { g.C = ws; g.bias = nullptr; }
         hipLaunchKernelGGL(k_gemm_f32_dma, dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(256), 0, s, g);
-        if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, Cm, (int64_t)N, bias);
+        if (splits > 1) launch_splitk_reduce(ws, splits, M, N, Cm, (int64_t)N, bias, s);
         return;
     }
     launch_gemm_f32<1, 1>(g, ws, wsn, s);
@@ -1711,7 +1755,7 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
         if (f16) hipLaunchKernelGGL((k_gemm3_ring<true>), dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
         else hipLaunchKernelGGL((k_gemm3_ring<false>), dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
         if (splits > 1)
-            hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
+            launch_splitk_reduce(ws, splits, M, N, out, (int64_t)ldo, bias, s);
         return;
     }
     const int mt = (M + G3_BM - 1) / G3_BM, NT = N / 128, tiles = mt * NT;
@@ -1725,7 +1769,7 @@ void launch_gemm3(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uin
     if (f16) hipLaunchKernelGGL((k_gemm3<true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm3<false>), grid, dim3(256), 0, s, g);
     if (splits > 1)
-        hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)M * N), dim3(256), 0, s, ws, splits, M, N, out, (int64_t)ldo, bias);
+        launch_splitk_reduce(ws, splits, M, N, out, (int64_t)ldo, bias, s);
 }
 // dW [Kin][N] = A^T dz on k_wgrad3_tr; split-K over the 32-row steps so that at most 256 workgroups exist, slices summed in slice order
 void launch_wgrad3_tr(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* z_hi, const uint16_t* z_lo, int ldz, float* out, int M,
@@ -1738,7 +1782,7 @@ void launch_wgrad3_tr(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const
     Wgrad3 g{a_hi, a_lo, z_hi, z_lo, splits > 1 ? ws : out, Kin, N, M, lda, ldz, sps, splits, ia ? *ia : ImplicitA{},
              ia ? (65536 + ia->Ht * ia->Wt - 1) / (ia->Ht * ia->Wt) : 0, ia ? (65536 + ia->Wt - 1) / ia->Wt : 0};
     hipLaunchKernelGGL(k_wgrad3_tr, dim3((unsigned)((tiles * splits + 7) / 8 * 8)), dim3(512), 0, s, g);
-    if (splits > 1) hipLaunchKernelGGL(k_splitk_reduce, grid1((int64_t)Kin * N), dim3(256), 0, s, ws, splits, Kin, N, out, (int64_t)N, nullptr);
+    if (splits > 1) launch_splitk_reduce(ws, splits, Kin, N, out, (int64_t)N, nullptr, s);
 }
 void launch_transpose_split2(const TransposeJob& j0, const TransposeJob& j1, int R, int Rp, hipStream_t s) {
     hipLaunchKernelGGL((k_transpose_split<false>), dim3((unsigned)(j0.tiles_c + j1.tiles_c), (unsigned)(Rp / 64)), dim3(256), 0, s, j0, j1,
