@@ -269,6 +269,7 @@ struct az_engine {
     // eval logs of the last az_arena with record_evals: [0] the new model's trees, [1] the old model's
     struct EvalLog { std::vector<int32_t> count; std::vector<uint64_t> states; std::vector<float> pi, v; };
     EvalLog ar_log[2];
+    struct SelfplaySession* sp_session = nullptr;      // az_selfplay_begin .. az_selfplay_end
     int ar_log_cap = 0, ar_log_games = 0;
     std::vector<uint8_t> ar_moves;      // [games][AZ_MAX_PLIES] move record of the last az_arena (az_arena_get_moves)
     std::vector<int32_t> ar_len;
@@ -752,6 +753,7 @@ void az_destroy(az_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    (void)az_selfplay_end(e);
     for (auto& kv : e->nets) if (kv.second.conv) convnet_destroy(kv.second.conv);
     for (NetWorkspace* w : e->ws) netws_destroy(w);
     if (e->cache_keys) (void)hipFree(e->cache_keys);
@@ -1381,15 +1383,42 @@ az_status az_tree_get_action_prob(az_tree* t, const uint64_t* states, float temp
 }
 
 // ---- Coach::execute_episode x many -----------------------------------------------------------
-az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out) {
-    if (!e || !p || !out) return AZ_ERR_BAD_ARGUMENT;
+// ---- Coach::execute_episode x many, as a SESSION: the slots stay full across the calls that fetch the episodes -------------------------
+// az_selfplay_begin fixes the session's episodes (ids 0 .. n_games-1, slot refill in id order); az_selfplay_next(k) plays until the next k
+// episodes IN ID ORDER are finished and emits their tuples -- the slots those episodes freed are already playing later ones, so a host
+// that fetches its episodes in chunks pays the drain (the last few slots finishing alone: 6 % of a 65536-episode call) once per session
+// instead of once per chunk.  An episode depends on (seed, first_game_id + index) and the net alone, so a chunk's tuples are the ones
+// az_selfplay would return for the same episodes.  az_selfplay is begin + next(all) + end.
+struct SelfplaySession {
+    az_selfplay_params p{};
+    int C = 0, T = 1, n_games = 0;
+    NetModel* net = nullptr;
+    uint64_t net_generation = 0;
+    TreeLease lease;
+    DeviceMem mem;
+    ScopedEvalLog evlog;
+    GamesDev gd{};
+    SearchParams sp{};
+    SelfplayMoveParams mp{};
+    uint32_t* h_ctr = nullptr;           // pinned read-back of gd.counters
+    int active = 0, rows_typ = 0;
+    int delivered = 0;                   // episodes handed out by az_selfplay_next so far
+    long long iter = 0;
+    bool async_mode = false;
+    // free-running mode (selfplay_async)
+    EvalBatch B[2];
+    EvalCache ec{};
+    int fill = 0;
+    long long step = 0;
+    ~SelfplaySession() { if (h_ctr) (void)hipHostFree(h_ctr); }
+};
+
+static az_status selfplay_begin_impl(az_engine* e, const az_selfplay_params* p, std::unique_ptr<SelfplaySession>& out) {
     if (p->n_games <= 0 || p->num_sims <= 0 || p->max_depth < 0 || p->reserve < 8)
         return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: bad argument");
     const int n_games = p->n_games;
     const int C = (p->concurrent <= 0 || p->concurrent > n_games) ? n_games : p->concurrent;
     if (C > 1024 * 64) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: at most 65536 concurrent games");
-    const int nsym = p->symmetries ? 2 : 1;
-    if (out->capacity < 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: negative capacity");
     NetModel* net;
     az_status st = find_net(e, p->model_id, &net);
     if (st) return st;
@@ -1398,173 +1427,262 @@ az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out
     if (st) return st;
     st = check_batch(e, *net, C * T);
     if (st) return st;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
+    if (az_status cs = check_tree_slots(e, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes))) return cs;
+    std::unique_ptr<SelfplaySession> ss(new SelfplaySession());
+    ss->p = *p; ss->C = C; ss->T = T; ss->n_games = n_games; ss->net = net; ss->net_generation = net->generation;
+    acquire_trees(e, ss->lease, C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES), T, s);
+    TreeHost& th = *ss->lease;
+    DeviceMem& mem = ss->mem;
+    GamesDev& gd = ss->gd;
+    gd.C = C;
+    gd.n_games = n_games;
+    gd.state = mem.alloc<ulonglong2>(C);
+    gd.player = mem.alloc<int8_t>(C);
+    gd.ply = mem.alloc<int32_t>(C);
+    gd.gid = mem.alloc<int32_t>(C);
+    gd.need_reset = mem.alloc<uint8_t>(C);
+    const size_t ns = (size_t)n_games * 42;
+    gd.smp_state = mem.alloc<ulonglong2>(ns);
+    gd.smp_pi = mem.alloc<float>(ns * 7);
+    gd.smp_player = mem.alloc<int8_t>(ns);
+    gd.moves = mem.alloc<uint8_t>(ns);
+    gd.g_len = mem.alloc<int32_t>(n_games);
+    gd.g_result = mem.alloc<float>(n_games);
+    gd.g_final_player = mem.alloc<int8_t>(n_games);
+    gd.counters = mem.alloc<uint32_t>(4);
+    if (p->record_evals > 0) {
+        // per-EPISODE logs (row = the slot's current episode id), so they survive slot refills
+        gd.g_log_len = mem.alloc<int32_t>(n_games);
+        HIPCHK(hipMemset(gd.g_log_len, 0, n_games * sizeof(int32_t)));
+        ss->evlog.attach(th, (size_t)n_games, p->record_evals, gd.gid);
+    }
+    {
+        std::vector<int32_t> gid(C);
+        std::vector<int8_t> pl(C, 1);
+        for (int i = 0; i < C; ++i) gid[i] = i;
+        HIPCHK(hipMemcpy(gd.gid, gid.data(), C * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(gd.player, pl.data(), C, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(gd.state, 0, (size_t)C * 16));
+        HIPCHK(hipMemset(gd.ply, 0, C * sizeof(int32_t)));
+        HIPCHK(hipMemset(gd.need_reset, 0, C));
+        HIPCHK(hipMemset(gd.moves, 0, ns));
+        HIPCHK(hipMemset(gd.g_len, 0, n_games * sizeof(int32_t)));
+        uint32_t ctr[4] = {(uint32_t)C, 0u, (uint32_t)C, 0u};
+        HIPCHK(hipMemcpy(gd.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
+    }
+    launch_reset_trees(th.d, nullptr, s);
+    prepare_cache(e, dedup_applies(e, *net), (uint64_t)n_games * AZ_MAX_PLIES * ((uint64_t)p->num_sims + 1), s);
+    ss->sp = SearchParams{(uint32_t)p->max_depth, (float)p->cpuct};
+    ss->mp = SelfplayMoveParams{p->seed, p->first_game_id, p->temp_threshold, C < n_games ? 1 : 0, 0, 0};
+    HIPCHK(hipHostMalloc((void**)&ss->h_ctr, 4 * sizeof(uint32_t)));
+    ss->active = C;                               // slots still playing (read back after every move)
+    ss->rows_typ = 0;                             // expected rows per leaf batch (0 = unknown: assume `active`)
+    // "selfplay_async": free-running slots (k_async_step) -- conv nets (anything that goes through leaf batches), one simulation in
+    // flight per tree.  `launches` tree launches share one leaf batch, then the forward runs on it.
+    ss->async_mode = e->selfplay_async != 0 && T == 1 && (net->kind == AZ_NET_CONV || dedup_applies(e, *net)) && p->num_sims >= 1;
+    if (ss->async_mode) {
+        gd.sims = mem.alloc<int32_t>(C);
+        HIPCHK(hipMemsetAsync(gd.sims, 0xFF, (size_t)C * sizeof(int32_t), s));       // -1: no root prepared yet
+        launch_selfplay_sync_active(th.d, gd, s);
+        th.d.block4 = e->tree_block4;
+        const bool dedup = dedup_applies(e, *net);
+        ss->ec = cache_for(e, *net);
+        ss->B[0] = th.eb; ss->B[1] = th.eb2;
+        ss->B[0].dedup = ss->B[1].dedup = dedup ? 1 : 0;
+        ss->B[0].max_n = ss->B[1].max_n = gd.counters + 3;
+    }
+    out = std::move(ss);
+    return AZ_OK;
+}
+
+// play until every episode below `hi` has finished (the counter of finished episodes is restarted for the range [delivered, hi))
+static az_status selfplay_run_until(az_engine* e, SelfplaySession& ss, int hi) {
+    hipStream_t s = e->stream;
+    TreeHost& th = *ss.lease;
+    GamesDev& gd = ss.gd;
+    NetModel* net = ss.net;
+    const az_selfplay_params* p = &ss.p;
+    const int C = ss.C, T = ss.T, n_games = ss.n_games, lo = ss.delivered;
+    uint32_t* h_ctr = ss.h_ctr;
+    ss.mp.done_lo = lo; ss.mp.done_hi = hi;
+    launch_count_done(gd.g_len, lo, hi, gd.counters + 1, s);
+    const uint32_t want = (uint32_t)(hi - lo);
+    az_status result = AZ_OK;
+    {   // a chunk whose episodes all finished while earlier ones were being waited for
+        HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h_ctr[1] >= want) return AZ_OK;
+    }
+    if (ss.async_mode) {
+        const int launches = std::max(1, e->selfplay_async_launches), iters = std::max(2, e->selfplay_async_iters);
+        const int every = std::max(1, e->profile_every);
+        // every leaf costs a forward at the latest `launches` launches after it was requested; a move needs num_sims + 2 leaves
+        const long long cap_steps = (long long)(AZ_MAX_PLIES + 2) * (n_games / C + 2) * ((long long)p->num_sims + 3) + 64;
+        for (;; ++ss.step) {
+            const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
+            for (int j = 0; j < launches; ++j) {
+                hipEvent_t t0 = nullptr;
+                if (timed && j == 0) t0 = e->prof.begin(s);
+                launch_async_step(th.d, gd, ss.B[ss.fill ^ 1], ss.B[ss.fill], ss.ec, ss.sp, ss.mp, p->num_sims, j == 0 ? 1 : 0, iters, s);
+                if (timed && j == 0) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
+                e->stats.tree_launches += 1;
+            }
+            if (ss.mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
+            net_forward(e, *net, ss.B[ss.fill], ss.active, s, ss.rows_typ, timed);
+            ss.fill ^= 1;
+            if ((ss.step & 15) == 15) {                  // look at the counters now and then: finished? how many slots still play?
+                HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                resolve_profile(e);
+                ss.active = std::max(1, (int)h_ctr[2]);
+                ss.rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)C) : 0;
+                HIPCHK(hipMemsetAsync(gd.counters + 3, 0, sizeof(uint32_t), s));
+                if (h_ctr[1] >= want) { ++ss.step; break; }
+                result = check_tree_errors(e, th);
+                if (result) break;
+                if (ss.step > cap_steps) { result = fail(e, AZ_ERR_HIP, "az_selfplay: episode loop did not terminate"); break; }
+            }
+        }
+        return result;
+    }
+    for (;; ++ss.iter) {
+        launch_selfplay_sync_active(th.d, gd, s);
+        // tile choice from the largest batch of the previous move (de-duplication makes batches much smaller than the
+        // number of searching trees); the grids still cover `active`
+        run_search(e, th, gd.state, p->num_sims, ss.sp, *net, ss.active, nullptr, ss.rows_typ, gd.counters + 3);
+        launch_selfplay_move(th.d, gd, ss.mp, s);
+        if (ss.mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
+        HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        resolve_profile(e);
+        ss.active = (int)h_ctr[2];
+        ss.rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)(C * T)) : 0;      // this move's largest batch
+        HIPCHK(hipMemsetAsync(gd.counters + 3, 0, sizeof(uint32_t), s));
+        if (h_ctr[1] >= want) { ++ss.iter; break; }
+        if ((ss.iter & 7) == 7 || h_ctr[2] == 0) {
+            result = check_tree_errors(e, th);
+            if (result) break;
+        }
+        if (h_ctr[2] == 0) { result = fail(e, AZ_ERR_HIP, "az_selfplay: every slot is idle before the requested episodes finished"); break; }
+        if (ss.iter > (long long)AZ_MAX_PLIES * (n_games / C + 2) + 8) {
+            result = fail(e, AZ_ERR_HIP, "az_selfplay: episode loop did not terminate");
+            break;
+        }
+    }
+    return result;
+}
+
+// tuples of the episodes [lo, hi) into `out` (game-id order then ply order)
+static az_status selfplay_emit(az_engine* e, SelfplaySession& ss, int lo, int hi, az_samples* out) {
+    hipStream_t s = e->stream;
+    const az_selfplay_params* p = &ss.p;
+    const GamesDev& gd = ss.gd;
+    const int n = hi - lo, nsym = p->symmetries ? 2 : 1;
+    std::vector<int32_t> glen((size_t)n);
+    HIPCHK(hipMemcpy(glen.data(), gd.g_len + lo, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int64_t> off((size_t)n);
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) { off[(size_t)i] = total; total += glen[(size_t)i]; }
+    e->stats.games += (uint64_t)n;
+    e->stats.moves += (uint64_t)total;
+    e->stats.samples += (uint64_t)total;
+    out->count = total * nsym;
+    if (out->capacity < out->count) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: sample buffers too small");
+    const size_t ns = (size_t)n * 42;
+    if (out->pis && out->zs) {
+        DeviceMem mem;
+        int64_t* d_off = mem.alloc<int64_t>((size_t)n);
+        HIPCHK(hipMemcpy(d_off, off.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+        const size_t cnt = (size_t)out->count;
+        ulonglong2* d_states = out->states ? mem.alloc<ulonglong2>(cnt) : nullptr;
+        float* d_boards = out->boards ? mem.alloc<float>(cnt * 84) : nullptr;
+        float* d_pis = mem.alloc<float>(cnt * 7);
+        float* d_zs = mem.alloc<float>(cnt);
+        GamesDev view = gd;          // the per-episode arrays of [lo, hi)
+        view.n_games = n;
+        view.smp_state += (size_t)lo * 42; view.smp_pi += (size_t)lo * 42 * 7; view.smp_player += (size_t)lo * 42; view.moves += (size_t)lo * 42;
+        view.g_len += lo; view.g_result += lo; view.g_final_player += lo;
+        launch_emit_samples(view, d_off, p->symmetries, d_states, d_boards, d_pis, d_zs, s);
+        HIPCHK(hipStreamSynchronize(s));
+        if (d_states) HIPCHK(hipMemcpy(out->states, d_states, cnt * 16, hipMemcpyDefault));
+        if (d_boards) HIPCHK(hipMemcpy(out->boards, d_boards, cnt * 84 * sizeof(float), hipMemcpyDefault));
+        HIPCHK(hipMemcpy(out->pis, d_pis, cnt * 7 * sizeof(float), hipMemcpyDefault));
+        HIPCHK(hipMemcpy(out->zs, d_zs, cnt * sizeof(float), hipMemcpyDefault));
+    }
+    if (out->game_len) HIPCHK(hipMemcpy(out->game_len, glen.data(), (size_t)n * sizeof(int32_t), hipMemcpyDefault));
+    if (out->moves) HIPCHK(hipMemcpy(out->moves, gd.moves + (size_t)lo * 42, ns, hipMemcpyDefault));
+    return AZ_OK;
+}
+
+static az_status selfplay_next_impl(az_engine* e, SelfplaySession& ss, int n, az_samples* out) {
+    if (ss.net->generation != ss.net_generation) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay_next: the session's model was changed");
+    const int lo = ss.delivered, hi = lo + n;
+    az_status result = selfplay_run_until(e, ss, hi);
+    harvest_stats(e, *ss.lease, *ss.net);
+    if (result == AZ_OK) result = check_tree_errors(e, *ss.lease);
+    if (result) return result;
+    result = selfplay_emit(e, ss, lo, hi, out);
+    if (result) return result;
+    ss.delivered = hi;
+    if (ss.p.record_evals > 0) {          // the whole session's log so far (rows of unfinished episodes are partial)
+        e->sp_log_cap = ss.p.record_evals;
+        e->sp_log_count.resize((size_t)ss.n_games);
+        HIPCHK(hipMemcpy(e->sp_log_count.data(), ss.gd.g_log_len, (size_t)ss.n_games * sizeof(int32_t), hipMemcpyDeviceToHost));
+        ss.evlog.copy_out(e->sp_log_states, e->sp_log_pi, e->sp_log_v);
+    }
+    return AZ_OK;
+}
+
+az_status az_selfplay_begin(az_engine* e, const az_selfplay_params* p) {
+    if (!e || !p) return AZ_ERR_BAD_ARGUMENT;
+    if (e->sp_session) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay_begin: a session is open (az_selfplay_end first)");
+    try {
+        std::unique_ptr<SelfplaySession> ss;
+        az_status st = selfplay_begin_impl(e, p, ss);
+        if (st) return st;
+        e->sp_session = ss.release();
+        return AZ_OK;
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_selfplay_next(az_engine* e, int32_t n_games, az_samples* out) {
+    if (!e || !out) return AZ_ERR_BAD_ARGUMENT;
+    SelfplaySession* ss = e->sp_session;
+    if (!ss) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay_next: no open session (az_selfplay_begin first)");
+    if (n_games <= 0 || ss->delivered + n_games > ss->n_games) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay_next: more episodes than the session has left");
+    if (out->capacity < 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: negative capacity");
     ScopedTimer timer{e};
     try {
         HIPCHK(hipSetDevice(e->device));
-        hipStream_t s = e->stream;
-        const uint64_t nodes = std::min<uint64_t>(p->reserve, reachable_slots(p->num_sims, AZ_MAX_PLIES));
-        TreeLease lease;
-        if (az_status cs = check_tree_slots(e, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes))) return cs;
-        acquire_trees(e, lease, C, reachable_blocks(p->num_sims, AZ_MAX_PLIES, nodes), nodes, hash_entries(p->num_sims, AZ_MAX_PLIES), T, s);
-        TreeHost& th = *lease;
-        DeviceMem mem;
-        ScopedEvalLog evlog;
-        GamesDev gd{};
-        gd.C = C;
-        gd.n_games = n_games;
-        gd.state = mem.alloc<ulonglong2>(C);
-        gd.player = mem.alloc<int8_t>(C);
-        gd.ply = mem.alloc<int32_t>(C);
-        gd.gid = mem.alloc<int32_t>(C);
-        gd.need_reset = mem.alloc<uint8_t>(C);
-        size_t ns = (size_t)n_games * 42;
-        gd.smp_state = mem.alloc<ulonglong2>(ns);
-        gd.smp_pi = mem.alloc<float>(ns * 7);
-        gd.smp_player = mem.alloc<int8_t>(ns);
-        gd.moves = mem.alloc<uint8_t>(ns);
-        gd.g_len = mem.alloc<int32_t>(n_games);
-        gd.g_result = mem.alloc<float>(n_games);
-        gd.g_final_player = mem.alloc<int8_t>(n_games);
-        gd.counters = mem.alloc<uint32_t>(4);
-        if (p->record_evals > 0) {
-            // per-EPISODE logs (row = the slot's current episode id), so they survive slot refills
-            gd.g_log_len = mem.alloc<int32_t>(n_games);
-            HIPCHK(hipMemset(gd.g_log_len, 0, n_games * sizeof(int32_t)));
-            evlog.attach(th, (size_t)n_games, p->record_evals, gd.gid);
-        }
-        {
-            std::vector<int32_t> gid(C);
-            std::vector<int8_t> pl(C, 1);
-            for (int i = 0; i < C; ++i) gid[i] = i;
-            HIPCHK(hipMemcpy(gd.gid, gid.data(), C * sizeof(int32_t), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(gd.player, pl.data(), C, hipMemcpyHostToDevice));
-            HIPCHK(hipMemset(gd.state, 0, (size_t)C * 16));
-            HIPCHK(hipMemset(gd.ply, 0, C * sizeof(int32_t)));
-            HIPCHK(hipMemset(gd.need_reset, 0, C));
-            HIPCHK(hipMemset(gd.moves, 0, ns));
-            HIPCHK(hipMemset(gd.g_len, 0, n_games * sizeof(int32_t)));
-            uint32_t ctr[4] = {(uint32_t)C, 0u, (uint32_t)C, 0u};
-            HIPCHK(hipMemcpy(gd.counters, ctr, sizeof ctr, hipMemcpyHostToDevice));
-        }
-        launch_reset_trees(th.d, nullptr, s);
-        prepare_cache(e, dedup_applies(e, *net), (uint64_t)n_games * AZ_MAX_PLIES * ((uint64_t)p->num_sims + 1), s);
-        SearchParams sp{(uint32_t)p->max_depth, (float)p->cpuct};
-        SelfplayMoveParams mp{p->seed, p->first_game_id, p->temp_threshold, C < n_games ? 1 : 0};
-        uint32_t* h_ctr = nullptr;
-        HIPCHK(hipHostMalloc((void**)&h_ctr, 4 * sizeof(uint32_t)));
-        struct PinnedFree { uint32_t* p; ~PinnedFree() { (void)hipHostFree(p); } } pinned{h_ctr};
-        uint64_t moves = 0;
-        az_status result = AZ_OK;
-        int active = C;                               // slots still playing (read back after every move)
-        int rows_typ = 0;                             // expected rows per leaf batch (0 = unknown: assume `active`)
-        // "selfplay_async": free-running slots (k_async_step) -- conv nets (anything that goes through leaf batches), one simulation in
-        // flight per tree.  `launches` tree launches share one leaf batch, then the forward runs on it.
-        const bool async_mode = e->selfplay_async != 0 && T == 1 && (net->kind == AZ_NET_CONV || dedup_applies(e, *net)) && p->num_sims >= 1;
-        if (async_mode) {
-            gd.sims = mem.alloc<int32_t>(C);
-            HIPCHK(hipMemsetAsync(gd.sims, 0xFF, (size_t)C * sizeof(int32_t), s));       // -1: no root prepared yet
-            launch_selfplay_sync_active(th.d, gd, s);
-            th.d.block4 = e->tree_block4;
-            const bool dedup = dedup_applies(e, *net);
-            const EvalCache ec = cache_for(e, *net);
-            EvalBatch B[2] = {th.eb, th.eb2};
-            B[0].dedup = B[1].dedup = dedup ? 1 : 0;
-            B[0].max_n = B[1].max_n = gd.counters + 3;
-            const int launches = std::max(1, e->selfplay_async_launches), iters = std::max(2, e->selfplay_async_iters);
-            const int every = std::max(1, e->profile_every);
-            int fill = 0;
-            // every leaf costs a forward at the latest `launches` launches after it was requested; a move needs num_sims + 2 leaves
-            const long long cap_steps = (long long)(AZ_MAX_PLIES + 2) * (n_games / C + 2) * ((long long)p->num_sims + 3) + 64;
-            for (long long step = 0;; ++step) {
-                const bool timed = e->prof.on && (e->profile_tick++ % (uint64_t)every) == 0;
-                for (int j = 0; j < launches; ++j) {
-                    hipEvent_t t0 = nullptr;
-                    if (timed && j == 0) t0 = e->prof.begin(s);
-                    launch_async_step(th.d, gd, B[fill ^ 1], B[fill], ec, sp, mp, p->num_sims, j == 0 ? 1 : 0, iters, s);
-                    if (timed && j == 0) { e->prof.end(t0, RG_TREE, s); e->stats.tree_launches_timed += 1; }
-                    e->stats.tree_launches += 1;
-                }
-                if (mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
-                net_forward(e, *net, B[fill], active, s, rows_typ, timed);
-                fill ^= 1;
-                if ((step & 15) == 15) {                  // look at the counters now and then: finished? how many slots still play?
-                    HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                    HIPCHK(hipStreamSynchronize(s));
-                    resolve_profile(e);
-                    active = std::max(1, (int)h_ctr[2]);
-                    rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)C) : 0;
-                    HIPCHK(hipMemsetAsync(gd.counters + 3, 0, sizeof(uint32_t), s));
-                    if (h_ctr[1] >= (uint32_t)n_games) break;
-                    result = check_tree_errors(e, th);
-                    if (result) break;
-                    if (step > cap_steps) { result = fail(e, AZ_ERR_HIP, "az_selfplay: episode loop did not terminate"); break; }
-                }
-            }
-        } else
-        for (int iter = 0;; ++iter) {
-            launch_selfplay_sync_active(th.d, gd, s);
-            // tile choice from the largest batch of the previous move (de-duplication makes batches much smaller than the
-            // number of searching trees); the grids still cover `active`
-            run_search(e, th, gd.state, p->num_sims, sp, *net, active, nullptr, rows_typ, gd.counters + 3);
-            launch_selfplay_move(th.d, gd, mp, s);
-            if (mp.refill) launch_reset_trees(th.d, gd.need_reset, s);
-            HIPCHK(hipMemcpyAsync(h_ctr, gd.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            resolve_profile(e);
-            ++moves;
-            active = (int)h_ctr[2];
-            rows_typ = h_ctr[3] ? (int)std::min<uint32_t>(h_ctr[3], (uint32_t)(C * T)) : 0;      // this move's largest batch
-            HIPCHK(hipMemsetAsync(gd.counters + 3, 0, sizeof(uint32_t), s));
-            if (h_ctr[1] >= (uint32_t)n_games) break;
-            if ((iter & 7) == 7 || h_ctr[2] == 0) {
-                result = check_tree_errors(e, th);
-                if (result) break;
-            }
-            if (iter > AZ_MAX_PLIES * (n_games / C + 2) + 8) {
-                result = fail(e, AZ_ERR_HIP, "az_selfplay: episode loop did not terminate");
-                break;
-            }
-        }
-        harvest_stats(e, th, *net);
-        if (result == AZ_OK) result = check_tree_errors(e, th);
-        if (result) return result;
-        // offsets (host prefix sum over n_games plies) and emit
-        std::vector<int32_t> glen(n_games);
-        HIPCHK(hipMemcpy(glen.data(), gd.g_len, n_games * sizeof(int32_t), hipMemcpyDeviceToHost));
-        std::vector<int64_t> off(n_games);
-        int64_t total = 0;
-        for (int i = 0; i < n_games; ++i) { off[i] = total; total += glen[i]; }
-        e->stats.games += (uint64_t)n_games;
-        e->stats.moves += (uint64_t)total;
-        e->stats.samples += (uint64_t)total;
-        out->count = total * nsym;
-        if (out->capacity < out->count) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: sample buffers too small");
-        if (out->pis && out->zs) {
-            int64_t* d_off = mem.alloc<int64_t>(n_games);
-            HIPCHK(hipMemcpy(d_off, off.data(), n_games * sizeof(int64_t), hipMemcpyHostToDevice));
-            size_t cnt = (size_t)out->count;
-            ulonglong2* d_states = out->states ? mem.alloc<ulonglong2>(cnt) : nullptr;
-            float* d_boards = out->boards ? mem.alloc<float>(cnt * 84) : nullptr;
-            float* d_pis = mem.alloc<float>(cnt * 7);
-            float* d_zs = mem.alloc<float>(cnt);
-            launch_emit_samples(gd, d_off, p->symmetries, d_states, d_boards, d_pis, d_zs, s);
-            HIPCHK(hipStreamSynchronize(s));
-            if (d_states) HIPCHK(hipMemcpy(out->states, d_states, cnt * 16, hipMemcpyDefault));
-            if (d_boards) HIPCHK(hipMemcpy(out->boards, d_boards, cnt * 84 * sizeof(float), hipMemcpyDefault));
-            HIPCHK(hipMemcpy(out->pis, d_pis, cnt * 7 * sizeof(float), hipMemcpyDefault));
-            HIPCHK(hipMemcpy(out->zs, d_zs, cnt * sizeof(float), hipMemcpyDefault));
-        }
-        if (out->game_len) HIPCHK(hipMemcpy(out->game_len, glen.data(), n_games * sizeof(int32_t), hipMemcpyDefault));
-        if (out->moves) HIPCHK(hipMemcpy(out->moves, gd.moves, ns, hipMemcpyDefault));
-        if (p->record_evals > 0) {
-            const int cap = p->record_evals;
-            e->sp_log_cap = cap;
-            e->sp_log_count.resize(n_games);
-            HIPCHK(hipMemcpy(e->sp_log_count.data(), gd.g_log_len, (size_t)n_games * sizeof(int32_t), hipMemcpyDeviceToHost));
-            evlog.copy_out(e->sp_log_states, e->sp_log_pi, e->sp_log_v);
-        }
-        (void)moves;
-        return AZ_OK;
+        return selfplay_next_impl(e, *ss, n_games, out);
+    } catch (const HipFail& f) { return fail_hip(e, f); }
+}
+
+az_status az_selfplay_end(az_engine* e) {
+    if (!e) return AZ_ERR_BAD_ARGUMENT;
+    if (!e->sp_session) return AZ_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    delete e->sp_session;            // the tree arena goes back to the pool, the per-episode arrays are freed
+    e->sp_session = nullptr;
+    return AZ_OK;
+}
+
+az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out) {
+    if (!e || !p || !out) return AZ_ERR_BAD_ARGUMENT;
+    if (out->capacity < 0) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: negative capacity");
+    if (e->sp_session) return fail(e, AZ_ERR_BAD_ARGUMENT, "az_selfplay: a session is open (az_selfplay_end first)");
+    ScopedTimer timer{e};
+    try {
+        std::unique_ptr<SelfplaySession> ss;
+        az_status st = selfplay_begin_impl(e, p, ss);
+        if (st) return st;
+        st = selfplay_next_impl(e, *ss, ss->n_games, out);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return st;
     } catch (const HipFail& f) { return fail_hip(e, f); }
 }
 

@@ -160,6 +160,7 @@ struct SelfplayMoveParams {
     uint64_t first_game_id;
     int32_t temp_threshold;
     int32_t refill;          // hand finished slots the next episode
+    int32_t done_lo, done_hi; // counters[1] counts the finished episodes with done_lo <= index < done_hi (a session delivers its episodes in chunks)
 };
 
 // arena::play_games state (src/arena.rs:7-99): game g < half is seated (new, old), g >= half (old, new)
@@ -176,6 +177,7 @@ struct ArenaDev {
 };
 
 // ---- launchers (all asynchronous on `s`; dispatch on TreeDev.game to the Game policy's instantiation) ------------------
+void launch_count_done(const int32_t* g_len, int lo, int hi, uint32_t* counter, hipStream_t s);   // *counter = #{lo <= i < hi : g_len[i] > 0}
 void launch_init_heads(const TreeDev& t, hipStream_t s);                      // zero every TreeHead, active = 1
 void launch_set_active(const TreeDev& t, uint32_t value, hipStream_t s);
 void launch_reset_trees(const TreeDev& t, const uint8_t* flags /*[G] or nullptr = all*/, hipStream_t s,

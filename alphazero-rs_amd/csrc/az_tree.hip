@@ -961,7 +961,7 @@ AZ_D int selfplay_move_body(const TreeDev& t, TreeHead& h, const GamesDev& gd, c
             gd.g_final_player[gi] = (int8_t)-player;
             gd.g_len[gi] = ply + 1;
             if (gd.g_log_len) gd.g_log_len[gi] = (int32_t)h.log_len;
-            atomicAdd(&gd.counters[1], 1u);
+            if (gi >= mp.done_lo && gi < mp.done_hi) atomicAdd(&gd.counters[1], 1u);
             int next = -1;
             if (mp.refill) {
                 uint32_t nx = atomicAdd(&gd.counters[0], 1u);
@@ -1263,6 +1263,22 @@ void launch_arena_sync(const TreeDev& t_new, const TreeDev& t_old, const ArenaDe
 }
 void launch_arena_move(const TreeDev& t, const ArenaDev& ad, uint64_t seed, hipStream_t s) {
     AZ_FOR_GAME(t.game, hipLaunchKernelGGL(k_arena_move<TG>, dim3(group_blocks(t.G)), dim3(64), 0, s, t, ad, seed));
+}
+// episodes of [lo, hi) that have already finished (g_len is set when an episode ends): a session's chunk starts its count from here
+__global__ void k_count_done(const int32_t* __restrict__ g_len, int lo, int hi, uint32_t* __restrict__ counter) {
+    __shared__ uint32_t part[256];
+    uint32_t n = 0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) n += g_len[i] > 0 ? 1u : 0u;
+    part[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *counter = part[0];
+}
+void launch_count_done(const int32_t* g_len, int lo, int hi, uint32_t* counter, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_done, dim3(1), dim3(256), 0, s, g_len, lo, hi, counter);
 }
 void launch_emit_samples(const GamesDev& gd, const int64_t* offsets, int symmetries, ulonglong2* out_states,
                          float* out_boards, float* out_pis, float* out_zs, hipStream_t s) {

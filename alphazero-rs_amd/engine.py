@@ -83,7 +83,7 @@ EXPORTS = [
     "az_net_get_params", "az_net_predict", "az_net_predict_states", "az_net_train", "az_net_train_history",
     "az_net_train_begin", "az_net_train_step", "az_net_train_end", "az_tree_create",
     "az_tree_destroy", "az_tree_reset", "az_tree_get_action_prob", "az_tree_record_evals", "az_tree_get_evals",
-    "az_tree_node_counts", "az_selfplay", "az_selfplay_get_evals", "az_arena", "az_arena_get_evals", "az_arena_get_moves",
+    "az_tree_node_counts", "az_selfplay", "az_selfplay_begin", "az_selfplay_next", "az_selfplay_end", "az_selfplay_get_evals", "az_arena", "az_arena_get_evals", "az_arena_get_moves",
     "az_comm_unique_id", "az_comm_init", "az_comm_destroy", "az_gather_samples", "az_allreduce_u64",
 ]
 COMM_ID_BYTES = 128
@@ -126,6 +126,9 @@ def load_library(path=LIB_PATH):
         "az_tree_get_evals": (i32, [vp, vp, vp, vp, vp]),
         "az_tree_node_counts": (i32, [vp, vp]),
         "az_selfplay": (i32, [vp, C.POINTER(az_selfplay_params), C.POINTER(az_samples)]),
+        "az_selfplay_begin": (i32, [vp, C.POINTER(az_selfplay_params)]),
+        "az_selfplay_next": (i32, [vp, C.c_int32, C.POINTER(az_samples)]),
+        "az_selfplay_end": (i32, [vp]),
         "az_selfplay_get_evals": (i32, [vp, vp, vp, vp, vp]),
         "az_arena": (i32, [vp, C.POINTER(az_arena_params), vp, vp]),
         "az_arena_get_evals": (i32, [vp, i32, vp, vp, vp, vp]),
@@ -323,6 +326,43 @@ class Engine:
             if k in out:
                 res[k] = out[k][:n]
         return res
+
+    def selfplay_begin(self, n_games, num_sims, model_id, seed=0, first_game_id=0, concurrent=0, temp_threshold=15, max_depth=1000,
+                       cpuct=1, reserve=1000000, symmetries=True, record_evals=0, num_sim_threads=1):
+        """Opens a self-play session of n_games episodes (az_selfplay_begin): selfplay_next(k) then returns the next k episodes in id
+        order while the slots they freed already play later ones."""
+        p = az_selfplay_params(n_games, concurrent, num_sims, temp_threshold, max_depth, cpuct, model_id,
+                               1 if symmetries else 0, reserve, seed, first_game_id, record_evals, num_sim_threads)
+        self._check(self._lib.az_selfplay_begin(self._h, C.byref(p)))
+        self._sp_sym = bool(symmetries)
+
+    def selfplay_next(self, n_games, want_boards=True, want_states=True, out=None):
+        """The next n_games episodes of the open session: the dict selfplay() returns for the same episodes."""
+        nsym = 2 if self._sp_sym else 1
+        cap = n_games * MAX_PLIES * nsym
+        out = dict(out or {})
+        if "pis" not in out:
+            out["pis"] = np.zeros((cap, ACTIONS), np.float32)
+        if "zs" not in out:
+            out["zs"] = np.zeros(cap, np.float32)
+        if want_states and "states" not in out:
+            out["states"] = np.zeros((cap, 2), np.uint64)
+        if want_boards and "boards" not in out:
+            out["boards"] = np.zeros((cap, 2, 6, 7), np.float32)
+        game_len = np.zeros(n_games, np.int32)
+        moves = np.zeros((n_games, MAX_PLIES), np.uint8)
+        s = az_samples(cap, 0, _as_ptr(out.get("states")), _as_ptr(out.get("boards")), _as_ptr(out["pis"]),
+                       _as_ptr(out["zs"]), _ptr(game_len), _ptr(moves))
+        self._check(self._lib.az_selfplay_next(self._h, n_games, C.byref(s)))
+        n = int(s.count)
+        res = {"count": n, "game_len": game_len, "moves": moves}
+        for k in ("states", "boards", "pis", "zs"):
+            if k in out:
+                res[k] = out[k][:n]
+        return res
+
+    def selfplay_end(self):
+        self._check(self._lib.az_selfplay_end(self._h))
 
     def selfplay_get_evals(self, n_games, cap):
         cnt = np.zeros(n_games, np.int32)

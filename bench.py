@@ -221,6 +221,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--per-call", action="store_true", help="one az_selfplay call per step instead of one session over all steps")
     ap.add_argument("--games", type=int, default=8192, help="concurrent game slots per GPU")
     ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU per step (0 = 8 x --games)")
     ap.add_argument("--sims", type=int, default=100)
@@ -303,10 +304,23 @@ def main():
                         "pis": torch.empty((gcap, 7), dtype=torch.float32, device=dev),
                         "zs": torch.empty(gcap, dtype=torch.float32, device=dev)}
 
+    # One self-play SESSION over the warm-up and the timed steps (az_selfplay_begin / _next / _end): a step fetches the next `episodes`
+    # episodes in id order while the slots they freed already play the following step's -- the slots stay full from step to step, and the
+    # drain of the last slots (6 % of a 65536-episode call) is paid once, inside the last timed step.  --per-call: one az_selfplay call
+    # per step instead (rounds 1-3 and r04b / r04c: every step ramps up and drains on its own).
+    n_steps_total = args.warmup + args.steps
+    session = not args.per_call
+    if session:
+        e.selfplay_begin(n_steps_total * episodes, args.sims, 0, seed=args.seed, first_game_id=rank * n_steps_total * episodes,
+                         concurrent=args.games, symmetries=False)
+
     def step(i):
-        first = (i * world + rank) * episodes          # global game ids: disjoint per (step, rank)
-        r = e.selfplay(n_games=episodes, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
-                       first_game_id=first, symmetries=False, want_boards=False, out=out)
+        if session:
+            r = e.selfplay_next(episodes, want_boards=False, out=out)
+        else:
+            first = (i * world + rank) * episodes          # global game ids: disjoint per (step, rank)
+            r = e.selfplay(n_games=episodes, concurrent=args.games, num_sims=args.sims, model_id=0, seed=args.seed,
+                           first_game_id=first, symmetries=False, want_boards=False, out=out)
         n = r["count"]
         if use_dist:
             _gs, _gp, gz, counts = e.gather_samples(out["states"][:n], out["pis"][:n], out["zs"][:n], dst=0, is_dst=rank == 0, out=gathered)
@@ -327,6 +341,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st_timed = e.stats()
+    if session:
+        e.selfplay_end()
     # the profiled pass (outside the timed region): the same call with the HIP-event brackets on
     prof_s = None
     if not args.no_profile:
@@ -376,6 +392,10 @@ def main():
                        "symmetries": "identity only in the timed region (the mirrored twin of every tuple is regenerated where the tuples are consumed: "
                                      "k_emit_samples' mirror pass is 0.004 % of device time)",
                        "csrc_sha": csrc_sha(),
+                       "session": ("one self-play session over the warm-up and the timed steps (az_selfplay_begin / _next / _end): a step is the next "
+                                   f"{episodes} episodes in id order, the slots stay full from step to step, and the timed region ends with the session's "
+                                   "drain (every episode of every timed step is finished and emitted inside it); --per-call times one az_selfplay call per step")
+                                  if session else "one az_selfplay call per step (--per-call)",
                        "passes": {"timed": f"{args.steps} steps after {args.warmup} warm-up steps, the engine's HIP-event brackets OFF (search loop as hipGraph replays): "
                                            "value, ms_per_step and every */s rate",
                                   "profiled": (f"one more step of the same call afterwards with the brackets ON (every {args.profile_every}th simulation step; "

@@ -295,6 +295,17 @@ typedef struct az_samples {
 } az_samples;
 
 az_status az_selfplay(az_engine* e, const az_selfplay_params* p, az_samples* out);
+/* The same as a SESSION (no reference counterpart: the reference's Coach collects an iteration's episodes from a rayon pool,
+ * src/coach.rs:246-260, in whatever order they finish).  az_selfplay_begin fixes the episodes (p->n_games of them, ids 0 ..
+ * n_games-1, first_game_id / seed as in az_selfplay) and fills the slots; az_selfplay_next(k, out) plays until the NEXT k episodes
+ * in id order have finished and returns exactly the tuples az_selfplay would return for them (an episode depends on its id,
+ * the seed and the net alone) -- while the slots they freed already play later episodes.  A host that fetches its episodes in
+ * chunks (one training-set shard, one bench step at a time) thereby pays the drain of the last slots once per session, not
+ * once per chunk.  az_selfplay_end closes the session (az_destroy does too); one session per engine; the model may not be
+ * changed while it is open.  az_selfplay is begin + next(n_games) + end. */
+az_status az_selfplay_begin(az_engine* e, const az_selfplay_params* p);
+az_status az_selfplay_next(az_engine* e, int32_t n_games, az_samples* out);
+az_status az_selfplay_end(az_engine* e);
 /* Eval log of the last az_selfplay with record_evals > 0: rec_count [n_games], states [n_games,cap,2], ... */
 az_status az_selfplay_get_evals(az_engine* e, int32_t* rec_count, uint64_t* states, float* pis, float* vs);
 

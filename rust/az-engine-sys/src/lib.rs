@@ -85,6 +85,10 @@ extern "C" {
     pub fn az_tree_node_counts(t: *mut az_tree, out: *mut u32) -> c_int;
     // ---- Coach::execute_episode x many, src/coach.rs:104-157; arena::play_games, src/arena.rs:62-99
     pub fn az_selfplay(e: *mut az_engine, p: *const az_selfplay_params, out: *mut az_samples) -> c_int;
+    // the same as a session: the slots stay full across the calls that fetch the episodes (no drain per chunk)
+    pub fn az_selfplay_begin(e: *mut az_engine, p: *const az_selfplay_params) -> c_int;
+    pub fn az_selfplay_next(e: *mut az_engine, n_games: i32, out: *mut az_samples) -> c_int;
+    pub fn az_selfplay_end(e: *mut az_engine) -> c_int;
     pub fn az_selfplay_get_evals(e: *mut az_engine, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;
     pub fn az_arena(e: *mut az_engine, p: *const az_arena_params, out_wld: *mut u64, results: *mut i8) -> c_int;
     pub fn az_arena_get_evals(e: *mut az_engine, which: i32, rec_count: *mut i32, states: *mut u64, pis: *mut f32, vs: *mut f32) -> c_int;

@@ -514,6 +514,34 @@ def test_free_running_selfplay_plays_the_same_games(engine, oracle):
         engine.set_option("selfplay_async_iters", 6)
 
 
+def test_selfplay_session_with_the_conv_net(engine, oracle):
+    """The session form (az_selfplay_begin / _next / _end) with the bf16 net, tables, de-duplication and the cache on: 3,072 episodes on
+    1,024 slots fetched as three chunks are tuple for tuple the one-shot call's, with the lock-step and the free-running driver, and every
+    episode of the chunked run replays on the oracle from its own recorded rows (the log is the session's, per episode)."""
+    engine.net_init_random(31, seed=16)
+    n, conc, sims, seed = 3072, 1024, 100, 77
+    cap = 42 * (sims + 1) + 8
+    ref = engine.selfplay(n_games=n, concurrent=conc, num_sims=sims, model_id=31, seed=seed, want_boards=False)
+    try:
+        for mode in (0, 1):
+            engine.set_option("selfplay_async", mode)
+            engine.reset_stats()
+            engine.selfplay_begin(n, sims, 31, seed=seed, concurrent=conc, record_evals=cap if mode == 0 else 0)
+            parts = [engine.selfplay_next(k, want_boards=False) for k in (1024, 1000, 1048)]
+            evals = engine.selfplay_get_evals(n, cap) if mode == 0 else None
+            engine.selfplay_end()
+            st = engine.stats()
+            got = {k: np.concatenate([q[k] for q in parts]) for k in ("game_len", "moves", "states", "pis", "zs")}
+            got["count"] = sum(q["count"] for q in parts)
+            assert st["games"] == n and st["simulations"] == sims * int(got["game_len"].sum())
+            for k in ("game_len", "moves", "states", "pis", "zs"):
+                assert np.array_equal(got[k], ref[k]), (mode, k)
+            if evals is not None:
+                _replay_every_episode(oracle, got, evals, sims, seed, n)
+    finally:
+        engine.set_option("selfplay_async", 0)
+
+
 def test_replay_parity_lockstep_threads_with_the_conv_net(engine, oracle):
     """Several simulations in flight per tree (num_sim_threads = 4: the lock-step schedule of DESIGN.md 4.1a) with the real bf16 net,
     tables, de-duplication and the evaluation cache on, 2,048 slots x 4 threads = up to 8,192 rows per step, with slot refill: the

@@ -171,6 +171,37 @@ def test_selfplay_shard_invariance(engine, oracle):
     assert np.array_equal(full["states"], np.concatenate([lo["states"], hi["states"]]))
 
 
+def test_selfplay_session_delivers_the_same_episodes_in_chunks(engine, oracle, engine_mod):
+    """az_selfplay_begin / _next / _end: the slots stay full across the calls that fetch the episodes.  A chunk is exactly what
+    az_selfplay returns for the same episode ids (and so what the oracle's execute_episode plays), whatever the chunk sizes, the
+    slot count and the order in which the episodes happened to finish; the session's misuse is refused."""
+    n, sims = 160, 25
+    ref = oracle.selfplay(n, sims, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=8, threads=8)
+    whole = engine.selfplay(n_games=n, num_sims=sims, model_id=10, seed=8, concurrent=24)
+    _compare_selfplay(whole, ref)
+    for concurrent, chunks in ((24, (40, 40, 40, 40)), (24, (1, 7, 100, 52)), (160, (80, 80)), (5, (159, 1))):
+        engine.selfplay_begin(n, sims, 10, seed=8, concurrent=concurrent)
+        parts = [engine.selfplay_next(k) for k in chunks]
+        with pytest.raises(engine_mod.AzError):
+            engine.selfplay_next(1)                                  # nothing left
+        engine.selfplay_end()
+        assert sum(q["count"] for q in parts) == whole["count"]
+        for key in ("pis", "zs", "states", "boards", "game_len", "moves"):
+            assert np.array_equal(np.concatenate([q[key] for q in parts]), whole[key]), (concurrent, chunks, key)
+    with pytest.raises(engine_mod.AzError):
+        engine.selfplay_next(1)                                      # no session
+    engine.selfplay_begin(16, sims, 10, seed=8)
+    with pytest.raises(engine_mod.AzError):
+        engine.selfplay_begin(16, sims, 10, seed=8)                  # one session per engine
+    with pytest.raises(engine_mod.AzError):
+        engine.selfplay(n_games=4, num_sims=sims, model_id=10)       # ... and no one-shot call beside it
+    a = engine.selfplay_next(16)
+    engine.selfplay_end()
+    engine.selfplay_end()                                            # idempotent
+    b = engine.selfplay(n_games=16, num_sims=sims, model_id=10, seed=8)
+    assert np.array_equal(a["pis"], b["pis"]) and np.array_equal(a["moves"], b["moves"])
+
+
 def test_selfplay_no_symmetries_and_temp_threshold(engine, oracle):
     got = engine.selfplay(n_games=16, num_sims=25, model_id=10, seed=3, symmetries=False, temp_threshold=4)
     ref = oracle.selfplay(16, 25, net_kind=oracle.NET_HASH, salt=oracle_salt(10), seed=3, temp_threshold=4, threads=8)
