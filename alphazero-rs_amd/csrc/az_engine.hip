@@ -302,7 +302,7 @@ struct az_engine {
     int search_graph_rows = 1024;   // "search_graph_rows": ... for searches whose expected leaf batch has at most this many rows (the arena, a drain, single trees)
     int fused_search = 1;           // stub / hash nets: the whole search in one launch ("fused_search"; 0 = one launch per simulation)
     int eval_dedup = 1;             // 0 off, 1 conv nets (default), 2 every net (lets the hash fixture exercise the machinery)
-    int eval_cache_log2 = 27;       // entries = 2^log2 (40 B each: 5.4 GB); 0 = no cache, in-batch de-duplication only
+    int eval_cache_log2 = 30;       // entries = 2^log2 (40 B each: 43 GB); 0 = no cache, in-batch de-duplication only
     int eval_cache_max_stones = 42;
     int eval_cache_persist = 0;     // 0: az_selfplay / az_arena / az_tree_get_action_prob start from an empty cache
     DeviceMem cache_mem;            // the accounting counters
@@ -388,7 +388,7 @@ bool dedup_applies(const az_engine* e, const NetModel& net) {
 
 // The engine's evaluation cache.  Sized FROM THE CALL: a search call can insert at most `inserts_bound` distinct states (trees x
 // get_action_prob calls x (sims + 1)), so it gets the smallest power of two >= 4 x that bound (8-way buckets stay sparse), at most
-// 2^"eval_cache_log2" entries (40 bytes each; 5.4 GB at the default 27, which only a bench-sized call reaches) -- a 1-tree, 25-sim
+// 2^"eval_cache_log2" entries (40 bytes each; 43 GB at the default 30, which only a bench-sized call reaches) -- a 1-tree, 25-sim
 // call allocates and clears 40 KB.  The allocation only grows; a smaller call uses (and clears) a prefix of it.  With
 // "eval_cache_persist" entries must stay findable across calls, so the cache then has its full configured size from the start.
 void prepare_cache(az_engine* e, bool wanted, uint64_t inserts_bound, hipStream_t s) {
@@ -791,7 +791,7 @@ az_status az_set_option(az_engine* e, const char* key, int64_t value) {
     if (is("selfplay_async_iters") && value >= 2 && value <= 64) { e->selfplay_async_iters = (int)value; return AZ_OK; }
     if (is("fused_search") && (value == 0 || value == 1)) { e->fused_search = (int)value; return AZ_OK; }
     if (is("eval_dedup") && value >= 0 && value <= 2) { e->eval_dedup = (int)value; return AZ_OK; }
-    if (is("eval_cache_log2") && (value == 0 || (value >= 10 && value <= 28))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
+    if (is("eval_cache_log2") && (value == 0 || (value >= 10 && value <= 30))) { e->eval_cache_log2 = (int)value; return AZ_OK; }
     if (is("eval_cache_max_stones") && value >= 0 && value <= 42) { e->eval_cache_max_stones = (int)value; return AZ_OK; }
     if (is("eval_cache_persist") && (value == 0 || value == 1)) { e->eval_cache_persist = (int)value; return AZ_OK; }
     // NNet::train hyper-parameters (defaults = connect_four_net.py:13-15, :21)

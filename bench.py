@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--no-train-probe", action="store_true", help="skip the NNet::train throughput probe (auxiliary field)")
     ap.add_argument("--conv2-table", type=int, default=1, choices=[0, 1], help="conv1 + conv2 as table lookups (default) / 0 = conv2 as the MFMA implicit GEMM")
     ap.add_argument("--dedup", type=int, default=1, choices=[0, 1], help="leaf de-duplication + per-call evaluation cache (bit-exact); 0 = every requested row runs")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="az_set_option on the timed engine (experiments; named in config.options)")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and run the gather even at world size 1 (rehearsal)")
     ap.add_argument("--dry-dist", default="", choices=["", "gloo"],
                     help="rehearse the N-rank launcher + gather on CPU over gloo with synthetic tuples (no engine, no GPU; value = 0)")
@@ -275,6 +276,9 @@ def main():
     e.set_option("eval_dedup", args.dedup)
     e.set_option("profile_every", args.profile_every)
     e.set_option("conv2_table", args.conv2_table)
+    for kv in args.set:
+        k, v = kv.split("=")
+        e.set_option(k, int(v))
     if args.net == "conv":
         e.net_init_random(0, seed=args.seed)       # identical weights on every rank (replicated, 21.5 MB bf16)
     else:
@@ -392,6 +396,7 @@ def main():
                        "symmetries": "identity only in the timed region (the mirrored twin of every tuple is regenerated where the tuples are consumed: "
                                      "k_emit_samples' mirror pass is 0.004 % of device time)",
                        "csrc_sha": csrc_sha(),
+                       "options": args.set or None,
                        "session": ("one self-play session over the warm-up and the timed steps (az_selfplay_begin / _next / _end): a step is the next "
                                    f"{episodes} episodes in id order, the slots stay full from step to step, and the timed region ends with the session's "
                                    "drain (every episode of every timed step is finished and emitted inside it); --per-call times one az_selfplay call per step")
@@ -401,6 +406,11 @@ def main():
                                   "profiled": (f"one more step of the same call afterwards with the brackets ON (every {args.profile_every}th simulation step; "
                                                f"{prof_s:.2f} s): roofline, kernels, conv2_table, tree_hbm") if prof_s is not None else None,
                                   "gather": "az_comm_init + az_gather_samples (RCCL on the engine's stream, through the C ABI) inside the timed step" if use_dist else None}},
+            # the same batch as ONE az_selfplay call (the profiled pass: its own ramp and drain, an empty evaluation cache; HIP-event brackets on
+            # every 64th simulation step cost it ~0.3 %): what rounds 1-3 reported as `value`, and what a session is measured against
+            "per_call": ({"games_per_sec": episodes * world / prof_s, "seconds": prof_s, "episodes_per_gpu": episodes,
+                          "executed_over_requested": st_prof["leaf_rows_executed"] / max(1, st_prof["leaf_rows_requested"]),
+                          "note": "rank 0's profiled az_selfplay call of one step's episodes x n_gpus"} if prof_s is not None else None),
             "node_expansions_per_sec": expansions / dt, "simulations_per_sec": simulations / dt,
             "leaf_evals_per_sec": leaf_evals / dt, "mean_plies": plies_all / games,
             # leaf de-duplication (bit-exact, az_engine.h "eval_dedup"): the trees REQUEST leaf_evals rows, the net EXECUTES

@@ -159,9 +159,12 @@ const char* az_last_error(const az_engine* e);
  *   leaf de-duplication (bit-exact: a row's (pi, v) depends on its state alone; the reference's per-tree analogue is `seen`,
  *   src/node.rs:282-289)
  *            "eval_dedup"   0 off / 1 conv nets (default) / 2 every net: each distinct state of a leaf batch is evaluated once
- *            "eval_cache_log2"  upper bound of log2 entries of the engine's evaluation cache (default 27, 0 = none, 10..28; 40 bytes per
- *                           entry).  A call allocates and clears only what ITS games can fill (4 x its bound on inserted rows,
- *                           at least 2^10): a 1-tree, 25-simulation call touches 40 KB, not the 5.4 GB of the full table
+ *            "eval_cache_log2"  upper bound of log2 entries of the engine's evaluation cache (default 30, 0 = none, 10..30; 40 bytes per
+ *                           entry).  A call (or session) allocates and clears only what ITS games can fill (4 x its bound on
+ *                           inserted rows, at least 2^10): a 1-tree, 25-simulation call touches 40 KB, a call of 8192 episodes
+ *                           11 GB, and only bench-sized ones (65536 episodes and more) the full 43 GB -- a seventh of the
+ *                           device's 288 GB, and worth it: a self-play session of 1.6 M episodes runs at 10.6 k games/s with
+ *                           2^30 entries and at 7.9 k with 2^27, whose table is full after a fifth of it
  *            "eval_cache_max_stones"  only states with at most that many stones are cached (default 42)
  *            "eval_cache_persist"  0 (default): every az_selfplay / az_arena / az_tree_get_action_prob call starts from an empty cache;
  *                           1: entries live until the model's weights change (the full "eval_cache_log2" table)

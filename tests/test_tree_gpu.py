@@ -637,7 +637,7 @@ def test_dedup_counters_and_cache_corner_cases(engine, oracle, dedup_mode):
         _compare_selfplay(got, ref2)
     finally:
         engine.net_set_kind(10, 1, HASH_SALT)
-        engine.set_option("eval_cache_log2", 27)
+        engine.set_option("eval_cache_log2", 30)
         engine.set_option("eval_cache_max_stones", 42)
         engine.set_option("eval_cache_persist", 0)
         engine.set_option("search_graph", 20)
