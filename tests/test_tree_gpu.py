@@ -188,6 +188,13 @@ def test_selfplay_session_delivers_the_same_episodes_in_chunks(engine, oracle, e
         assert sum(q["count"] for q in parts) == whole["count"]
         for key in ("pis", "zs", "states", "boards", "game_len", "moves"):
             assert np.array_equal(np.concatenate([q[key] for q in parts]), whole[key]), (concurrent, chunks, key)
+    # several simulations in flight per tree (the lock-step schedule), chunked: the same episodes as the one-shot call
+    whole4 = engine.selfplay(n_games=48, num_sims=24, model_id=10, seed=5, concurrent=16, num_sim_threads=4)
+    engine.selfplay_begin(48, 24, 10, seed=5, concurrent=16, num_sim_threads=4)
+    parts = [engine.selfplay_next(k) for k in (10, 38)]
+    engine.selfplay_end()
+    for key in ("pis", "zs", "game_len", "moves"):
+        assert np.array_equal(np.concatenate([q[key] for q in parts]), whole4[key]), key
     with pytest.raises(engine_mod.AzError):
         engine.selfplay_next(1)                                      # no session
     engine.selfplay_begin(16, sims, 10, seed=8)
