@@ -1,5 +1,6 @@
-// az_train.hip -- NNet::train (src/nnet.rs:38) as HIP kernels for gfx950: f32 state, forward GEMMs on the f32 matrix cores, backward
-// GEMMs as bf16 x 3 on the bf16 matrix cores (second half of this file).
+// az_train.hip -- NNet::train (src/nnet.rs:38) as HIP kernels for gfx950: f32 state; by default the forward GEMMs of conv2..conv4 as
+// f16 x 3 on the f16 matrix cores and the backward GEMMs as bf16 x 3 on the bf16 matrix cores (second half of this file: k_gemm3,
+// k_gemm3_ring, k_wgrad3_tr, the gathered-operand forms), conv1 and the FC forward on the f32 matrix cores; "train_gemm" 0: every GEMM f32.
 //
 // Recipe (the reference's Python net, connect_four_net.py; only its hyper-parameters and layer list are taken,
 // the TF1 code itself is broken -- SURVEY.md B11): loss = softmax cross-entropy(pi) + mean squared error(v)
@@ -13,7 +14,7 @@
 //
 // Parameters, activations (row-major [rows][channels], rows = (sample, y, x)), gradients and the optimiser state are f32; k_gemm_f32
 // (v_mfma_f32_16x16x4_f32, 64 x 64 or 128 x 128 block tiles, deterministic split-K) runs the forward GEMMs and, with "train_gemm" = 0,
-// every GEMM.  At the reference's batch of 64 a step is ~63 GFLOP over ~75 launches of 5 - 150 us.
+// every GEMM.  At the reference's batch of 64 a step is ~63 GFLOP over 59 launches of 5 - 50 us.
 #include "az_train.h"
 
 #include <algorithm>
@@ -322,11 +323,13 @@ void launch_splitk_reduce(const float* partial, int splits, int M, int N, float*
 // Both operands must be contiguous along the contraction:
 //     dgrad     dA = dz W^T    dz [M][N] (written split by k_bn_bwd_apply), W [K][N] as stored (k_split_weights)
 //     wgrad     dW = A^T dz    A^T [K][M'] and dz^T [N][M'] (k_transpose_split: f32 in, hi / lo out; M' = M rounded up to 64, zero-filled)
-// THE FORWARD GEMMS STAY ON THE f32 KERNEL: a 2^-17 error in a pre-activation flips the ReLU (and the dropout-free BatchNorm sign) of the
+// THE FORWARD GEMMS ARE NOT bf16 x 3: a 2^-17 error in a pre-activation flips the ReLU (and the dropout-free BatchNorm sign) of the
 // elements that lie that close to zero -- about one of fc2's 32 k activations per step and a few dozen per conv layer -- and ONE flip in an
 // FC layer moves every upstream gradient tensor by ~3e-4 (tools/train_check.py: the forward as bf16 x 3 measured 3e-3 against float64
-// autograd at batch 64, the f32 forward 1e-6).  The backward pass has no such discontinuity: its GEMMs' 1e-5 stays 1e-5.
-// conv1 (K = 18) stays on the f32 kernel too.  Measured error of a step's gradients against float64 autograd: DESIGN.md section 8.
+// autograd at batch 64, the f32 forward 1e-6).  The backward pass has no such discontinuity: its GEMMs' 1e-5 stays 1e-5.  Round 3 kept the
+// forward on the f32 kernel; since round 4 conv2..conv4 run it as f16 x 3 (split_f16 below: 2^-22, the f32 kernel's own grade, with
+// the operands scaled into half's NORMAL range -- the matrix cores treat half subnormals as zero).  conv1 (K = 18) and the FC layers
+// (64 rows) stay on the f32 kernel.  Measured error of a step's gradients against float64 autograd: DESIGN.md section 8.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 AZ_D uint16_t bf16_rne(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
