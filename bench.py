@@ -247,6 +247,12 @@ def main():
         # N ranks as children of torch.distributed.run and relays their output and exit code
         raise SystemExit(self_launch(args.gpus))
 
+    # Libraries write banners to the process's stdout (RCCL's version block at communicator creation, for one): everything but the ONE
+    # JSON line goes to stderr -- file descriptor 1 points at stderr until the line is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -255,6 +261,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.dry_dist:
+        os.dup2(stdout_fd, 1)
         return dry_dist(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -649,7 +656,10 @@ def main():
                 line["config1_dropin"] = config1_dropin()
             except Exception as ex:
                 line["config1_dropin"] = {"error": repr(ex)}
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     e.close()
     if use_dist:
         dist.destroy_process_group()
